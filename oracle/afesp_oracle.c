@@ -1,0 +1,613 @@
+/*
+ * afesp_oracle.c -- CPU restatement of the AFESP coupled-cluster hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (the HIP library under
+ * a-fortran-electronic-structure-program_amd/csrc, the Fortran host, the Python
+ * binding) links, loads or calls this file.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may use it, and there only as the checker.
+ *
+ * It restates, in plain C loops, the algorithm of the reference
+ * (brianz98/A-Fortran-Electronic-Structure-Program, citations are file:line into
+ * /root/reference/src):
+ *   packed 8-fold ERI index ........ integrals.f90:187-210
+ *   AO->MO four quarter transforms . mp2.f90:321-386, repack :388-410
+ *   MP2 energy ..................... mp2.f90:418-440
+ *   denominators, slices, MP1 guess  ccsd.f90:436-445, :496-521
+ *   spin-free CCSD intermediates ... ccsd.f90:1040-1312 (plain-loop form :1334-1454)
+ *   spin-free CCSD amplitudes ...... ccsd.f90:1538-1732 (plain-loop form :1487-1530)
+ *   energy / rms / convergence ..... ccsd.f90:1764-1782, :1803-1806
+ *   DIIS ........................... ccsd.f90:577-676, linalg.fpp:38-56
+ *   (T): W, t3, z3, x_bar, sums .... ccsd.f90:2152-2237, :2295-2318
+ *   R-CCSD denominators ............ ccsd.f90:2181-2185, :2228-2247
+ *
+ * Parity pin: tests/test_oracle_golden.py runs this restatement on the reference's
+ * bundled N2 and F2 cc-pVDZ inputs and checks it against the reference's own bundled
+ * outputs (tests/golden/<system>/els.out: every CCSD iteration energy to 12 decimals,
+ * MP2, CCSD, CCSD[T], CCSD(T), R-CCSD[T]/(T), D[T], D(T) to 10 decimals).
+ *
+ * All tensors are Fortran column-major, first index fastest, virtual indices 0..v-1.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef int64_t i64;
+
+/* ---------------------------------------------------------------- packed index */
+/* integrals.f90:196-210 (1-based there; 0-based here: tri(i,j)=i(i+1)/2+j, i>=j) */
+static inline i64 tri(i64 i, i64 j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+i64 orc_npair(i64 n) { return n * (n + 1) / 2; }
+i64 orc_neri(i64 n) { i64 np = orc_npair(n); return np * (np + 1) / 2; } /* integrals.f90:175-176 */
+i64 orc_eri_index(i64 i, i64 j, i64 k, i64 l) { return tri(tri(i, j), tri(k, l)); }
+
+/* ---------------------------------------------------------------- AO -> MO */
+/* mp2.f90:321-386: (pq|rs) = sum C(p,i) C(q,j) C(r,k) C(s,l) (ij|kl), C is (MO,AO)
+ * column-major, i.e. C[p + n*i].  Output is the full n^4 tensor mo[p + n*(q + n*(r + n*s))]. */
+static void quarter(i64 n, const double *C, const double *in, double *out)
+{
+    /* out(p, rest) = sum_i C(p,i) in(i, rest) and then rotate so the transformed index
+     * goes last: out2(rest, p).  Doing that four times transforms all four indices and
+     * restores the original index order. */
+    i64 n3 = n * n * n;
+#pragma omp parallel for schedule(static)
+    for (i64 r = 0; r < n3; ++r) {
+        const double *col = in + r * n;
+        for (i64 p = 0; p < n; ++p) {
+            double s = 0.0;
+            for (i64 i = 0; i < n; ++i) s += C[p + n * i] * col[i];
+            out[r + n3 * p] = s;
+        }
+    }
+}
+
+void orc_unpack_eri(i64 n, const double *packed, double *full)
+{
+#pragma omp parallel for schedule(static)
+    for (i64 l = 0; l < n; ++l)
+        for (i64 k = 0; k < n; ++k)
+            for (i64 j = 0; j < n; ++j)
+                for (i64 i = 0; i < n; ++i)
+                    full[i + n * (j + n * (k + n * l))] = packed[orc_eri_index(i, j, k, l)];
+}
+
+/* mp2.f90:388-410 canonical order: p>=q, r<=p, s<=(q if r==p else r) == packed order */
+void orc_pack_eri(i64 n, const double *full, double *packed)
+{
+    i64 pqrs = 0;
+    for (i64 p = 0; p < n; ++p)
+        for (i64 q = 0; q <= p; ++q)
+            for (i64 r = 0; r <= p; ++r) {
+                i64 sup = (r == p) ? q : r;
+                for (i64 s = 0; s <= sup; ++s)
+                    packed[pqrs++] = full[s + n * (r + n * (q + n * p))];
+            }
+}
+
+void orc_ao2mo(i64 n, const double *C, const double *eri_packed, double *eri_mo_packed)
+{
+    i64 n4 = n * n * n * n;
+    double *a = (double *)malloc(sizeof(double) * n4);
+    double *b = (double *)malloc(sizeof(double) * n4);
+    orc_unpack_eri(n, eri_packed, a);
+    quarter(n, C, a, b);
+    quarter(n, C, b, a);
+    quarter(n, C, a, b);
+    quarter(n, C, b, a);
+    orc_pack_eri(n, a, eri_mo_packed);
+    free(a);
+    free(b);
+}
+
+/* mp2.f90:418-440 */
+double orc_mp2_energy(i64 n, i64 o, const double *eri_mo, const double *e)
+{
+    double emp = 0.0;
+    for (i64 i = 0; i < o; ++i)
+        for (i64 j = 0; j < o; ++j)
+            for (i64 a = o; a < n; ++a)
+                for (i64 b = o; b < n; ++b) {
+                    double iajb = eri_mo[orc_eri_index(i, a, j, b)];
+                    double ibja = eri_mo[orc_eri_index(i, b, j, a)];
+                    emp += iajb * (2.0 * iajb - ibja) / (e[i] + e[j] - e[a] - e[b]);
+                }
+    return emp;
+}
+
+/* ---------------------------------------------------------------- CCSD state */
+typedef struct {
+    i64 o, v;
+    double *e;                                   /* n orbital energies */
+    double *v_oovv, *v_ovov, *v_vvov, *v_oovo, *v_oooo, *v_vvvv;
+    double *D1, *D2;
+    double *t1, *t2, *t2_old;
+    /* intermediates */
+    double *I_vo, *I_vv, *I_oo_p, *I_oo, *c, *asym, *x_voov, *I_oooo, *I_ovov, *I_voov, *I_vovv_p, *I_ooov_p;
+    double *r1, *r2;
+    double energy, energy_old, rms;
+    /* DIIS (ccsd.f90:38-67) */
+    int nerr, nact, it;
+    double *d_t1, *d_e1, *d_t2, *d_e2, *t1_s, *t2_s;
+} orc_cc;
+
+#define O (s->o)
+#define V (s->v)
+#define T1(i, a) s->t1[(i) + O * (a)]
+#define T2(i, j, a, b) s->t2[(i) + O * ((j) + O * ((a) + V * (b)))]
+#define OOVV(i, j, a, b) s->v_oovv[(i) + O * ((j) + O * ((a) + V * (b)))]
+#define OVOV(i, a, j, b) s->v_ovov[(i) + O * ((a) + V * ((j) + O * (b)))]
+#define VVOV(a, b, i, c) s->v_vvov[(a) + V * ((b) + V * ((i) + O * (c)))]
+#define OOVO(i, j, a, k) s->v_oovo[(i) + O * ((j) + O * ((a) + V * (k)))]
+#define OOOO(i, j, k, l) s->v_oooo[(i) + O * ((j) + O * ((k) + O * (l)))]
+#define VVVV(a, b, c, d) s->v_vvvv[(a) + V * ((b) + V * ((c) + V * (d)))]
+#define CC(i, j, a, b) s->c[(i) + O * ((j) + O * ((a) + V * (b)))]
+#define AS(i, j, a, b) s->asym[(i) + O * ((j) + O * ((a) + V * (b)))]
+#define IVO(a, i) s->I_vo[(a) + V * (i)]
+#define IVV(a, b) s->I_vv[(a) + V * (b)]
+#define IOOP(i, j) s->I_oo_p[(i) + O * (j)]
+#define IOO(i, j) s->I_oo[(i) + O * (j)]
+#define IOOOO(i, j, k, l) s->I_oooo[(i) + O * ((j) + O * ((k) + O * (l)))]
+#define IOVOV(i, a, j, b) s->I_ovov[(i) + O * ((a) + V * ((j) + O * (b)))]
+#define IVOOV(a, i, j, b) s->I_voov[(a) + V * ((i) + O * ((j) + O * (b)))]
+#define XVOOV(a, i, j, b) s->x_voov[(a) + V * ((i) + O * ((j) + O * (b)))]
+#define IVOVV(c, i, a, b) s->I_vovv_p[(c) + V * ((i) + O * ((a) + V * (b)))]
+#define IOOOV(i, j, k, a) s->I_ooov_p[(i) + O * ((j) + O * ((k) + O * (a)))]
+#define R1(i, a) s->r1[(i) + O * (a)]
+#define R2(i, j, a, b) s->r2[(i) + O * ((j) + O * ((a) + V * (b)))]
+
+static double *dalloc(i64 n) { return (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double)); }
+
+/* ccsd.f90:404-575 init_cc (restricted branch): denominators, physicist slices from the
+ * packed chemist MO integrals, <pq|rs> = (pr|qs) (:501), t1 = 0, t2 = v_oovv / D (:520-521). */
+orc_cc *orc_cc_create(i64 o, i64 v, const double *eri_mo, const double *e, int diis_nerr)
+{
+    orc_cc *s = (orc_cc *)calloc(1, sizeof(orc_cc));
+    i64 n = o + v, o2v2 = o * o * v * v;
+    s->o = o; s->v = v;
+    s->e = dalloc(n); memcpy(s->e, e, sizeof(double) * n);
+    s->v_oovv = dalloc(o2v2); s->v_ovov = dalloc(o2v2);
+    s->v_vvov = dalloc(o * v * v * v); s->v_oovo = dalloc(o * o * o * v);
+    s->v_oooo = dalloc(o * o * o * o); s->v_vvvv = dalloc(v * v * v * v);
+    s->D1 = dalloc(o * v); s->D2 = dalloc(o2v2);
+    s->t1 = dalloc(o * v); s->t2 = dalloc(o2v2); s->t2_old = dalloc(o2v2);
+    s->I_vo = dalloc(o * v); s->I_vv = dalloc(v * v); s->I_oo_p = dalloc(o * o); s->I_oo = dalloc(o * o);
+    s->c = dalloc(o2v2); s->asym = dalloc(o2v2); s->x_voov = dalloc(o2v2);
+    s->I_oooo = dalloc(o * o * o * o); s->I_ovov = dalloc(o2v2); s->I_voov = dalloc(o2v2);
+    s->I_vovv_p = dalloc(o * v * v * v); s->I_ooov_p = dalloc(o * o * o * v);
+    s->r1 = dalloc(o * v); s->r2 = dalloc(o2v2);
+#define PHYS(p, q, r, t) eri_mo[orc_eri_index((p), (r), (q), (t))]
+    for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) for (i64 j = 0; j < o; ++j) for (i64 i = 0; i < o; ++i) {
+        OOVV(i, j, a, b) = PHYS(i, j, a + o, b + o);
+        s->D2[i + o * (j + o * (a + v * b))] = e[i] + e[j] - e[a + o] - e[b + o];
+    }
+    for (i64 b = 0; b < v; ++b) for (i64 j = 0; j < o; ++j) for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i)
+        OVOV(i, a, j, b) = PHYS(i, a + o, j, b + o);
+    for (i64 c = 0; c < v; ++c) for (i64 i = 0; i < o; ++i) for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a)
+        VVOV(a, b, i, c) = PHYS(a + o, b + o, i, c + o);
+    for (i64 k = 0; k < o; ++k) for (i64 a = 0; a < v; ++a) for (i64 j = 0; j < o; ++j) for (i64 i = 0; i < o; ++i)
+        OOVO(i, j, a, k) = PHYS(i, j, a + o, k);
+    for (i64 l = 0; l < o; ++l) for (i64 k = 0; k < o; ++k) for (i64 j = 0; j < o; ++j) for (i64 i = 0; i < o; ++i)
+        OOOO(i, j, k, l) = PHYS(i, j, k, l);
+#pragma omp parallel for schedule(static)
+    for (i64 d = 0; d < v; ++d) for (i64 c = 0; c < v; ++c) for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a)
+        VVVV(a, b, c, d) = PHYS(a + o, b + o, c + o, d + o);
+#undef PHYS
+    for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i) s->D1[i + o * a] = e[i] - e[a + o];
+    for (i64 x = 0; x < o2v2; ++x) s->t2[x] = s->v_oovv[x] / s->D2[x];
+    /* init_diis_cc_t ccsd.f90:577-615 */
+    s->nerr = diis_nerr; s->nact = 0; s->it = 0;
+    if (diis_nerr >= 2) {
+        s->d_t1 = dalloc(o * v * diis_nerr); s->d_e1 = dalloc(o * v * diis_nerr);
+        s->d_t2 = dalloc(o2v2 * diis_nerr); s->d_e2 = dalloc(o2v2 * diis_nerr);
+        s->t1_s = dalloc(o * v); s->t2_s = dalloc(o2v2);
+    }
+    return s;
+}
+
+void orc_cc_destroy(orc_cc *s)
+{
+    if (!s) return;
+    double *p[] = {s->e, s->v_oovv, s->v_ovov, s->v_vvov, s->v_oovo, s->v_oooo, s->v_vvvv, s->D1, s->D2, s->t1, s->t2,
+                   s->t2_old, s->I_vo, s->I_vv, s->I_oo_p, s->I_oo, s->c, s->asym, s->x_voov, s->I_oooo, s->I_ovov,
+                   s->I_voov, s->I_vovv_p, s->I_ooov_p, s->r1, s->r2, s->d_t1, s->d_e1, s->d_t2, s->d_e2, s->t1_s, s->t2_s};
+    for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); ++i) free(p[i]);
+    free(s);
+}
+
+/* ccsd.f90:1040-1312 (equations as the plain loops of :1334-1454; asym_t2 is built FIRST, :1063) */
+void orc_cc_intermediates(orc_cc *s)
+{
+    const i64 o = O, v = V;
+#pragma omp parallel
+    {
+#pragma omp for collapse(2) schedule(static)
+    for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) for (i64 j = 0; j < o; ++j) for (i64 i = 0; i < o; ++i) {
+        AS(i, j, a, b) = 2.0 * T2(i, j, a, b) - T2(j, i, a, b);          /* :1063-1064 */
+        CC(i, j, a, b) = T2(i, j, a, b) + T1(i, a) * T1(j, b);            /* :1071-1079 */
+    }
+    /* I_vo(a,i) = (2<im|ae> - <im|ea>) t(m,e)   :1085-1092 */
+#pragma omp for collapse(2) schedule(static)
+    for (i64 i = 0; i < o; ++i) for (i64 a = 0; a < v; ++a) {
+        double x = 0.0;
+        for (i64 e = 0; e < v; ++e) for (i64 m = 0; m < o; ++m)
+            x += (2.0 * OOVV(m, i, e, a) - OOVV(m, i, a, e)) * T1(m, e);
+        IVO(a, i) = x;
+    }
+    /* I_vv(b,a)  :1096-1113 */
+#pragma omp for collapse(2) schedule(static)
+    for (i64 a = 0; a < v; ++a) for (i64 b = 0; b < v; ++b) {
+        double x = 0.0;
+        for (i64 m = 0; m < o; ++m) for (i64 e = 0; e < v; ++e)
+            x += (2.0 * VVOV(e, b, m, a) - VVOV(b, e, m, a)) * T1(m, e);
+        for (i64 e = 0; e < v; ++e) for (i64 n = 0; n < o; ++n) for (i64 m = 0; m < o; ++m)
+            x -= (2.0 * OOVV(m, n, e, b) - OOVV(m, n, b, e)) * CC(m, n, e, a);
+        IVV(b, a) = x;
+    }
+    /* I_oo_p(j,i)  :1115-1132 */
+#pragma omp for collapse(2) schedule(static)
+    for (i64 i = 0; i < o; ++i) for (i64 j = 0; j < o; ++j) {
+        double x = 0.0;
+        for (i64 e = 0; e < v; ++e) for (i64 m = 0; m < o; ++m)
+            x += (2.0 * OOVO(m, i, e, j) - OOVO(i, m, e, j)) * T1(m, e);
+        for (i64 f = 0; f < v; ++f) for (i64 e = 0; e < v; ++e) for (i64 m = 0; m < o; ++m)
+            x += OOVV(m, i, e, f) * AS(m, j, e, f);
+        IOOP(j, i) = x;
+    }
+    }
+    /* I_oo(j,i) = I_oo_p + t(j,e) I_vo(e,i)  :1134-1137 */
+    for (i64 i = 0; i < o; ++i) for (i64 j = 0; j < o; ++j) {
+        double x = IOOP(j, i);
+        for (i64 e = 0; e < v; ++e) x += T1(j, e) * IVO(e, i);
+        IOO(j, i) = x;
+    }
+#pragma omp parallel
+    {
+    /* I_oooo(k,l,i,j)  :1139-1156 */
+#pragma omp for collapse(2) schedule(static)
+    for (i64 j = 0; j < o; ++j) for (i64 i = 0; i < o; ++i) for (i64 l = 0; l < o; ++l) for (i64 k = 0; k < o; ++k) {
+        double x = OOOO(k, l, i, j);
+        for (i64 f = 0; f < v; ++f) for (i64 e = 0; e < v; ++e) x += OOVV(i, j, e, f) * CC(k, l, e, f);
+        for (i64 e = 0; e < v; ++e) x += T1(k, e) * OOVO(i, l, e, j) + T1(l, e) * OOVO(j, k, e, i);
+        IOOOO(k, l, i, j) = x;
+    }
+    /* I_ovov(j,b,i,a)  :1158-1191 */
+#pragma omp for collapse(2) schedule(static)
+    for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i) for (i64 b = 0; b < v; ++b) for (i64 j = 0; j < o; ++j) {
+        double x = OVOV(j, b, i, a);
+        for (i64 e = 0; e < v; ++e) for (i64 m = 0; m < o; ++m) x -= 0.5 * OOVV(m, i, b, e) * CC(m, j, a, e);
+        for (i64 m = 0; m < o; ++m) x -= OOVO(m, i, b, j) * T1(m, a);
+        for (i64 e = 0; e < v; ++e) x += T1(j, e) * VVOV(e, b, i, a);
+        IOVOV(j, b, i, a) = x;
+    }
+    /* I_voov(b,j,i,a)  :1193-1252 */
+#pragma omp for collapse(2) schedule(static)
+    for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i) for (i64 j = 0; j < o; ++j) for (i64 b = 0; b < v; ++b) {
+        double x = OOVV(j, i, a, b);
+        for (i64 e = 0; e < v; ++e) for (i64 m = 0; m < o; ++m) {
+            x += (OOVV(i, m, b, e) - 0.5 * OOVV(i, m, e, b)) * T2(m, j, e, a);
+            x -= 0.5 * OOVV(i, m, b, e) * CC(m, j, a, e);
+        }
+        for (i64 e = 0; e < v; ++e) x += VVOV(b, e, i, a) * T1(j, e);
+        for (i64 m = 0; m < o; ++m) x -= OOVO(i, m, b, j) * T1(m, a);
+        IVOOV(b, j, i, a) = x;
+    }
+    /* I_vovv_p(c,i,a,b)  :1255-1272, :1296-1299 */
+#pragma omp for collapse(2) schedule(static)
+    for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i) for (i64 c = 0; c < v; ++c) {
+        double x = VVOV(b, a, i, c);
+        for (i64 m = 0; m < o; ++m) x -= OOVV(m, i, c, b) * T1(m, a) + OVOV(m, a, i, c) * T1(m, b);
+        IVOVV(c, i, a, b) = x;
+    }
+    /* x_voov(b,j,i,a)  :1275-1290 */
+#pragma omp for collapse(2) schedule(static)
+    for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i) for (i64 j = 0; j < o; ++j) for (i64 b = 0; b < v; ++b) {
+        double x = 0.0;
+        for (i64 e = 0; e < v; ++e) x += VVOV(b, e, i, a) * T1(j, e);
+        XVOOV(b, j, i, a) = x;
+    }
+    }
+    /* I_ooov_p(j,k,i,a)  :1302-1308 */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i) for (i64 k = 0; k < o; ++k) for (i64 j = 0; j < o; ++j) {
+        double x = OOVO(k, j, a, i);
+        for (i64 f = 0; f < v; ++f) for (i64 e = 0; e < v; ++e) x += T2(j, k, e, f) * VVOV(e, f, i, a);
+        for (i64 e = 0; e < v; ++e) x += T1(j, e) * XVOOV(e, k, i, a);
+        IOOOV(j, k, i, a) = x;
+    }
+}
+
+/* ccsd.f90:1538-1732 */
+void orc_cc_amplitudes(orc_cc *s)
+{
+    const i64 o = O, v = V;
+#pragma omp parallel
+    {
+    /* T1, Eq. 43  :1569-1631 */
+#pragma omp for collapse(2) schedule(static)
+    for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i) {
+        double x = 0.0;
+        for (i64 e = 0; e < v; ++e) x += T1(i, e) * IVV(e, a);
+        for (i64 m = 0; m < o; ++m) x -= IOOP(i, m) * T1(m, a);
+        for (i64 e = 0; e < v; ++e) for (i64 m = 0; m < o; ++m)
+            x += IVO(e, m) * AS(m, i, e, a) + T1(m, e) * (2.0 * OOVV(m, i, e, a) - OVOV(m, a, i, e));
+        for (i64 e = 0; e < v; ++e) for (i64 n = 0; n < o; ++n) for (i64 m = 0; m < o; ++m)
+            x -= OOVO(m, i, e, n) * AS(m, n, e, a);
+        for (i64 f = 0; f < v; ++f) for (i64 e = 0; e < v; ++e) for (i64 m = 0; m < o; ++m)
+            x += VVOV(e, f, m, a) * AS(m, i, e, f);
+        R1(i, a) = x;
+    }
+    /* T2, Eq. 44  :1637-1716 */
+#pragma omp for collapse(2) schedule(static)
+    for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) for (i64 j = 0; j < o; ++j) for (i64 i = 0; i < o; ++i) {
+        double x = 0.0;
+        for (i64 e = 0; e < v; ++e) x += T2(i, j, a, e) * IVV(e, b);                       /* :1647 */
+        for (i64 m = 0; m < o; ++m) x -= T2(m, i, b, a) * IOO(j, m);                        /* :1654-1664 */
+        double lad = 0.0;
+        for (i64 f = 0; f < v; ++f) for (i64 e = 0; e < v; ++e) lad += CC(i, j, e, f) * VVVV(e, f, a, b); /* :1669 */
+        for (i64 n = 0; n < o; ++n) for (i64 m = 0; m < o; ++m) lad += IOOOO(i, j, m, n) * CC(m, n, a, b); /* :1673 */
+        x += 0.5 * lad;
+        for (i64 e = 0; e < v; ++e) for (i64 m = 0; m < o; ++m)                              /* :1680-1695 */
+            x += -T2(m, j, a, e) * IOVOV(i, e, m, b) - IOVOV(i, e, m, a) * T2(m, j, e, b) + AS(m, i, e, a) * IVOOV(e, j, m, b);
+        for (i64 e = 0; e < v; ++e) x += T1(i, e) * IVOVV(e, j, a, b);                      /* :1700 */
+        for (i64 m = 0; m < o; ++m) x -= T1(m, a) * IOOOV(i, j, m, b);                      /* :1705-1715 */
+        R2(i, j, a, b) = x;
+    }
+    }
+    /* P(ia/jb) + v_oovv, Jacobi divide  :1720-1728 */
+    for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i) T1(i, a) = R1(i, a) / s->D1[i + o * a];
+#pragma omp parallel for collapse(2) schedule(static)
+    for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) for (i64 j = 0; j < o; ++j) for (i64 i = 0; i < o; ++i)
+        T2(i, j, a, b) = (R2(i, j, a, b) + R2(j, i, b, a) + OOVV(i, j, a, b)) / s->D2[i + o * (j + o * (a + v * b))];
+}
+
+/* ccsd.f90:1764-1782, :1803-1806.  Returns 1 if converged.  s->rms holds the UN-rooted sum (as :1806). */
+int orc_cc_energy(orc_cc *s, double e_tol, double t_tol)
+{
+    const i64 o = O, v = V;
+    double ecc = 0.0, rms = 0.0;
+    s->energy_old = s->energy;
+    for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) for (i64 j = 0; j < o; ++j) for (i64 i = 0; i < o; ++i) {
+        i64 x = i + o * (j + o * (a + v * b));
+        ecc += (2.0 * OOVV(i, j, a, b) - OOVV(i, j, b, a)) * (T2(i, j, a, b) + T1(i, a) * T1(j, b));
+        double d = s->t2[x] - s->t2_old[x];
+        rms += d * d;
+    }
+    s->energy = ecc;
+    memcpy(s->t2_old, s->t2, sizeof(double) * o * o * v * v);
+    s->rms = rms;
+    return (sqrt(rms) < t_tol && fabs(s->energy - s->energy_old) < e_tol) ? 1 : 0;
+}
+
+/* Dense symmetric solve standing in for linalg.fpp:38-56 (LAPACK dsysv, lower triangle).
+ * Gaussian elimination with partial pivoting on the symmetrised full matrix. */
+int orc_linsolve(int n, double *A /* n*n col-major, lower triangle valid */, double *b)
+{
+    for (int j = 0; j < n; ++j) for (int i = 0; i < j; ++i) A[i + n * j] = A[j + n * i];
+    for (int k = 0; k < n; ++k) {
+        int p = k; double big = fabs(A[k + n * k]);
+        for (int i = k + 1; i < n; ++i) if (fabs(A[i + n * k]) > big) { big = fabs(A[i + n * k]); p = i; }
+        if (big == 0.0) return 1;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) { double t = A[k + n * j]; A[k + n * j] = A[p + n * j]; A[p + n * j] = t; }
+            double t = b[k]; b[k] = b[p]; b[p] = t;
+        }
+        for (int i = k + 1; i < n; ++i) {
+            double f = A[i + n * k] / A[k + n * k];
+            if (f == 0.0) continue;
+            for (int j = k; j < n; ++j) A[i + n * j] -= f * A[k + n * j];
+            b[i] -= f * b[k];
+        }
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        double x = b[k];
+        for (int j = k + 1; j < n; ++j) x -= A[k + n * j] * b[j];
+        b[k] = x / A[k + n * k];
+    }
+    return 0;
+}
+
+static double ddot(i64 n, const double *x, const double *y)
+{
+    double s = 0.0;
+    for (i64 i = 0; i < n; ++i) s += x[i] * y[i];
+    return s;
+}
+
+/* ccsd.f90:342-343: called at the top of every iteration */
+void orc_cc_diis_save(orc_cc *s)
+{
+    if (s->nerr < 2) return;
+    memcpy(s->t1_s, s->t1, sizeof(double) * O * V);
+    memcpy(s->t2_s, s->t2, sizeof(double) * O * O * V * V);
+}
+
+/* ccsd.f90:617-676 */
+int orc_cc_diis_update(orc_cc *s)
+{
+    if (s->nerr < 2) return 0;
+    const i64 n1 = O * V, n2 = O * O * V * V;
+    s->it += 1;
+    if (s->it > s->nerr) s->it -= s->nerr;
+    if (s->nact < s->nerr) s->nact += 1;
+    const int slot = s->it - 1, n = s->nact;
+    memcpy(s->d_t1 + n1 * slot, s->t1, sizeof(double) * n1);
+    memcpy(s->d_t2 + n2 * slot, s->t2, sizeof(double) * n2);
+    for (i64 x = 0; x < n1; ++x) s->d_e1[n1 * slot + x] = s->t1[x] - s->t1_s[x];
+    for (i64 x = 0; x < n2; ++x) s->d_e2[n2 * slot + x] = s->t2[x] - s->t2_s[x];
+    const int N = n + 1;
+    double *B = dalloc(N * N), *c = dalloc(N);
+    for (int j = 0; j < N; ++j) B[n + N * j] = -1.0;
+    B[n + N * n] = 0.0;
+    c[n] = -1.0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j)
+        B[i + N * j] = ddot(n1, s->d_e1 + n1 * i, s->d_e1 + n1 * j) + ddot(n2, s->d_e2 + n2 * i, s->d_e2 + n2 * j);
+    int ierr = orc_linsolve(N, B, c);
+    if (!ierr) {
+        memset(s->t1, 0, sizeof(double) * n1);
+        memset(s->t2, 0, sizeof(double) * n2);
+        for (int i = 0; i < n; ++i) {
+            for (i64 x = 0; x < n1; ++x) s->t1[x] += c[i] * s->d_t1[n1 * i + x];
+            for (i64 x = 0; x < n2; ++x) s->t2[x] += c[i] * s->d_t2[n2 * i + x];
+        }
+    }
+    free(B); free(c);
+    return ierr;
+}
+
+/* ccsd.f90:325-396 driver.  iter_energy/iter_rms (length maxiter+1) receive the printed table:
+ * entry 0 is the "MP1" line.  Returns the number of iterations taken, or -1 if not converged. */
+int orc_cc_solve(orc_cc *s, int maxiter, double e_tol, double t_tol, double *iter_energy, double *iter_rms)
+{
+    s->energy = 0.0; s->energy_old = 0.0;
+    memset(s->t2_old, 0, sizeof(double) * O * O * V * V);
+    orc_cc_energy(s, e_tol, t_tol);
+    if (iter_energy) iter_energy[0] = s->energy;
+    if (iter_rms) iter_rms[0] = s->rms;
+    for (int it = 1; it <= maxiter; ++it) {
+        orc_cc_diis_save(s);
+        orc_cc_intermediates(s);
+        orc_cc_amplitudes(s);
+        int conv = orc_cc_energy(s, e_tol, t_tol);
+        if (iter_energy) iter_energy[it] = s->energy;
+        if (iter_rms) iter_rms[it] = s->rms;
+        if (conv) return it;
+        if (orc_cc_diis_update(s)) return -2;
+    }
+    return -1;
+}
+
+double orc_cc_get_energy(const orc_cc *s) { return s->energy; }
+double orc_cc_get_rms(const orc_cc *s) { return s->rms; }
+double *orc_cc_t1(orc_cc *s) { return s->t1; }
+double *orc_cc_t2(orc_cc *s) { return s->t2; }
+/* field access for tests: 0 v_oovv 1 v_ovov 2 v_vvov 3 v_oovo 4 v_oooo 5 v_vvvv 6 I_vo 7 I_vv 8 I_oo_p 9 I_oo
+ * 10 c 11 asym 12 x_voov 13 I_oooo 14 I_ovov 15 I_voov 16 I_vovv_p 17 I_ooov_p 18 r1 19 r2 20 D1 21 D2 */
+double *orc_cc_field(orc_cc *s, int which)
+{
+    double *f[] = {s->v_oovv, s->v_ovov, s->v_vvov, s->v_oovo, s->v_oooo, s->v_vvvv, s->I_vo, s->I_vv, s->I_oo_p, s->I_oo,
+                   s->c, s->asym, s->x_voov, s->I_oooo, s->I_ovov, s->I_voov, s->I_vovv_p, s->I_ooov_p, s->r1, s->r2,
+                   s->D1, s->D2};
+    return (which >= 0 && which < 22) ? f[which] : NULL;
+}
+/* ccsd.f90:372 */
+double orc_cc_t1_diagnostic(const orc_cc *s, i64 nel)
+{
+    return sqrt(ddot(s->o * s->v, s->t1, s->t1)) / sqrt((double)nel);
+}
+
+/* ---------------------------------------------------------------- (T) */
+/* ccsd.f90:2152-2237 as coded: all o^3 (i,j,k), W from the six permuted particle/hole terms (:2168-2173),
+ * t3 = W/D (:2175), z3 (:2178-2179), y (:2183-2184), x_bar = 4/3 x(abc) - 2 x(acb) + 2/3 x(cab) (:2314-2318).
+ * out[0]=E[T] (:2218-2219)  out[1]=E(T) with z_bar (:2220, the R/CR-mode value = the correct (T))
+ * out[2]=D[T] out[3]=D(T) (:2228-2247, include the 1+2 t1^2+asym.c base term)
+ * Triples (i,j,k) with flat index i*o*o+j*o+k in [t_begin,t_end) only (sharding / bounded timing). */
+void orc_ccsd_t(i64 o, i64 v, const double *e, const double *t1, const double *t2, const double *v_vvov,
+                const double *v_oovo, const double *v_oovv, i64 t_begin, i64 t_end, double *out)
+{
+    const i64 v3 = v * v * v;
+    double eT = 0.0, eTT = 0.0, dT = 0.0, dTT = 0.0;
+#define t1_(i, a) t1[(i) + o * (a)]
+#define t2_(i, j, a, b) t2[(i) + o * ((j) + o * ((a) + v * (b)))]
+#define vvov_(a, b, i, c) v_vvov[(a) + v * ((b) + v * ((i) + o * (c)))]
+#define oovo_(i, j, a, k) v_oovo[(i) + o * ((j) + o * ((a) + v * (k)))]
+#define oovv_(i, j, a, b) v_oovv[(i) + o * ((j) + o * ((a) + v * (b)))]
+/* X^{ijk}(a,b,c) = sum_d t2(i,j,a,d) <cb|kd> - sum_l t2(l,i,b,a) <kj|cl>   (:2168, operands per :2056-2066) */
+#pragma omp parallel reduction(+ : eT, eTT, dT, dTT)
+    {
+        double *W = (double *)malloc(sizeof(double) * v3), *T3 = (double *)malloc(sizeof(double) * v3);
+        double *Z = (double *)malloc(sizeof(double) * v3), *Y = (double *)malloc(sizeof(double) * v3);
+        /* per-thread contiguous copies so the inner dot products run over unit stride */
+        double *ta = (double *)malloc(sizeof(double) * 6 * v * v);  /* ta[p][a][d] = t2(x,y,a,d) for 6 (x,y) */
+        double *va = (double *)malloc(sizeof(double) * 3 * v3);     /* va[q][(b,c)][d] = <cb|qd> for q in {i,j,k} */
+#pragma omp for schedule(dynamic, 1)
+        for (i64 ijk = t_begin; ijk < t_end; ++ijk) {
+            const i64 i = ijk / (o * o), j = (ijk / o) % o, k = ijk % o;
+            const i64 occ[3] = {i, j, k};
+            /* pairs (x,y) needed: ij, ji, kj, ik, jk, ki */
+            const i64 px[6] = {i, j, k, i, j, k}, py[6] = {j, i, j, k, k, i};
+            for (int p = 0; p < 6; ++p)
+                for (i64 a = 0; a < v; ++a) for (i64 d = 0; d < v; ++d)
+                    ta[(p * v + a) * v + d] = t2_(px[p], py[p], a, d);
+            for (int q = 0; q < 3; ++q)
+                for (i64 c = 0; c < v; ++c) for (i64 b = 0; b < v; ++b) for (i64 d = 0; d < v; ++d)
+                    va[((q * v + c) * v + b) * v + d] = vvov_(c, b, occ[q], d);   /* V(d,q,b,c) */
+#define TA(p, a) (ta + ((p) * v + (a)) * v)
+#define VA(q, b, c) (va + (((q) * v + (c)) * v + (b)) * v)
+            const double eo = e[i] + e[j] + e[k];
+            for (i64 c = 0; c < v; ++c) for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) {
+                double w = ddot(v, TA(0, a), VA(2, b, c))    /* t2(i,j,a,:) V(:,k,b,c) */
+                         + ddot(v, TA(1, b), VA(2, a, c))    /* t2(j,i,b,:) V(:,k,a,c) */
+                         + ddot(v, TA(2, c), VA(0, b, a))    /* t2(k,j,c,:) V(:,i,b,a) */
+                         + ddot(v, TA(3, a), VA(1, c, b))    /* t2(i,k,a,:) V(:,j,c,b) */
+                         + ddot(v, TA(4, b), VA(0, c, a))    /* t2(j,k,b,:) V(:,i,c,a) */
+                         + ddot(v, TA(5, c), VA(1, a, b));   /* t2(k,i,c,:) V(:,j,a,b) */
+                for (i64 l = 0; l < o; ++l)
+                    w -= t2_(l, i, b, a) * oovo_(k, j, c, l) + t2_(l, j, a, b) * oovo_(k, i, c, l)
+                       + t2_(l, k, b, c) * oovo_(i, j, a, l) + t2_(l, i, c, a) * oovo_(j, k, b, l)
+                       + t2_(l, j, c, b) * oovo_(i, k, a, l) + t2_(l, k, a, c) * oovo_(j, i, b, l);
+                const double D = eo - e[a + o] - e[b + o] - e[c + o];
+                const i64 x = a + v * (b + v * c);
+                W[x] = w;
+                T3[x] = w / D;
+                Z[x] = (t1_(i, a) * oovv_(j, k, b, c) + t1_(j, b) * oovv_(i, k, a, c) + t1_(k, c) * oovv_(i, j, a, b)) / D;
+                Y[x] = t1_(i, a) * t1_(j, b) * t1_(k, c) + t1_(i, a) * t2_(j, k, b, c) + t1_(j, b) * t2_(i, k, a, c)
+                     + t1_(k, c) * t2_(i, j, a, b);
+            }
+            /* x_bar(a,b,c) = 4/3 x(a,b,c) - 2 x(a,c,b) + 2/3 x(c,a,b)  (:2314-2318) */
+            double s_tw = 0.0, s_zw = 0.0, s_ty = 0.0, s_zy = 0.0;
+            for (i64 c = 0; c < v; ++c) for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) {
+                const i64 x = a + v * (b + v * c), xacb = a + v * (c + v * b), xcab = c + v * (a + v * b);
+                const double tb = 4.0 * T3[x] / 3.0 - 2.0 * T3[xacb] + 2.0 * T3[xcab] / 3.0;
+                const double zb = 4.0 * Z[x] / 3.0 - 2.0 * Z[xacb] + 2.0 * Z[xcab] / 3.0;
+                s_tw += tb * W[x]; s_zw += zb * W[x]; s_ty += tb * Y[x]; s_zy += zb * Y[x];
+            }
+            eT += s_tw; eTT += s_tw + s_zw; dT += s_ty; dTT += s_ty + s_zy;
+        }
+        free(W); free(T3); free(Z); free(Y); free(ta); free(va);
+    }
+    /* :2243: 1 + 2 sum t1^2 + sum asym_t2 * c_oovv (added once, only by the caller holding t_begin == 0) */
+    if (t_begin == 0) {
+        double base = 1.0;
+        for (i64 x = 0; x < o * v; ++x) base += 2.0 * t1[x] * t1[x];
+        for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) for (i64 j = 0; j < o; ++j) for (i64 i = 0; i < o; ++i)
+            base += (2.0 * t2_(i, j, a, b) - t2_(j, i, a, b)) * (t2_(i, j, a, b) + t1_(i, a) * t1_(j, b));
+        dT += base; dTT += base;
+    }
+    out[0] = eT; out[1] = eTT; out[2] = dT; out[3] = dTT;
+}
+
+/* ---------------------------------------------------------------- operator layer (linalg.fpp) */
+/* linalg.fpp:58-89 dgemm_wrapper: C(m x n) = alpha op(A) op(B) + beta C, dense column-major, LD from shapes */
+void orc_gemm(int transA, int transB, i64 m, i64 n, i64 k, double alpha, const double *A, const double *B, double beta,
+              double *C)
+{
+    i64 lda = transA ? k : m, ldb = transB ? n : k;
+#pragma omp parallel for schedule(static)
+    for (i64 j = 0; j < n; ++j)
+        for (i64 i = 0; i < m; ++i) {
+            double s = 0.0;
+            for (i64 l = 0; l < k; ++l) {
+                double a = transA ? A[l + lda * i] : A[i + lda * l];
+                double b = transB ? B[j + ldb * l] : B[l + ldb * j];
+                s += a * b;
+            }
+            C[i + m * j] = alpha * s + (beta == 0.0 ? 0.0 : beta * C[i + m * j]);
+        }
+}
+
+/* linalg.fpp:99-156 omp_reshape: out(perm(i,j,k,l)) = beta*out + in(i,j,k,l); digit d of `order` names the INPUT
+ * index that sits in OUTPUT position d.  has_beta == 0 reproduces the "zero out then add" branch (:125-131). */
+void orc_permute4(const i64 dims[4], const char *order, const double *in, double *out, int has_beta, double beta)
+{
+    int p[4];
+    for (int d = 0; d < 4; ++d) p[d] = order[d] - '1';
+    i64 od[4];
+    for (int d = 0; d < 4; ++d) od[d] = dims[p[d]];
+    i64 idx[4];
+    for (idx[3] = 0; idx[3] < dims[3]; ++idx[3]) for (idx[2] = 0; idx[2] < dims[2]; ++idx[2])
+        for (idx[1] = 0; idx[1] < dims[1]; ++idx[1]) for (idx[0] = 0; idx[0] < dims[0]; ++idx[0]) {
+            i64 src = idx[0] + dims[0] * (idx[1] + dims[1] * (idx[2] + dims[2] * idx[3]));
+            i64 dst = idx[p[0]] + od[0] * (idx[p[1]] + od[1] * (idx[p[2]] + od[2] * idx[p[3]]));
+            out[dst] = (has_beta ? beta * out[dst] : 0.0) + in[src];
+        }
+}
