@@ -1,0 +1,220 @@
+"""ctypes binding of libafesp_hip.so (include/afesp.h).  Python-side mirror of the three calls the reference's driver
+makes into the hot path (src/main.F90:98,105,112): `do_mp2_spatial`, `do_ccsd_spatial`, `do_ccsd_t_spatial`.
+
+There is no CPU fallback: if the shared library is missing, or no GPU is visible, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libafesp_hip.so")
+
+i64 = C.c_int64
+dbl = C.c_double
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_opt = C.c_void_p
+
+EXPORTS = [
+    "afesp_ctx_create", "afesp_ctx_destroy", "afesp_last_error", "afesp_version", "afesp_neri", "afesp_ao2mo_mp2",
+    "afesp_ccsd_init", "afesp_ccsd_iterate", "afesp_ccsd_energy", "afesp_ccsd_diis", "afesp_ccsd_solve",
+    "afesp_ccsd_get_amplitudes", "afesp_ccsd_set_amplitudes", "afesp_ccsd_get_tensor", "afesp_ccsd_update_intermediates",
+    "afesp_ccsd_update_amplitudes", "afesp_ccsd_t_ntriples", "afesp_ccsd_t", "afesp_gemm", "afesp_permute4",
+    "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder",
+]
+
+
+class AfespError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library.  Raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AfespError(f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
+                         "(there is no CPU fallback for the accelerated path)")
+    L = C.CDLL(LIB_PATH)
+    L.afesp_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.afesp_ctx_destroy.argtypes = [C.c_void_p]
+    L.afesp_ctx_destroy.restype = None
+    L.afesp_last_error.argtypes = [C.c_void_p]
+    L.afesp_last_error.restype = C.c_char_p
+    L.afesp_neri.argtypes = [i64]
+    L.afesp_neri.restype = i64
+    L.afesp_ao2mo_mp2.argtypes = [C.c_void_p, i64, i64, _dp, _dp, _dp, _opt, C.POINTER(dbl)]
+    L.afesp_ccsd_init.argtypes = [C.c_void_p, i64, i64, _opt, _dp, C.c_int]
+    L.afesp_ccsd_iterate.argtypes = [C.c_void_p, dbl, dbl, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_int)]
+    L.afesp_ccsd_energy.argtypes = [C.c_void_p, dbl, dbl, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_int)]
+    L.afesp_ccsd_diis.argtypes = [C.c_void_p]
+    L.afesp_ccsd_solve.argtypes = [C.c_void_p, C.c_int, dbl, dbl, _dp, _dp, C.POINTER(C.c_int)]
+    L.afesp_ccsd_get_amplitudes.argtypes = [C.c_void_p, _dp, _dp]
+    L.afesp_ccsd_set_amplitudes.argtypes = [C.c_void_p, _dp, _dp]
+    L.afesp_ccsd_get_tensor.argtypes = [C.c_void_p, C.c_char_p, _dp, i64]
+    L.afesp_ccsd_update_intermediates.argtypes = [C.c_void_p]
+    L.afesp_ccsd_update_amplitudes.argtypes = [C.c_void_p]
+    L.afesp_ccsd_t_ntriples.argtypes = [i64]
+    L.afesp_ccsd_t_ntriples.restype = i64
+    L.afesp_ccsd_t.argtypes = [C.c_void_p, i64, i64, _dp]
+    L.afesp_gemm.argtypes = [C.c_void_p, C.c_char, C.c_char, i64, i64, i64, dbl, _dp, _dp, dbl, _dp]
+    L.afesp_permute4.argtypes = [C.c_void_p, C.POINTER(i64), C.c_char_p, _dp, _dp, C.c_int, dbl]
+    L.afesp_contract.argtypes = [C.c_void_p, dbl, _dp, C.c_char_p, C.POINTER(i64), _dp, C.c_char_p, C.POINTER(i64), dbl,
+                                 _dp, C.c_char_p, C.POINTER(i64), C.c_int, C.c_int, C.c_int]
+    L.afesp_synthetic_init.argtypes = [C.c_void_p, i64, i64, dbl, C.c_uint64, C.c_int]
+    L.afesp_time_pp_ladder.argtypes = [C.c_void_p, C.c_int, C.POINTER(dbl)]
+    _lib = L
+    return L
+
+
+def _f(a):
+    """Fortran-order flat copy of an array (what the C-ABI expects)."""
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).ravel(order="F"))
+
+
+TENSOR_SHAPES = {
+    "v_oovv": "oovv", "v_ovov": "ovov", "v_vvov": "vvov", "v_oovo": "oovo", "v_oooo": "oooo", "v_vvvv": "vvvv",
+    "I_vo": "vo", "I_vv": "vv", "I_oo_p": "oo", "I_oo": "oo", "c_oovv": "oovv", "asym_t2": "oovv", "x_voov": "voov",
+    "I_oooo": "oooo", "I_ovov": "ovov", "I_voov": "voov", "I_vovv_p": "vovv", "I_ooov_p": "ooov", "r1": "ov",
+    "r2": "oovv", "D1": "ov", "D2": "oovv", "t1": "ov", "t2": "oovv",
+}
+
+
+class Engine:
+    """One GPU context.  Method names follow the reference routines they replace."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.afesp_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise AfespError(f"afesp_ctx_create(device={device}) failed with status {rc} "
+                             "(no usable MI355X/HIP device; the accelerated path has no CPU fallback)")
+        self.h = h
+        self.o = self.v = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.afesp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AfespError(f"status {rc}: {self.L.afesp_last_error(self.h).decode()}")
+
+    # ---- src/mp2.f90:261-449
+    def do_mp2_spatial(self, nbasis, nocc, canon_coeff, canon_levels, eri_packed, want_eri_mo=True):
+        e2 = dbl(0.0)
+        out = np.zeros(self.L.afesp_neri(nbasis)) if want_eri_mo else None
+        self._chk(self.L.afesp_ao2mo_mp2(self.h, nbasis, nocc, _f(canon_coeff), _f(canon_levels),
+                                         np.ascontiguousarray(eri_packed, dtype=np.float64),
+                                         out.ctypes.data_as(C.c_void_p) if out is not None else None, C.byref(e2)))
+        return e2.value, out
+
+    # ---- src/ccsd.f90:279-402
+    def ccsd_init(self, nocc, nvirt, canon_levels, eri_mo_packed=None, diis_n_errmat=8):
+        self.o, self.v = int(nocc), int(nvirt)
+        ptr = None
+        if eri_mo_packed is not None:
+            eri_mo_packed = np.ascontiguousarray(eri_mo_packed, dtype=np.float64)
+            ptr = eri_mo_packed.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.afesp_ccsd_init(self.h, nocc, nvirt, ptr, _f(canon_levels), diis_n_errmat))
+
+    def synthetic_init(self, nocc, nvirt, scale=0.02, seed=12345, diis_n_errmat=8):
+        self.o, self.v = int(nocc), int(nvirt)
+        self._chk(self.L.afesp_synthetic_init(self.h, nocc, nvirt, scale, seed, diis_n_errmat))
+
+    def ccsd_energy(self, e_tol=1e-6, t_tol=1e-7):
+        e, r, c = dbl(), dbl(), C.c_int()
+        self._chk(self.L.afesp_ccsd_energy(self.h, e_tol, t_tol, C.byref(e), C.byref(r), C.byref(c)))
+        return e.value, r.value, bool(c.value)
+
+    def ccsd_iterate(self, e_tol=1e-6, t_tol=1e-7):
+        e, r, c = dbl(), dbl(), C.c_int()
+        self._chk(self.L.afesp_ccsd_iterate(self.h, e_tol, t_tol, C.byref(e), C.byref(r), C.byref(c)))
+        return e.value, r.value, bool(c.value)
+
+    def ccsd_diis(self):
+        self._chk(self.L.afesp_ccsd_diis(self.h))
+
+    def update_intermediates(self):
+        self._chk(self.L.afesp_ccsd_update_intermediates(self.h))
+
+    def update_amplitudes(self):
+        self._chk(self.L.afesp_ccsd_update_amplitudes(self.h))
+
+    def do_ccsd_spatial(self, maxiter=50, e_tol=1e-6, t_tol=1e-7):
+        en = np.zeros(maxiter + 1)
+        rm = np.zeros(maxiter + 1)
+        nit = C.c_int()
+        self._chk(self.L.afesp_ccsd_solve(self.h, maxiter, e_tol, t_tol, en, rm, C.byref(nit)))
+        return nit.value, en, rm
+
+    def amplitudes(self):
+        o, v = self.o, self.v
+        t1 = np.zeros(o * v)
+        t2 = np.zeros(o * o * v * v)
+        self._chk(self.L.afesp_ccsd_get_amplitudes(self.h, t1, t2))
+        return t1.reshape((o, v), order="F"), t2.reshape((o, o, v, v), order="F")
+
+    def set_amplitudes(self, t1, t2):
+        self._chk(self.L.afesp_ccsd_set_amplitudes(self.h, _f(t1), _f(t2)))
+
+    def tensor(self, name):
+        dims = tuple(self.o if ch == "o" else self.v for ch in TENSOR_SHAPES[name])
+        buf = np.zeros(int(np.prod(dims)))
+        self._chk(self.L.afesp_ccsd_get_tensor(self.h, name.encode(), buf, buf.size))
+        return buf.reshape(dims, order="F")
+
+    # ---- src/ccsd.f90:2018-2293
+    def ntriples(self):
+        return self.L.afesp_ccsd_t_ntriples(self.o)
+
+    def do_ccsd_t_spatial(self, t_begin=0, t_end=None):
+        out = np.zeros(4)
+        if t_end is None:
+            t_end = self.ntriples()
+        self._chk(self.L.afesp_ccsd_t(self.h, t_begin, t_end, out))
+        return out
+
+    # ---- src/linalg.fpp operator layer
+    def gemm(self, transA, transB, m, n, k, A, B, Cmat=None, alpha=1.0, beta=0.0):
+        Cflat = np.zeros(m * n) if Cmat is None else _f(Cmat)
+        self._chk(self.L.afesp_gemm(self.h, transA.encode(), transB.encode(), m, n, k, alpha, _f(A), _f(B), beta, Cflat))
+        return Cflat.reshape((m, n), order="F")
+
+    def omp_reshape(self, in_arr, order, out_arr=None, beta=None):
+        dims = (i64 * 4)(*in_arr.shape)
+        oshape = tuple(in_arr.shape[int(ch) - 1] for ch in order)
+        out = np.zeros(int(np.prod(oshape))) if out_arr is None else _f(out_arr)
+        self._chk(self.L.afesp_permute4(self.h, dims, order.encode(), _f(in_arr), out, 0 if beta is None else 1,
+                                        0.0 if beta is None else beta))
+        return out.reshape(oshape, order="F")
+
+    def contract(self, alpha, A, la, B, lb, beta, Cmat, lc, force_split=0, force_tm=0, force_tn=0):
+        dA, dB, dC = (i64 * len(la))(*A.shape), (i64 * len(lb))(*B.shape), (i64 * len(lc))(*Cmat.shape)
+        Cflat = _f(Cmat)
+        self._chk(self.L.afesp_contract(self.h, alpha, _f(A), la.encode(), dA, _f(B), lb.encode(), dB, beta, Cflat,
+                                        lc.encode(), dC, force_split, force_tm, force_tn))
+        return Cflat.reshape(Cmat.shape, order="F")
+
+    def time_pp_ladder(self, reps=10):
+        ms = dbl()
+        self._chk(self.L.afesp_time_pp_ladder(self.h, reps, C.byref(ms)))
+        return ms.value

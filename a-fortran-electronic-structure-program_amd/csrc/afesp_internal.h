@@ -1,0 +1,105 @@
+// afesp_internal.h -- device context, tensor views and the contraction planner (C++ side, not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gett.h"
+
+namespace afesp {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define AFESP_HIP(expr)                                                                                    \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            throw ::afesp::Error(2, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + \
+                                        ":" + std::to_string(__LINE__) + ")");                            \
+    } while (0)
+
+// Dense or strided view of device memory, Fortran index order (dim[0] fastest when dense).
+struct Tensor {
+    double* d = nullptr;
+    int rank = 0;
+    int64_t dim[6] = {0, 0, 0, 0, 0, 0};
+    int64_t stride[6] = {0, 0, 0, 0, 0, 0};
+    int64_t size() const
+    {
+        int64_t s = 1;
+        for (int i = 0; i < rank; ++i) s *= dim[i];
+        return s;
+    }
+};
+
+struct Plan {
+    int64_t *offAm, *offAk, *offBk, *offBn, *offCm, *offCn;
+    int M, N, K;
+    bool swapped, a_kc, b_kc;
+};
+
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void*> owned;             // everything freed at destroy
+    GettWorkspace ws{nullptr, 0};
+    double* scal = nullptr;               // small device scratch for reductions (64 doubles)
+    double* scal_host = nullptr;          // pinned mirror
+    std::map<std::string, Plan> plans;
+    std::string last_error;
+
+    double* alloc(int64_t n);             // zero-initialised doubles
+    int64_t* alloc_i64(int64_t n);
+    void release(void* p);                // early free of an `owned` buffer
+    Tensor tensor(std::initializer_list<int64_t> dims);
+    void sync();
+    ~Context();
+};
+
+Tensor view(double* d, std::initializer_list<int64_t> dims);
+
+// C[lc] = alpha * sum_K A[la] * B[lb] + beta * C[lc].  One label character per tensor index; labels shared by
+// A and B and absent from C are summed.  Optional batching: nbatch problems whose operand bases are shifted by
+// the device arrays bA/bB/bC (element offsets; null = no shift).
+void contract(Context& cx, double alpha, const Tensor& A, const char* la, const Tensor& B, const char* lb, double beta,
+              const Tensor& C, const char* lc, int nbatch = 1, const int64_t* bA = nullptr, const int64_t* bB = nullptr,
+              const int64_t* bC = nullptr, int force_split = 0, int force_tm = 0, int force_tn = 0);
+
+// out[lo] = beta * out[lo] + alpha * in[li]  (li is a permutation of lo)
+void permute_add(Context& cx, double alpha, const Tensor& in, const char* li, double beta, const Tensor& out,
+                 const char* lo);
+
+// ---- elementwise / reduction kernels (kernels.hip)
+void k_fill(Context& cx, double* x, int64_t n, double val);
+void k_copy(Context& cx, double* dst, const double* src, int64_t n);
+void k_axpby(Context& cx, double* y, double a, const double* x, double b, int64_t n);   // y = a x + b y
+void k_div(Context& cx, double* out, const double* num, const double* den, int64_t n);
+void k_antisym_pair(Context& cx, double* out, const double* in, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
+                    int which);   // which=0: 2x - x(swap idx 0,1)   which=1: 2x - x(swap idx 2,3)
+void k_asym_c(Context& cx, double* asym, double* c, const double* t1, const double* t2, int o, int v);
+void k_t2_update(Context& cx, double* t2, const double* r2, const double* v_oovv, const double* D2, int o, int v);
+void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v);
+// out[0] = sum (2 v(ijab) - v(ijba)) (t2 + t1 t1), out[1] = sum (t2 - t2_old)^2 ; then t2_old = t2
+void k_cc_energy(Context& cx, double* out2, const double* v_oovv, const double* t1, const double* t2, double* t2_old,
+                 int o, int v);
+void k_mp2_energy(Context& cx, double* out1, const double* v_oovv, const double* D2, int o, int v);
+void k_dots(Context& cx, double* out, const double* x, const double* ybase, int64_t ystride, int ny, int64_t n,
+            bool accumulate);   // out[j] (+)= <x, ybase + j*ystride>
+void k_lincomb(Context& cx, double* out, const double* xbase, int64_t xstride, const double* coef_dev, int nx,
+               int64_t n);      // out = sum_j coef[j] * x_j
+void k_sub(Context& cx, double* out, const double* a, const double* b, int64_t n);
+void k_unpack_eri(Context& cx, double* full, const double* packed, int n);
+void k_pack_eri(Context& cx, double* packed, const double* full, int n);
+// out(p,q,r,s) = packed[ index( (p+b0)(r+b2) | (q+b1)(s+b3) ) ]  physicist <pq|rs> from packed chemist (pr|qs)
+void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1, int d2, int d3, int b0, int b1, int b2,
+                  int b3);
+double* host_scalars(Context& cx, int n);   // copies cx.scal[0..n) to pinned host memory and synchronises
+
+}  // namespace afesp

@@ -1,0 +1,414 @@
+// capi.hip -- extern "C" boundary (include/afesp.h), the AO->MO transform, and the synthetic-input generators.
+#include <cmath>
+#include <cstring>
+
+#include "../../include/afesp.h"
+#include "ccsd.h"
+
+using namespace afesp;
+
+struct afesp_ctx {
+    Context cx;
+    CCState cc;
+    double* eri_mo_dev = nullptr;   // packed MO integrals left on the device by afesp_ao2mo_mp2
+    int64_t eri_mo_n = 0;           // nbasis they belong to
+};
+
+namespace {
+
+template <class F>
+int guarded(afesp_ctx* c, F&& f)
+{
+    if (!c) return 1;
+    try {
+        f();
+        return 0;
+    } catch (const Error& e) {
+        c->cx.last_error = e.what();
+        return e.code ? e.code : 1;
+    } catch (const std::exception& e) {
+        c->cx.last_error = e.what();
+        return 1;
+    }
+}
+
+int64_t neri_of(int64_t n)
+{
+    int64_t np = n * (n + 1) / 2;
+    return np * (np + 1) / 2;
+}
+
+// splitmix64 -> uniform in [0,1)
+__device__ __forceinline__ double hash_uniform(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+__global__ void synth_packed_kernel(double* packed, int64_t n, double scale, uint64_t seed)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+        packed[k] = scale * (2.0 * hash_uniform(seed + (uint64_t)k) - 1.0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int afesp_version(void) { return 1; }
+int64_t afesp_neri(int64_t nbasis) { return neri_of(nbasis); }
+
+int afesp_ctx_create(int device, afesp_ctx** out)
+{
+    if (!out) return 1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return 10;   // no GPU: fail loudly, no CPU fallback
+    if (device < 0 || device >= ndev) return 11;
+    if (hipSetDevice(device) != hipSuccess) return 12;
+    afesp_ctx* c = new afesp_ctx();
+    c->cx.device = device;
+    int rc = guarded(c, [&] {
+        AFESP_HIP(hipStreamCreate(&c->cx.stream));
+        c->cx.scal = c->cx.alloc(64 + 16 * 512);
+        AFESP_HIP(hipHostMalloc((void**)&c->cx.scal_host, sizeof(double) * 64, hipHostMallocDefault));
+        c->cx.ws.bytes = (size_t)256 << 20;   // split-K slabs
+        c->cx.ws.ptr = c->cx.alloc((int64_t)(c->cx.ws.bytes / sizeof(double)));
+        c->cx.sync();
+    });
+    if (rc) {
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+void afesp_ctx_destroy(afesp_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cx.device);
+    delete ctx;
+}
+
+const char* afesp_last_error(const afesp_ctx* ctx) { return ctx ? ctx->cx.last_error.c_str() : "null context"; }
+
+// src/mp2.f90:261-449.  Four quarter transforms as MFMA GEMMs on the unpacked tensor; each pass contracts the
+// leading AO index with C(MO,AO) and the planner writes the result with the new MO index in place, so after four
+// passes the tensor is (pq|rs) in natural order with no transposes in between.
+int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* canon_coeff, const double* canon_levels,
+                    const double* eri_packed, double* eri_mo_packed, double* e_mp2)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        const int64_t n = nbasis, o = nocc, v = n - o, ne = neri_of(n);
+        if (n <= 0 || o <= 0 || v <= 0 || n > 1024) throw Error(1, "afesp_ao2mo_mp2: bad extents");
+        double* packed = cx.alloc(ne);
+        AFESP_HIP(hipMemcpyAsync(packed, eri_packed, sizeof(double) * ne, hipMemcpyHostToDevice, cx.stream));
+        Tensor Cm = cx.tensor({n, n});
+        AFESP_HIP(hipMemcpyAsync(Cm.d, canon_coeff, sizeof(double) * n * n, hipMemcpyHostToDevice, cx.stream));
+        Tensor Ta = cx.tensor({n, n, n, n}), Tb = cx.tensor({n, n, n, n});
+        k_unpack_eri(cx, Ta.d, packed, (int)n);
+        contract(cx, 1.0, Cm, "pi", Ta, "ijkl", 0.0, Tb, "pjkl");   // mp2.f90:321-333
+        contract(cx, 1.0, Cm, "qj", Tb, "pjkl", 0.0, Ta, "pqkl");   // mp2.f90:338-348
+        contract(cx, 1.0, Cm, "rk", Ta, "pqkl", 0.0, Tb, "pqrl");   // mp2.f90:357-367
+        contract(cx, 1.0, Cm, "sl", Tb, "pqrl", 0.0, Ta, "pqrs");   // mp2.f90:375-385
+        if (ctx->eri_mo_dev) cx.release(ctx->eri_mo_dev);
+        ctx->eri_mo_dev = packed;   // reuse the upload buffer for the packed MO integrals
+        ctx->eri_mo_n = n;
+        k_pack_eri(cx, packed, Ta.d, (int)n);                        // mp2.f90:388-410
+        // MP2 energy on the <ij|ab> slice (mp2.f90:418-440)
+        Tensor voovv = cx.tensor({o, o, v, v}), D1 = cx.tensor({o, v}), D2 = cx.tensor({o, o, v, v});
+        double* e_dev = cx.alloc(n);
+        AFESP_HIP(hipMemcpyAsync(e_dev, canon_levels, sizeof(double) * n, hipMemcpyHostToDevice, cx.stream));
+        k_slice_phys(cx, voovv.d, packed, (int)o, (int)o, (int)v, (int)v, 0, 0, (int)o, (int)o);
+        k_denominators(cx, D1.d, D2.d, e_dev, (int)o, (int)v);
+        k_mp2_energy(cx, cx.scal, voovv.d, D2.d, (int)o, (int)v);
+        double* h = host_scalars(cx, 1);
+        if (e_mp2) *e_mp2 = h[0];
+        if (eri_mo_packed) {
+            AFESP_HIP(hipMemcpyAsync(eri_mo_packed, packed, sizeof(double) * ne, hipMemcpyDeviceToHost, cx.stream));
+            cx.sync();
+        }
+        cx.release(Cm.d); cx.release(Ta.d); cx.release(Tb.d); cx.release(voovv.d); cx.release(D1.d); cx.release(D2.d);
+        cx.release(e_dev);
+    });
+}
+
+int afesp_ccsd_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, const double* eri_mo_packed, const double* canon_levels,
+                    int diis_n_errmat)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        const int64_t n = nocc + nvirt;
+        if (nocc <= 0 || nvirt <= 0 || n > 1024) throw Error(1, "afesp_ccsd_init: bad extents");
+        const double* src = ctx->eri_mo_dev;
+        double* tmp = nullptr;
+        if (eri_mo_packed) {
+            tmp = cx.alloc(neri_of(n));
+            AFESP_HIP(hipMemcpyAsync(tmp, eri_mo_packed, sizeof(double) * neri_of(n), hipMemcpyHostToDevice, cx.stream));
+            src = tmp;
+        } else if (!src || ctx->eri_mo_n != n) {
+            throw Error(1, "afesp_ccsd_init: no MO integrals resident for this basis size (call afesp_ao2mo_mp2 first)");
+        }
+        ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, src, canon_levels, diis_n_errmat);
+        if (tmp) cx.release(tmp);
+    });
+}
+
+int afesp_ccsd_energy(afesp_ctx* ctx, double e_tol, double t_tol, double* energy, double* rms_sq, int* converged)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_energy: call afesp_ccsd_init first");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        int conv = ccsd_energy(ctx->cx, ctx->cc, e_tol, t_tol);
+        if (energy) *energy = ctx->cc.energy;
+        if (rms_sq) *rms_sq = ctx->cc.rms;
+        if (converged) *converged = conv;
+    });
+}
+
+int afesp_ccsd_update_intermediates(afesp_ctx* ctx)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "call afesp_ccsd_init first");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        ccsd_intermediates(ctx->cx, ctx->cc);
+        ctx->cx.sync();
+    });
+}
+int afesp_ccsd_update_amplitudes(afesp_ctx* ctx)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "call afesp_ccsd_init first");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        ccsd_amplitudes(ctx->cx, ctx->cc);
+        ctx->cx.sync();
+    });
+}
+
+int afesp_ccsd_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* energy, double* rms_sq, int* converged)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_iterate: call afesp_ccsd_init first");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        ccsd_diis_save(ctx->cx, ctx->cc);
+        ccsd_intermediates(ctx->cx, ctx->cc);
+        ccsd_amplitudes(ctx->cx, ctx->cc);
+        int conv = ccsd_energy(ctx->cx, ctx->cc, e_tol, t_tol);
+        if (energy) *energy = ctx->cc.energy;
+        if (rms_sq) *rms_sq = ctx->cc.rms;
+        if (converged) *converged = conv;
+    });
+}
+
+int afesp_ccsd_diis(afesp_ctx* ctx)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_diis: call afesp_ccsd_init first");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        ccsd_diis_update(ctx->cx, ctx->cc);
+    });
+}
+
+int afesp_ccsd_solve(afesp_ctx* ctx, int maxiter, double e_tol, double t_tol, double* iter_energy, double* iter_rms_sq, int* niter)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_solve: call afesp_ccsd_init first");
+        Context& cx = ctx->cx;
+        CCState& s = ctx->cc;
+        AFESP_HIP(hipSetDevice(cx.device));
+        // ccsd.f90:314-315, :325
+        s.energy = s.energy_old = 0.0;
+        k_fill(cx, s.t2_old.d, s.t2_old.size(), 0.0);
+        ccsd_energy(cx, s, e_tol, t_tol);
+        if (iter_energy) iter_energy[0] = s.energy;
+        if (iter_rms_sq) iter_rms_sq[0] = s.rms;
+        int result = -1;
+        for (int it = 1; it <= maxiter; ++it) {
+            ccsd_diis_save(cx, s);
+            ccsd_intermediates(cx, s);
+            ccsd_amplitudes(cx, s);
+            int conv = ccsd_energy(cx, s, e_tol, t_tol);
+            if (iter_energy) iter_energy[it] = s.energy;
+            if (iter_rms_sq) iter_rms_sq[it] = s.rms;
+            if (conv) {
+                result = it;
+                break;
+            }
+            ccsd_diis_update(cx, s);
+        }
+        if (niter) *niter = result;
+    });
+}
+
+int afesp_ccsd_get_amplitudes(afesp_ctx* ctx, double* t1, double* t2)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_get_amplitudes: no CCSD state");
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        if (t1) AFESP_HIP(hipMemcpyAsync(t1, ctx->cc.t1.d, sizeof(double) * ctx->cc.t1.size(), hipMemcpyDeviceToHost, cx.stream));
+        if (t2) AFESP_HIP(hipMemcpyAsync(t2, ctx->cc.t2.d, sizeof(double) * ctx->cc.t2.size(), hipMemcpyDeviceToHost, cx.stream));
+        cx.sync();
+    });
+}
+
+int afesp_ccsd_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_set_amplitudes: no CCSD state");
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        if (t1) AFESP_HIP(hipMemcpyAsync(ctx->cc.t1.d, t1, sizeof(double) * ctx->cc.t1.size(), hipMemcpyHostToDevice, cx.stream));
+        if (t2) AFESP_HIP(hipMemcpyAsync(ctx->cc.t2.d, t2, sizeof(double) * ctx->cc.t2.size(), hipMemcpyHostToDevice, cx.stream));
+        cx.sync();
+    });
+}
+
+int afesp_ccsd_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t capacity)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_get_tensor: no CCSD state");
+        CCState& s = ctx->cc;
+        struct { const char* n; const Tensor* t; } tab[] = {
+            {"v_oovv", &s.v_oovv}, {"v_ovov", &s.v_ovov}, {"v_vvov", &s.v_vvov}, {"v_oovo", &s.v_oovo}, {"v_oooo", &s.v_oooo},
+            {"v_vvvv", &s.v_vvvv}, {"I_vo", &s.I_vo}, {"I_vv", &s.I_vv}, {"I_oo_p", &s.I_oo_p}, {"I_oo", &s.I_oo},
+            {"c_oovv", &s.c}, {"asym_t2", &s.asym}, {"x_voov", &s.x_voov}, {"I_oooo", &s.I_oooo}, {"I_ovov", &s.I_ovov},
+            {"I_voov", &s.I_voov}, {"I_vovv_p", &s.I_vovv_p}, {"I_ooov_p", &s.I_ooov_p}, {"r1", &s.r1}, {"r2", &s.r2},
+            {"D1", &s.D1}, {"D2", &s.D2}, {"t1", &s.t1}, {"t2", &s.t2}};
+        for (auto& e : tab)
+            if (!strcmp(e.n, name)) {
+                if (e.t->size() > capacity) throw Error(1, std::string("afesp_ccsd_get_tensor: buffer too small for ") + name);
+                AFESP_HIP(hipSetDevice(ctx->cx.device));
+                AFESP_HIP(hipMemcpyAsync(out, e.t->d, sizeof(double) * e.t->size(), hipMemcpyDeviceToHost, ctx->cx.stream));
+                ctx->cx.sync();
+                return;
+            }
+        throw Error(1, std::string("afesp_ccsd_get_tensor: unknown tensor ") + name);
+    });
+}
+
+int64_t afesp_ccsd_t_ntriples(int64_t nocc) { return triples_count((int)nocc); }
+
+int afesp_ccsd_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[4])
+{
+    return guarded(ctx, [&] {
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        ccsd_triples(ctx->cx, ctx->cc, t_begin, t_end, out);
+    });
+}
+
+// ---------------------------------------------------------------- operator layer on host arrays
+int afesp_contract(afesp_ctx* ctx, double alpha, const double* A, const char* la, const int64_t* dimsA, const double* B,
+                   const char* lb, const int64_t* dimsB, double beta, double* C, const char* lc, const int64_t* dimsC,
+                   int force_split, int force_tm, int force_tn)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        auto mk = [&](const char* l, const int64_t* dims) {
+            Tensor t;
+            t.rank = (int)strlen(l);
+            if (t.rank > 6) throw Error(1, "afesp_contract: rank > 6");
+            int64_t s = 1;
+            for (int i = 0; i < t.rank; ++i) {
+                t.dim[i] = dims[i];
+                t.stride[i] = s;
+                s *= dims[i];
+            }
+            t.d = cx.alloc(s);
+            return t;
+        };
+        Tensor tA = mk(la, dimsA), tB = mk(lb, dimsB), tC = mk(lc, dimsC);
+        AFESP_HIP(hipMemcpyAsync(tA.d, A, sizeof(double) * tA.size(), hipMemcpyHostToDevice, cx.stream));
+        AFESP_HIP(hipMemcpyAsync(tB.d, B, sizeof(double) * tB.size(), hipMemcpyHostToDevice, cx.stream));
+        AFESP_HIP(hipMemcpyAsync(tC.d, C, sizeof(double) * tC.size(), hipMemcpyHostToDevice, cx.stream));
+        contract(cx, alpha, tA, la, tB, lb, beta, tC, lc, 1, nullptr, nullptr, nullptr, force_split, force_tm, force_tn);
+        AFESP_HIP(hipMemcpyAsync(C, tC.d, sizeof(double) * tC.size(), hipMemcpyDeviceToHost, cx.stream));
+        cx.sync();
+        cx.release(tA.d); cx.release(tB.d); cx.release(tC.d);
+    });
+}
+
+int afesp_gemm(afesp_ctx* ctx, char transA, char transB, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
+               const double* B, double beta, double* C)
+{
+    // dgemm_wrapper (linalg.fpp:58-89): leading dimensions follow from the logical shapes
+    const bool ta = (transA == 'T' || transA == 't'), tb = (transB == 'T' || transB == 't');
+    int64_t dA[2] = {ta ? k : m, ta ? m : k}, dB[2] = {tb ? n : k, tb ? k : n}, dC[2] = {m, n};
+    return afesp_contract(ctx, alpha, A, ta ? "km" : "mk", dA, B, tb ? "nk" : "kn", dB, beta, C, "mn", dC, 0, 0, 0);
+}
+
+int afesp_permute4(afesp_ctx* ctx, const int64_t dims[4], const char order[4], const double* in, double* out, int has_beta, double beta)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        // omp_reshape (linalg.fpp:136-147): character d of `order` names the input index in output position d
+        const char names[5] = "ijkl";
+        char lo[5] = {0, 0, 0, 0, 0};
+        int64_t od[4];
+        for (int d = 0; d < 4; ++d) {
+            int p = order[d] - '1';
+            if (p < 0 || p > 3) throw Error(1, "afesp_permute4: bad order string");
+            lo[d] = names[p];
+            od[d] = dims[p];
+        }
+        Tensor tin = cx.tensor({dims[0], dims[1], dims[2], dims[3]}), tout = cx.tensor({od[0], od[1], od[2], od[3]});
+        AFESP_HIP(hipMemcpyAsync(tin.d, in, sizeof(double) * tin.size(), hipMemcpyHostToDevice, cx.stream));
+        if (has_beta) AFESP_HIP(hipMemcpyAsync(tout.d, out, sizeof(double) * tout.size(), hipMemcpyHostToDevice, cx.stream));
+        permute_add(cx, 1.0, tin, names, has_beta ? beta : 0.0, tout, lo);
+        AFESP_HIP(hipMemcpyAsync(out, tout.d, sizeof(double) * tout.size(), hipMemcpyDeviceToHost, cx.stream));
+        cx.sync();
+        cx.release(tin.d); cx.release(tout.d);
+    });
+}
+
+// ---------------------------------------------------------------- synthetic inputs generated in HBM
+int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double scale, uint64_t seed, int diis_n_errmat)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        const int64_t n = nocc + nvirt, ne = neri_of(n);
+        if (nocc <= 0 || nvirt <= 0 || n > 1024) throw Error(1, "afesp_synthetic_init: bad extents");
+        std::vector<double> e((size_t)n);
+        for (int64_t i = 0; i < nocc; ++i) e[i] = -2.0 + (nocc > 1 ? (double)i / (double)(nocc - 1) : 0.0);
+        for (int64_t a = 0; a < nvirt; ++a) e[nocc + a] = 1.0 + (nvirt > 1 ? 2.0 * (double)a / (double)(nvirt - 1) : 0.0);
+        double* packed = cx.alloc(ne);
+        hipLaunchKernelGGL(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, packed, ne, scale, seed);
+        AFESP_HIP(hipGetLastError());
+        ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, packed, e.data(), diis_n_errmat);
+        cx.release(packed);
+    });
+}
+
+int afesp_time_pp_ladder(afesp_ctx* ctx, int reps, double* ms_per_launch)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "afesp_time_pp_ladder: no CCSD state");
+        Context& cx = ctx->cx;
+        CCState& s = ctx->cc;
+        AFESP_HIP(hipSetDevice(cx.device));
+        hipEvent_t a, b;
+        AFESP_HIP(hipEventCreate(&a));
+        AFESP_HIP(hipEventCreate(&b));
+        contract(cx, 0.5, s.c, "ijef", s.v_vvvv, "efab", 0.0, s.r2, "ijab");   // warm (plan + caches)
+        AFESP_HIP(hipEventRecord(a, cx.stream));
+        for (int r = 0; r < reps; ++r) contract(cx, 0.5, s.c, "ijef", s.v_vvvv, "efab", 0.0, s.r2, "ijab");
+        AFESP_HIP(hipEventRecord(b, cx.stream));
+        AFESP_HIP(hipEventSynchronize(b));
+        float ms = 0.f;
+        AFESP_HIP(hipEventElapsedTime(&ms, a, b));
+        if (ms_per_launch) *ms_per_launch = (double)ms / (reps > 0 ? reps : 1);
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// ccsd.h -- device-resident state of the spin-free CCSD solver and the (T) correction.
+#pragma once
+#include "afesp_internal.h"
+
+namespace afesp {
+
+struct CCState {
+    int o = 0, v = 0;
+    bool ready = false;
+    double* e = nullptr;   // orbital energies on device, length o+v
+    // integral slices (ccsd.f90:507-512) and their immutable "2x - x^T" companions
+    Tensor v_oovv, v_ovov, v_vvov, v_oovo, v_oooo, v_vvvv, w_oovv, w_vvov, w_oovo;
+    Tensor D1, D2, t1, t2, t2_old, r1, r2;
+    Tensor I_vo, I_vv, I_oo_p, I_oo, c, asym, x_voov, I_oooo, I_ovov, I_voov, I_vovv_p, I_ooov_p;
+    // DIIS ring (ccsd.f90:38-67): vectors are [t1 ; t2] concatenated, length nvec
+    int nerr = 0, nact = 0, it = 0;
+    int64_t nvec = 0;
+    double *amp = nullptr;      // [t1 ; t2] contiguous, t1 = amp, t2 = amp + o*v
+    double *amp_s = nullptr;    // amplitudes saved at the top of the iteration (t1_s/t2_s)
+    double *hist_t = nullptr, *hist_e = nullptr;   // nerr * nvec each
+    double *coef = nullptr;     // device coefficients
+    std::vector<double> B;      // host copy of the error overlap matrix (nerr x nerr, full)
+    double energy = 0.0, energy_old = 0.0, rms = 0.0;
+};
+
+// eri_mo_dev: packed chemist MO integrals ON DEVICE (length neri(o+v)); e_host: orbital energies (host)
+void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, const double* e_host, int diis_nerr);
+void ccsd_diis_save(Context& cx, CCState& s);
+void ccsd_intermediates(Context& cx, CCState& s);
+void ccsd_amplitudes(Context& cx, CCState& s);
+// updates s.energy / s.energy_old / s.rms (un-rooted, as ccsd.f90:1806); returns 1 if converged
+int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol);
+void ccsd_diis_update(Context& cx, CCState& s);
+void ccsd_free(Context& cx, CCState& s);
+
+// (T): out[0]=E[T] out[1]=E(T) out[2]=D[T] out[3]=D(T) contributions of the unordered triples with
+// flat index in [t_begin, t_end) of the i<=j<=k enumeration; D base term (ccsd.f90:2243) added iff t_begin==0.
+int64_t triples_count(int o);
+void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host);
+
+}  // namespace afesp

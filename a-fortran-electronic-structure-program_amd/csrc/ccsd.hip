@@ -1,0 +1,224 @@
+// ccsd.hip -- spin-free CCSD (Piecuch et al., CPC 149 (2002) 71) on the device.
+//
+// Follows the fixed-point path of the reference exactly -- MP1 start, Jacobi update, DIIS from iteration 1,
+// the same convergence rule (src/ccsd.f90:279-402) -- but every contraction site of
+// update_restricted_intermediates (src/ccsd.f90:1040-1312) and update_amplitudes_restricted (:1538-1732)
+// is a single gather-GEMM on the resident tensors: no reshape temporaries, and the integrals are never
+// antisymmetrised in place (the reference mutates and restores v_oovv/v_vvov/v_oovo every iteration,
+// :1089,:1101-1126; here the three "2x - x^T" companions are built once at init).
+#include <cmath>
+#include <cstring>
+
+#include "ccsd.h"
+
+namespace afesp {
+
+static inline int64_t tri64(int64_t i, int64_t j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, const double* e_host, int diis_nerr)
+{
+    if (o <= 0 || v <= 0) throw Error(1, "ccsd_init: need at least one occupied and one virtual orbital");
+    ccsd_free(cx, s);
+    s.o = o; s.v = v;
+    const int64_t O = o, V = v, n = o + v, ov = O * V, o2v2 = O * O * V * V;
+    s.e = cx.alloc(n);
+    AFESP_HIP(hipMemcpyAsync(s.e, e_host, sizeof(double) * n, hipMemcpyHostToDevice, cx.stream));
+    cx.sync();
+    s.v_oovv = cx.tensor({O, O, V, V}); s.v_ovov = cx.tensor({O, V, O, V}); s.v_vvov = cx.tensor({V, V, O, V});
+    s.v_oovo = cx.tensor({O, O, V, O}); s.v_oooo = cx.tensor({O, O, O, O}); s.v_vvvv = cx.tensor({V, V, V, V});
+    s.w_oovv = cx.tensor({O, O, V, V}); s.w_vvov = cx.tensor({V, V, O, V}); s.w_oovo = cx.tensor({O, O, V, O});
+    // ccsd.f90:496-512: <pq|rs> = (pr|qs), virtual offsets removed
+    k_slice_phys(cx, s.v_oovv.d, eri_mo_dev, o, o, v, v, 0, 0, o, o);
+    k_slice_phys(cx, s.v_ovov.d, eri_mo_dev, o, v, o, v, 0, o, 0, o);
+    k_slice_phys(cx, s.v_vvov.d, eri_mo_dev, v, v, o, v, o, o, 0, o);
+    k_slice_phys(cx, s.v_oovo.d, eri_mo_dev, o, o, v, o, 0, 0, o, 0);
+    k_slice_phys(cx, s.v_oooo.d, eri_mo_dev, o, o, o, o, 0, 0, 0, 0);
+    k_slice_phys(cx, s.v_vvvv.d, eri_mo_dev, v, v, v, v, o, o, o, o);
+    k_antisym_pair(cx, s.w_oovv.d, s.v_oovv.d, O, O, V, V, 1);   // 2<ij|ab> - <ij|ba>   (ccsd.f90:1089)
+    k_antisym_pair(cx, s.w_vvov.d, s.v_vvov.d, V, V, O, V, 0);   // 2<ab|ic> - <ba|ic>   (ccsd.f90:1101)
+    k_antisym_pair(cx, s.w_oovo.d, s.v_oovo.d, O, O, V, O, 0);   // 2<ij|ak> - <ji|ak>   (ccsd.f90:1121)
+    s.D1 = cx.tensor({O, V}); s.D2 = cx.tensor({O, O, V, V});
+    k_denominators(cx, s.D1.d, s.D2.d, s.e, o, v);
+    s.nvec = ov + o2v2;
+    s.amp = cx.alloc(s.nvec);
+    s.t1 = view(s.amp, {O, V}); s.t2 = view(s.amp + ov, {O, O, V, V});
+    double* res = cx.alloc(s.nvec);
+    s.r1 = view(res, {O, V}); s.r2 = view(res + ov, {O, O, V, V});
+    s.t2_old = cx.tensor({O, O, V, V});
+    s.I_vo = cx.tensor({V, O}); s.I_vv = cx.tensor({V, V}); s.I_oo_p = cx.tensor({O, O}); s.I_oo = cx.tensor({O, O});
+    s.c = cx.tensor({O, O, V, V}); s.asym = cx.tensor({O, O, V, V}); s.x_voov = cx.tensor({V, O, O, V});
+    s.I_oooo = cx.tensor({O, O, O, O}); s.I_ovov = cx.tensor({O, V, O, V}); s.I_voov = cx.tensor({V, O, O, V});
+    s.I_vovv_p = cx.tensor({V, O, V, V}); s.I_ooov_p = cx.tensor({O, O, O, V});
+    // ccsd.f90:520-521: t1 = 0, t2 = v_oovv / D
+    k_div(cx, s.t2.d, s.v_oovv.d, s.D2.d, o2v2);
+    // ccsd.f90:577-615
+    s.nerr = diis_nerr; s.nact = 0; s.it = 0;
+    if (diis_nerr >= 2) {
+        if (diis_nerr > 15) throw Error(1, "ccsd_init: ccsd_diis_n_errmat > 15 is not supported");
+        s.amp_s = cx.alloc(s.nvec);
+        s.hist_t = cx.alloc(s.nvec * diis_nerr);
+        s.hist_e = cx.alloc(s.nvec * diis_nerr);
+        s.coef = cx.alloc(32);
+        s.B.assign((size_t)diis_nerr * diis_nerr, 0.0);
+    }
+    s.energy = s.energy_old = s.rms = 0.0;
+    s.ready = true;
+    cx.sync();
+}
+
+void ccsd_free(Context& cx, CCState& s)
+{
+    if (!s.o) return;
+    double* bufs[] = {s.e, s.v_oovv.d, s.v_ovov.d, s.v_vvov.d, s.v_oovo.d, s.v_oooo.d, s.v_vvvv.d, s.w_oovv.d, s.w_vvov.d,
+                      s.w_oovo.d, s.D1.d, s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.I_vo.d, s.I_vv.d, s.I_oo_p.d, s.I_oo.d, s.c.d,
+                      s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_vovv_p.d, s.I_ooov_p.d, s.amp_s, s.hist_t,
+                      s.hist_e, s.coef};
+    for (double* b : bufs) cx.release(b);
+    s = CCState();
+}
+
+void ccsd_diis_save(Context& cx, CCState& s)
+{
+    if (s.nerr >= 2) k_copy(cx, s.amp_s, s.amp, s.nvec);   // ccsd.f90:342-343
+}
+
+void ccsd_intermediates(Context& cx, CCState& s)
+{
+    auto C = [&](double al, const Tensor& A, const char* la, const Tensor& B, const char* lb, double be, const Tensor& Cc,
+                 const char* lc) { contract(cx, al, A, la, B, lb, be, Cc, lc); };
+    // asym_t2, c_oovv                                                    ccsd.f90:1063-1079
+    k_asym_c(cx, s.asym.d, s.c.d, s.t1.d, s.t2.d, s.o, s.v);
+    // I_vo(a,i) = (2<im|ae> - <im|ea>) t(m,e)                            ccsd.f90:1085-1092
+    C(1.0, s.w_oovv, "miea", s.t1, "me", 0.0, s.I_vo, "ai");
+    // I_vv(b,a)                                                          ccsd.f90:1096-1113
+    C(1.0, s.w_vvov, "ebma", s.t1, "me", 0.0, s.I_vv, "ba");
+    C(-1.0, s.w_oovv, "mneb", s.c, "mnea", 1.0, s.I_vv, "ba");
+    // I_oo_p(j,i)                                                        ccsd.f90:1115-1132
+    C(1.0, s.w_oovo, "miej", s.t1, "me", 0.0, s.I_oo_p, "ji");
+    C(1.0, s.asym, "mjef", s.v_oovv, "mief", 1.0, s.I_oo_p, "ji");
+    // I_oo(j,i) = I_oo_p + t(j,e) I_vo(e,i)                              ccsd.f90:1134-1137
+    k_copy(cx, s.I_oo.d, s.I_oo_p.d, s.I_oo.size());
+    C(1.0, s.t1, "je", s.I_vo, "ei", 1.0, s.I_oo, "ji");
+    // I_oooo(k,l,i,j)                                                    ccsd.f90:1139-1156
+    k_copy(cx, s.I_oooo.d, s.v_oooo.d, s.I_oooo.size());
+    C(1.0, s.c, "klef", s.v_oovv, "ijef", 1.0, s.I_oooo, "klij");
+    C(1.0, s.t1, "ke", s.v_oovo, "ilej", 1.0, s.I_oooo, "klij");
+    C(1.0, s.t1, "le", s.v_oovo, "jkei", 1.0, s.I_oooo, "klij");
+    // I_ovov(j,b,i,a)                                                    ccsd.f90:1158-1191
+    k_copy(cx, s.I_ovov.d, s.v_ovov.d, s.I_ovov.size());
+    C(-0.5, s.v_oovv, "mibe", s.c, "mjae", 1.0, s.I_ovov, "jbia");
+    C(-1.0, s.v_oovo, "mibj", s.t1, "ma", 1.0, s.I_ovov, "jbia");
+    C(1.0, s.t1, "je", s.v_vvov, "ebia", 1.0, s.I_ovov, "jbia");
+    // x_voov(b,j,i,a) = <be|ia> t(j,e)                                   ccsd.f90:1275-1290
+    C(1.0, s.v_vvov, "beia", s.t1, "je", 0.0, s.x_voov, "bjia");
+    // I_voov(b,j,i,a)                                                    ccsd.f90:1193-1252
+    permute_add(cx, 1.0, s.v_oovv, "jiab", 0.0, s.I_voov, "bjia");
+    k_axpby(cx, s.I_voov.d, 1.0, s.x_voov.d, 1.0, s.I_voov.size());
+    C(0.5, s.w_oovv, "imbe", s.t2, "mjea", 1.0, s.I_voov, "bjia");
+    C(-0.5, s.v_oovv, "imbe", s.c, "mjae", 1.0, s.I_voov, "bjia");
+    C(-1.0, s.v_oovo, "imbj", s.t1, "ma", 1.0, s.I_voov, "bjia");
+    // I_vovv_p(c,i,a,b)                                                  ccsd.f90:1255-1272, :1296-1299
+    permute_add(cx, 1.0, s.v_vvov, "baic", 0.0, s.I_vovv_p, "ciab");
+    C(-1.0, s.v_oovv, "micb", s.t1, "ma", 1.0, s.I_vovv_p, "ciab");
+    C(-1.0, s.v_ovov, "maic", s.t1, "mb", 1.0, s.I_vovv_p, "ciab");
+    // I_ooov_p(j,k,i,a)                                                  ccsd.f90:1302-1308
+    permute_add(cx, 1.0, s.v_oovo, "kjai", 0.0, s.I_ooov_p, "jkia");
+    C(1.0, s.t2, "jkef", s.v_vvov, "efia", 1.0, s.I_ooov_p, "jkia");
+    C(1.0, s.t1, "je", s.x_voov, "ekia", 1.0, s.I_ooov_p, "jkia");
+}
+
+void ccsd_amplitudes(Context& cx, CCState& s)
+{
+    auto C = [&](double al, const Tensor& A, const char* la, const Tensor& B, const char* lb, double be, const Tensor& Cc,
+                 const char* lc) { contract(cx, al, A, la, B, lb, be, Cc, lc); };
+    // ---- T1, Eq. 43                                                    ccsd.f90:1569-1631
+    C(1.0, s.t1, "ie", s.I_vv, "ea", 0.0, s.r1, "ia");
+    C(-1.0, s.I_oo_p, "im", s.t1, "ma", 1.0, s.r1, "ia");
+    C(1.0, s.asym, "miea", s.I_vo, "em", 1.0, s.r1, "ia");
+    C(2.0, s.v_oovv, "miea", s.t1, "me", 1.0, s.r1, "ia");
+    C(-1.0, s.v_ovov, "maie", s.t1, "me", 1.0, s.r1, "ia");
+    C(-1.0, s.v_oovo, "mien", s.asym, "mnea", 1.0, s.r1, "ia");
+    C(1.0, s.asym, "mief", s.v_vvov, "efma", 1.0, s.r1, "ia");
+    // ---- T2, Eq. 44                                                    ccsd.f90:1637-1716
+    C(1.0, s.t2, "ijae", s.I_vv, "eb", 0.0, s.r2, "ijab");                 // :1647
+    C(-1.0, s.t2, "miba", s.I_oo, "jm", 1.0, s.r2, "ijab");                // :1654-1664
+    C(0.5, s.c, "ijef", s.v_vvvv, "efab", 1.0, s.r2, "ijab");              // :1669  particle-particle ladder
+    C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");              // :1673  hole-hole ladder
+    C(-1.0, s.t2, "mjae", s.I_ovov, "iemb", 1.0, s.r2, "ijab");            // :1680-1695 ring terms
+    C(-1.0, s.I_ovov, "iema", s.t2, "mjeb", 1.0, s.r2, "ijab");
+    C(1.0, s.asym, "miea", s.I_voov, "ejmb", 1.0, s.r2, "ijab");
+    C(1.0, s.t1, "ie", s.I_vovv_p, "ejab", 1.0, s.r2, "ijab");             // :1700
+    C(-1.0, s.t1, "ma", s.I_ooov_p, "ijmb", 1.0, s.r2, "ijab");            // :1705-1715
+    // P(ia/jb), + v_oovv, Jacobi divide                                  ccsd.f90:1720-1728
+    k_div(cx, s.t1.d, s.r1.d, s.D1.d, s.t1.size());
+    k_t2_update(cx, s.t2.d, s.r2.d, s.v_oovv.d, s.D2.d, s.o, s.v);
+}
+
+int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol)
+{
+    k_cc_energy(cx, cx.scal, s.v_oovv.d, s.t1.d, s.t2.d, s.t2_old.d, s.o, s.v);
+    double* h = host_scalars(cx, 2);
+    s.energy_old = s.energy;        // ccsd.f90:1760
+    s.energy = h[0];
+    s.rms = h[1];                   // un-rooted, ccsd.f90:1806
+    return (std::sqrt(h[1]) < t_tol && std::fabs(s.energy - s.energy_old) < e_tol) ? 1 : 0;   // ccsd.f90:1805
+}
+
+// Symmetric solve of the (n+1)x(n+1) DIIS system on the host (the reference calls LAPACK dsysv, linalg.fpp:38-56;
+// the matrix is at most 16x16).  Gaussian elimination with partial pivoting.
+static int solve_dense(int n, std::vector<double>& A, std::vector<double>& b)
+{
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double big = std::fabs(A[k + n * k]);
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(A[i + n * k]) > big) { big = std::fabs(A[i + n * k]); p = i; }
+        if (big == 0.0) return 1;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) std::swap(A[k + n * j], A[p + n * j]);
+            std::swap(b[k], b[p]);
+        }
+        for (int i = k + 1; i < n; ++i) {
+            double f = A[i + n * k] / A[k + n * k];
+            if (f == 0.0) continue;
+            for (int j = k; j < n; ++j) A[i + n * j] -= f * A[k + n * j];
+            b[i] -= f * b[k];
+        }
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        double x = b[k];
+        for (int j = k + 1; j < n; ++j) x -= A[k + n * j] * b[j];
+        b[k] = x / A[k + n * k];
+    }
+    return 0;
+}
+
+void ccsd_diis_update(Context& cx, CCState& s)
+{
+    if (s.nerr < 2) return;
+    // ccsd.f90:633-646
+    s.it += 1;
+    if (s.it > s.nerr) s.it -= s.nerr;
+    if (s.nact < s.nerr) s.nact += 1;
+    const int slot = s.it - 1, n = s.nact;
+    double* ht = s.hist_t + (int64_t)slot * s.nvec;
+    double* he = s.hist_e + (int64_t)slot * s.nvec;
+    k_copy(cx, ht, s.amp, s.nvec);
+    k_sub(cx, he, s.amp, s.amp_s, s.nvec);
+    // ccsd.f90:653-663: only row/column `slot` of B changes; the other entries are sums over unchanged vectors
+    k_dots(cx, cx.scal, he, s.hist_e, s.nvec, n, s.nvec, false);
+    double* h = host_scalars(cx, n);
+    for (int j = 0; j < n; ++j) s.B[slot + s.nerr * j] = s.B[j + s.nerr * slot] = h[j];
+    const int N = n + 1;
+    std::vector<double> A((size_t)N * N, 0.0), c((size_t)N, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) A[i + N * j] = s.B[i + s.nerr * j];
+    for (int j = 0; j < n; ++j) A[n + N * j] = A[j + N * n] = -1.0;
+    c[n] = -1.0;
+    if (solve_dense(N, A, c)) throw Error(4, "ccsd::update_diis_cc: Linear solve failed!");   // ccsd.f90:666
+    AFESP_HIP(hipMemcpyAsync(s.coef, c.data(), sizeof(double) * n, hipMemcpyHostToDevice, cx.stream));
+    cx.sync();   // c is a local
+    k_lincomb(cx, s.amp, s.hist_t, s.nvec, s.coef, n, s.nvec);   // ccsd.f90:668-673
+}
+
+}  // namespace afesp

@@ -1,0 +1,270 @@
+// contract.hip -- device context and the label-driven contraction planner on top of the gather-GEMM.
+//
+// A contraction site of the reference is "omp_reshape the operands until dgemm_wrapper applies"
+// (src/linalg.fpp:58-156; sites listed in SURVEY.md section 2a).  Here a site is one contract() call that
+// names the tensor indices; the planner groups them into row / column / summation groups, orders each group for
+// coalesced access, builds the six offset tables once (cached per shape) and launches the MFMA kernel.
+#include <algorithm>
+#include <cstring>
+
+#include "afesp_internal.h"
+
+namespace afesp {
+
+// ------------------------------------------------------------------ context
+double* Context::alloc(int64_t n)
+{
+    void* p = nullptr;
+    size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(double);
+    AFESP_HIP(hipMalloc(&p, bytes));
+    AFESP_HIP(hipMemsetAsync(p, 0, bytes, stream));
+    owned.push_back(p);
+    return (double*)p;
+}
+int64_t* Context::alloc_i64(int64_t n) { return (int64_t*)alloc(n); }
+void Context::release(void* p)
+{
+    if (!p) return;
+    auto it = std::find(owned.begin(), owned.end(), p);
+    if (it != owned.end()) {
+        owned.erase(it);
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(p);
+    }
+}
+Tensor Context::tensor(std::initializer_list<int64_t> dims)
+{
+    int64_t n = 1;
+    for (auto d : dims) n *= d;
+    return view(alloc(n), dims);
+}
+void Context::sync() { AFESP_HIP(hipStreamSynchronize(stream)); }
+Context::~Context()
+{
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (void* p : owned) (void)hipFree(p);
+    if (scal_host) (void)hipHostFree(scal_host);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+Tensor view(double* d, std::initializer_list<int64_t> dims)
+{
+    Tensor t;
+    t.d = d;
+    t.rank = (int)dims.size();
+    int64_t s = 1;
+    int i = 0;
+    for (auto x : dims) {
+        t.dim[i] = x;
+        t.stride[i] = s;
+        s *= x;
+        ++i;
+    }
+    return t;
+}
+
+double* host_scalars(Context& cx, int n)
+{
+    AFESP_HIP(hipMemcpyAsync(cx.scal_host, cx.scal, sizeof(double) * n, hipMemcpyDeviceToHost, cx.stream));
+    cx.sync();
+    return cx.scal_host;
+}
+
+// ------------------------------------------------------------------ planner
+namespace {
+
+struct Lab {
+    char c;
+    int64_t dim;
+    int64_t sa, sb, sc;   // strides in A, B, C (0 if absent)
+};
+
+int64_t stride_of(const Tensor& t, const char* l, char c)
+{
+    for (int i = 0; i < t.rank; ++i)
+        if (l[i] == c) return t.stride[i];
+    return -1;
+}
+
+char min_stride_label(const Tensor& t, const char* l)
+{
+    char best = 0;
+    int64_t bs = INT64_MAX;
+    for (int i = 0; i < t.rank; ++i)
+        if (t.dim[i] > 1 && t.stride[i] < bs) {
+            bs = t.stride[i];
+            best = l[i];
+        }
+    if (!best && t.rank > 0) best = l[0];
+    return best;
+}
+
+std::vector<int64_t> table(const std::vector<Lab>& g, int which)
+{
+    int64_t n = 1;
+    for (auto& l : g) n *= l.dim;
+    std::vector<int64_t> t((size_t)n);
+    std::vector<int64_t> idx(g.size(), 0);
+    for (int64_t x = 0; x < n; ++x) {
+        int64_t off = 0;
+        for (size_t q = 0; q < g.size(); ++q) off += idx[q] * (which == 0 ? g[q].sa : which == 1 ? g[q].sb : g[q].sc);
+        t[(size_t)x] = off;
+        for (size_t q = 0; q < g.size(); ++q) {
+            if (++idx[q] < g[q].dim) break;
+            idx[q] = 0;
+        }
+    }
+    return t;
+}
+
+int64_t* upload(Context& cx, const std::vector<int64_t>& h)
+{
+    int64_t* d = cx.alloc_i64((int64_t)h.size());
+    AFESP_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
+    AFESP_HIP(hipStreamSynchronize(cx.stream));   // h is a temporary
+    return d;
+}
+
+void sort_by(std::vector<Lab>& g, int which)
+{
+    std::stable_sort(g.begin(), g.end(), [which](const Lab& x, const Lab& y) {
+        int64_t a = which == 0 ? x.sa : which == 1 ? x.sb : x.sc, b = which == 0 ? y.sa : which == 1 ? y.sb : y.sc;
+        return a < b;
+    });
+}
+
+bool has(const std::vector<Lab>& g, char c)
+{
+    for (auto& l : g)
+        if (l.c == c) return true;
+    return false;
+}
+
+}  // namespace
+
+void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, const Tensor& B0, const char* lb0, double beta,
+              const Tensor& C, const char* lc, int nbatch, const int64_t* bA0, const int64_t* bB0, const int64_t* bC,
+              int force_split, int force_tm, int force_tn)
+{
+    if ((int)strlen(la0) != A0.rank || (int)strlen(lb0) != B0.rank || (int)strlen(lc) != C.rank)
+        throw Error(3, std::string("contract: label/rank mismatch ") + la0 + "," + lb0 + "->" + lc);
+    std::string key = std::string(la0) + "," + lb0 + ">" + lc;
+    auto sig = [&key](const Tensor& t) {
+        for (int i = 0; i < t.rank; ++i) key += ":" + std::to_string(t.dim[i]) + "/" + std::to_string(t.stride[i]);
+        key += ";";
+    };
+    sig(A0); sig(B0); sig(C);
+    auto it = cx.plans.find(key);
+    if (it == cx.plans.end()) {
+        // orientation: the kernel's column index n runs along lanes in the epilogue -> put C's fastest label in N
+        char cfast = min_stride_label(C, lc);
+        bool swapped = stride_of(A0, la0, cfast) >= 0;
+        const Tensor& A = swapped ? B0 : A0;
+        const Tensor& B = swapped ? A0 : B0;
+        const char* la = swapped ? lb0 : la0;
+        const char* lb = swapped ? la0 : lb0;
+        std::vector<Lab> M, N, K;
+        for (int i = 0; i < A.rank; ++i) {
+            Lab l{la[i], A.dim[i], A.stride[i], stride_of(B, lb, la[i]), stride_of(C, lc, la[i])};
+            bool inB = l.sb >= 0, inC = l.sc >= 0;
+            if (inB == inC) throw Error(3, "contract: label '" + std::string(1, l.c) + "' must be in exactly two tensors: " + key);
+            if (inB && B.dim[std::strchr(lb, l.c) - lb] != l.dim) throw Error(3, "contract: extent mismatch in " + key);
+            if (inC && C.dim[std::strchr(lc, l.c) - lc] != l.dim) throw Error(3, "contract: extent mismatch in " + key);
+            (inC ? M : K).push_back(l);
+        }
+        for (int i = 0; i < B.rank; ++i) {
+            Lab l{lb[i], B.dim[i], stride_of(A, la, lb[i]), B.stride[i], stride_of(C, lc, lb[i])};
+            if (l.sa >= 0) continue;   // K label, already taken from A
+            if (l.sc < 0) throw Error(3, "contract: label '" + std::string(1, l.c) + "' only in one operand: " + key);
+            if (C.dim[std::strchr(lc, l.c) - lc] != l.dim) throw Error(3, "contract: extent mismatch in " + key);
+            N.push_back(l);
+        }
+        if ((int)(M.size() + N.size()) != C.rank) throw Error(3, "contract: output label not produced: " + key);
+        char afast = min_stride_label(A, la), bfast = min_stride_label(B, lb);
+        sort_by(N, 2);
+        sort_by(M, has(M, afast) ? 0 : 2);
+        if (has(K, afast)) sort_by(K, 0);
+        else if (has(K, bfast)) sort_by(K, 1);
+        else sort_by(K, 0);
+        Plan p;
+        p.swapped = swapped;
+        p.a_kc = !K.empty() && K[0].c == afast && K[0].sa == 1;
+        p.b_kc = !K.empty() && K[0].c == bfast && K[0].sb == 1;
+        auto tAm = table(M, 0), tAk = table(K, 0), tBk = table(K, 1), tBn = table(N, 1), tCm = table(M, 2), tCn = table(N, 2);
+        if (tAm.size() > INT32_MAX || tBn.size() > INT32_MAX || tAk.size() > INT32_MAX) throw Error(3, "contract: extent too large");
+        p.M = (int)tAm.size(); p.N = (int)tBn.size(); p.K = (int)tAk.size();
+        p.offAm = upload(cx, tAm); p.offAk = upload(cx, tAk); p.offBk = upload(cx, tBk);
+        p.offBn = upload(cx, tBn); p.offCm = upload(cx, tCm); p.offCn = upload(cx, tCn);
+        it = cx.plans.emplace(key, p).first;
+    }
+    const Plan& p = it->second;
+    GettProblem g;
+    g.A = p.swapped ? B0.d : A0.d;
+    g.B = p.swapped ? A0.d : B0.d;
+    g.C = C.d;
+    g.offAm = p.offAm; g.offAk = p.offAk; g.offBk = p.offBk; g.offBn = p.offBn; g.offCm = p.offCm; g.offCn = p.offCn;
+    g.M = p.M; g.N = p.N; g.K = p.K;
+    g.alpha = alpha; g.beta = beta;
+    g.nbatch = nbatch;
+    g.batchA = p.swapped ? bB0 : bA0;
+    g.batchB = p.swapped ? bA0 : bB0;
+    g.batchC = bC;
+    g.a_kcontig = p.a_kc; g.b_kcontig = p.b_kc;
+    AFESP_HIP(gett_launch(g, cx.ws, cx.stream, force_split, force_tm, force_tn));
+}
+
+// ------------------------------------------------------------------ permute_add
+struct PermArgs {
+    int rank;
+    int64_t dim[6], so[6], si[6];
+    int64_t n;
+    double alpha, beta;
+};
+
+__global__ __launch_bounds__(256) void permute_add_kernel(double* __restrict__ out, const double* __restrict__ in, PermArgs a)
+{
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < a.n; x += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = x, oo = 0, io = 0;
+        for (int q = 0; q < a.rank; ++q) {
+            int64_t i = r % a.dim[q];
+            r /= a.dim[q];
+            oo += i * a.so[q];
+            io += i * a.si[q];
+        }
+        double val = a.alpha * in[io];
+        if (a.beta != 0.0) val += a.beta * out[oo];
+        out[oo] = val;
+    }
+}
+
+void permute_add(Context& cx, double alpha, const Tensor& in, const char* li, double beta, const Tensor& out, const char* lo)
+{
+    if ((int)strlen(li) != in.rank || (int)strlen(lo) != out.rank || in.rank != out.rank || in.rank > 6)
+        throw Error(3, "permute_add: rank mismatch");
+    // iterate in ascending output stride so that consecutive threads write consecutive addresses
+    std::vector<int> ord(out.rank);
+    for (int i = 0; i < out.rank; ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return out.stride[x] < out.stride[y]; });
+    PermArgs a;
+    a.rank = out.rank;
+    a.n = 1;
+    for (int q = 0; q < out.rank; ++q) {
+        int i = ord[q];
+        const char* p = std::strchr(li, lo[i]);
+        if (!p) throw Error(3, "permute_add: labels are not a permutation");
+        int j = (int)(p - li);
+        if (in.dim[j] != out.dim[i]) throw Error(3, "permute_add: extent mismatch");
+        a.dim[q] = out.dim[i];
+        a.so[q] = out.stride[i];
+        a.si[q] = in.stride[j];
+        a.n *= out.dim[i];
+    }
+    a.alpha = alpha;
+    a.beta = beta;
+    if (a.n == 0) return;
+    unsigned grid = (unsigned)std::min<int64_t>((a.n + 255) / 256, 4096);
+    hipLaunchKernelGGL(permute_add_kernel, dim3(grid), dim3(256), 0, cx.stream, out.d, in.d, a);
+    AFESP_HIP(hipGetLastError());
+}
+
+}  // namespace afesp

@@ -1,0 +1,48 @@
+// gett.h -- separable-offset ("gather") fp64 GEMM on MFMA for gfx950.
+//
+//   C[offCm[m] + offCn[n]] = alpha * sum_k A[offAm[m] + offAk[k]] * B[offBk[k] + offBn[n]] + beta * C[...]
+//
+// Every tensor contraction of the coupled-cluster path is a GEMM whose row, column
+// and summation indices are each a *group* of tensor indices.  Because the address of a tensor element is a
+// sum of per-index strides, grouping indices keeps the address separable into a row part and a column part.
+// The reference permutes tensors in memory (omp_reshape, src/linalg.fpp:99-156) until a dense dgemm
+// (src/linalg.fpp:58-89) applies; here the permutation lives in three pairs of small offset tables and the
+// operands are gathered straight into LDS, so no permuted copy ever touches HBM.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace afesp {
+
+struct GettProblem {
+    const double* A;
+    const double* B;
+    double* C;
+    const int64_t* offAm;  // [M]
+    const int64_t* offAk;  // [K]
+    const int64_t* offBk;  // [K]
+    const int64_t* offBn;  // [N]
+    const int64_t* offCm;  // [M]
+    const int64_t* offCn;  // [N]
+    int M, N, K;
+    double alpha, beta;
+    // batching: grid.z problems, operand bases shifted by batch{A,B,C}[z] elements (device arrays or null)
+    int nbatch;
+    const int64_t* batchA;
+    const int64_t* batchB;
+    const int64_t* batchC;
+    // layout hints: true = consecutive k are (mostly) consecutive in memory, false = consecutive m (or n) are
+    bool a_kcontig, b_kcontig;
+};
+
+// Workspace for split-K partial sums.  The launcher picks the tile shape and the split count itself.
+struct GettWorkspace {
+    double* ptr;
+    size_t bytes;
+};
+
+// Returns hipSuccess or the launch error.  `force_split` > 0 overrides the heuristic (tests).
+hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_t stream, int force_split = 0,
+                       int force_tm = 0, int force_tn = 0);
+
+}  // namespace afesp

@@ -1,0 +1,304 @@
+// gett.hip -- separable-offset fp64 GEMM on v_mfma_f64_16x16x4_f64 (gfx950).  See gett.h.
+//
+// Work decomposition (one workgroup = 256 threads = 4 waves in a 2x2 grid):
+//   block tile  BM x BN = (32*TM) x (32*TN),  K step BK = 16
+//   wave tile   (16*TM) x (16*TN) = TM x TN accumulators of v_mfma_f64_16x16x4_f64
+// Per K step a wave issues 4*TM*TN MFMAs (64 cycles each on gfx950: fp64 MFMA runs at 32 FLOP/clk/SIMD)
+// against 4*(TM+TN) ds_read_b64, so the matrix pipe, not LDS, is the limiter; the global gather
+// for tile t+1 is issued before the MFMAs of tile t and parked in registers (one barrier per K step).
+//
+// LDS images (padding chosen so that ds_read_b64 fragment reads AND the staging ds_write_b64 are
+// bank-conflict free; bank = (byte/4) mod 64 for b64 reads, mod 32 for writes):
+//   operand contiguous along m (or n):  s[k][mn], row stride BMN+16 doubles  (stride = 32 mod 64 dwords)
+//   operand contiguous along k:         s[mn][k], row stride BK+2  doubles  (36 dwords)
+// MFMA operand lane map (f64 16x16x4): lane l supplies A[m = l&15][k = l>>4], B[k = l>>4][n = l&15];
+// result register r of lane l is C[m = (l>>4) + 4r][n = l&15]  (cdna_hip_programming.md section 3).
+#include "gett.h"
+
+namespace afesp {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;
+constexpr int NT = 256;
+
+template <int BMN, bool KC>
+struct TileImg {
+    static constexpr int LD = KC ? (BK + 2) : (BMN + 16);
+    static constexpr int SIZE = KC ? BMN * LD : BK * LD;
+    static constexpr int PER = BMN * BK / NT;  // elements staged per thread per K step
+    __device__ static __forceinline__ int at(int mn, int k) { return KC ? mn * LD + k : k * LD + mn; }
+    // staging map: which (mn,k) of the tile thread t handles as its r-th element
+    __device__ static __forceinline__ int mn_of(int t, int r) { return KC ? (t >> 4) + 16 * r : t % BMN; }
+    __device__ static __forceinline__ int k_of(int t, int r) { return KC ? (t & 15) : t / BMN + (NT / BMN) * r; }
+};
+
+// Per-thread constant part of the gather addresses of one operand.
+template <int BMN, bool KC>
+struct Stager {
+    using T = TileImg<BMN, KC>;
+    static constexpr int NROW = KC ? T::PER : 1;
+    int64_t rowoff[NROW];
+    bool rowok[NROW];
+    const double* base;
+    const int64_t* offK;
+    int K;
+
+    __device__ __forceinline__ void init(const double* X, const int64_t* offMN, const int64_t* offK_, int mn0, int MN,
+                                         int K_, int t)
+    {
+        base = X;
+        offK = offK_;
+        K = K_;
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+            int mn = mn0 + T::mn_of(t, r);
+            rowok[r] = mn < MN;
+            rowoff[r] = offMN[mn < MN ? mn : MN - 1];
+        }
+    }
+    __device__ __forceinline__ void fetch(double (&reg)[T::PER], int k0, int kend, int t) const
+    {
+        if (KC) {
+            int k = k0 + T::k_of(t, 0);
+            bool kok = k < kend;
+            int64_t ko = offK[kok ? k : K - 1];
+#pragma unroll
+            for (int r = 0; r < T::PER; ++r) reg[r] = (kok && rowok[r]) ? base[rowoff[r] + ko] : 0.0;
+        } else {
+#pragma unroll
+            for (int r = 0; r < T::PER; ++r) {
+                int k = k0 + T::k_of(t, r);
+                bool kok = k < kend;
+                int64_t ko = offK[kok ? k : K - 1];
+                reg[r] = (kok && rowok[0]) ? base[rowoff[0] + ko] : 0.0;
+            }
+        }
+    }
+    __device__ __forceinline__ void stash(double* s, const double (&reg)[T::PER], int t) const
+    {
+#pragma unroll
+        for (int r = 0; r < T::PER; ++r) s[T::at(T::mn_of(t, r), T::k_of(t, r))] = reg[r];
+    }
+};
+
+struct GettKernelArgs {
+    GettProblem p;
+    int ksplit;   // grid.y
+    int kchunk;   // K range per split, multiple of BK
+    double* ws;   // partial sums [z][split][M][N] when ksplit > 1
+    int mtiles, ntiles;
+};
+
+// XCD-aware bijective remap (cdna_hip_programming.md T1): blocks b, b+8, b+16... share an XCD (and its L2);
+// give them consecutive tile ids so that neighbouring tiles -- which share an A or B panel -- hit the same L2.
+__device__ __forceinline__ int xcd_remap(int b, int nwg)
+{
+    int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+template <int TM, int TN, bool AKC, bool BKC>
+__global__ __launch_bounds__(NT) void gett_kernel(GettKernelArgs a)
+{
+    constexpr int BM = 32 * TM, BN = 32 * TN;
+    using TA = TileImg<BM, AKC>;
+    using TB = TileImg<BN, BKC>;
+    __shared__ double lds[2 * (TA::SIZE + TB::SIZE)];
+    constexpr int STAGE = TA::SIZE + TB::SIZE;   // buffer b: A image at lds + b*STAGE, B image right behind it
+
+    const GettProblem& p = a.p;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile % a.mtiles) * BM, n0 = (tile / a.mtiles) * BN;
+    const int z = blockIdx.z, split = blockIdx.y;
+    const int kbeg = split * a.kchunk;
+    const int kend = min(p.K, kbeg + a.kchunk);
+
+    const double* Ab = p.A + (p.batchA ? p.batchA[z] : 0);
+    const double* Bb = p.B + (p.batchB ? p.batchB[z] : 0);
+
+    Stager<BM, AKC> stA;
+    Stager<BN, BKC> stB;
+    stA.init(Ab, p.offAm, p.offAk, m0, p.M, p.K, t);
+    stB.init(Bb, p.offBn, p.offBk, n0, p.N, p.K, t);
+
+    v4d acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    double ra[TA::PER], rb[TB::PER];
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        stA.fetch(ra, kbeg, kend, t);
+        stB.fetch(rb, kbeg, kend, t);
+        stA.stash(lds, ra, t);
+        stB.stash(lds + TA::SIZE, rb, t);
+    }
+    __syncthreads();
+
+    const int fa = wm * 16 * TM + (lane & 15), fb = wn * 16 * TN + (lane & 15), fk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            stA.fetch(ra, kbeg + (kt + 1) * BK, kend, t);
+            stB.fetch(rb, kbeg + (kt + 1) * BK, kend, t);
+        }
+        const double* cA = lds + cur * STAGE;
+        const double* cB = cA + TA::SIZE;
+#pragma unroll
+        for (int s = 0; s < BK / 4; ++s) {
+            double af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = cA[TA::at(fa + 16 * i, 4 * s + fk)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = cB[TB::at(fb + 16 * j, 4 * s + fk)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            stA.stash(lds + (cur ^ 1) * STAGE, ra, t);
+            stB.stash(lds + (cur ^ 1) * STAGE + TA::SIZE, rb, t);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane l, register r of accumulator (i,j) is C[m0 + wm*16*TM + 16i + (l>>4) + 4r][n0 + ... + (l&15)]
+    const int nl = n0 + wn * 16 * TN + (lane & 15);
+    const int ml = m0 + wm * 16 * TM + (lane >> 4);
+    if (a.ksplit == 1) {
+        double* Cb = p.C + (p.batchC ? p.batchC[z] : 0);
+        int64_t cn[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int n = nl + 16 * j;
+            cn[j] = p.offCn[n < p.N ? n : p.N - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int m = ml + 16 * i + 4 * r;
+                if (m >= p.M) continue;
+                int64_t cm = p.offCm[m];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    int n = nl + 16 * j;
+                    if (n >= p.N) continue;
+                    double* dst = Cb + cm + cn[j];
+                    double val = p.alpha * acc[i][j][r];
+                    if (p.beta != 0.0) val += p.beta * *dst;
+                    *dst = val;
+                }
+            }
+    } else {
+        double* W = a.ws + ((int64_t)z * a.ksplit + split) * (int64_t)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int m = ml + 16 * i + 4 * r;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    int n = nl + 16 * j;
+                    if (n < p.N) W[(int64_t)m * p.N + n] = acc[i][j][r];
+                }
+            }
+    }
+}
+
+// Deterministic split-K combine: fixed summation order over the split index.
+__global__ __launch_bounds__(256) void gett_reduce_kernel(GettKernelArgs a)
+{
+    const GettProblem& p = a.p;
+    const int64_t mn = (int64_t)p.M * p.N;
+    const int z = blockIdx.y;
+    double* Cb = p.C + (p.batchC ? p.batchC[z] : 0);
+    const double* W = a.ws + (int64_t)z * a.ksplit * mn;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < mn; x += (int64_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int k = 0; k < a.ksplit; ++k) s += W[(int64_t)k * mn + x];
+        int m = (int)(x / p.N), n = (int)(x % p.N);
+        double* dst = Cb + p.offCm[m] + p.offCn[n];
+        double val = p.alpha * s;
+        if (p.beta != 0.0) val += p.beta * *dst;
+        *dst = val;
+    }
+}
+
+template <int TM, int TN>
+static void launch_tile(const GettKernelArgs& a, dim3 grid, hipStream_t st)
+{
+    const bool ak = a.p.a_kcontig, bk = a.p.b_kcontig;
+    if (ak && bk) hipLaunchKernelGGL((gett_kernel<TM, TN, true, true>), grid, dim3(NT), 0, st, a);
+    else if (ak) hipLaunchKernelGGL((gett_kernel<TM, TN, true, false>), grid, dim3(NT), 0, st, a);
+    else if (bk) hipLaunchKernelGGL((gett_kernel<TM, TN, false, true>), grid, dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((gett_kernel<TM, TN, false, false>), grid, dim3(NT), 0, st, a);
+}
+
+static int pick_t(int extent)
+{
+    if (extent <= 32) return 1;
+    if (extent <= 64) return 2;
+    return 4;
+}
+
+hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_t stream, int force_split, int force_tm,
+                       int force_tn)
+{
+    if (p.M <= 0 || p.N <= 0 || p.nbatch <= 0) return hipSuccess;
+    GettKernelArgs a;
+    a.p = p;
+    const int tm = force_tm ? force_tm : pick_t(p.M), tn = force_tn ? force_tn : pick_t(p.N);
+    const int BM = 32 * tm, BN = 32 * tn;
+    a.mtiles = (p.M + BM - 1) / BM;
+    a.ntiles = (p.N + BN - 1) / BN;
+    const int64_t tiles = (int64_t)a.mtiles * a.ntiles * p.nbatch;
+    const int ksteps = (p.K + BK - 1) / BK;
+    int split = 1;
+    if (force_split > 0) {
+        split = force_split;
+    } else if (tiles < 192 && ksteps >= 8) {
+        // too few tiles to fill 256 CUs: slice K, at least 4 K steps per slice, aim for ~2 blocks per CU
+        split = (int)((512 + tiles - 1) / tiles);
+        if (split > ksteps / 4) split = ksteps / 4;
+    }
+    if (split > ksteps) split = ksteps > 0 ? ksteps : 1;
+    const int64_t need = (int64_t)split * p.nbatch * p.M * p.N * (int64_t)sizeof(double);
+    if (split > 1 && (ws.ptr == nullptr || (size_t)need > ws.bytes)) {
+        split = (ws.ptr == nullptr) ? 1 : (int)(ws.bytes / ((size_t)p.nbatch * p.M * p.N * sizeof(double)));
+        if (split < 1) split = 1;
+    }
+    int steps_per = (ksteps + split - 1) / split;
+    if (steps_per < 1) steps_per = 1;
+    a.kchunk = steps_per * BK;
+    a.ksplit = (ksteps + steps_per - 1) / steps_per;
+    if (a.ksplit < 1) a.ksplit = 1;
+    a.ws = ws.ptr;
+    dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)a.ksplit, (unsigned)p.nbatch);
+#define AFESP_TILE(TM_, TN_) \
+    if (tm == TM_ && tn == TN_) launch_tile<TM_, TN_>(a, grid, stream);
+    AFESP_TILE(1, 1) AFESP_TILE(1, 2) AFESP_TILE(1, 4)
+    AFESP_TILE(2, 1) AFESP_TILE(2, 2) AFESP_TILE(2, 4)
+    AFESP_TILE(4, 1) AFESP_TILE(4, 2) AFESP_TILE(4, 4)
+#undef AFESP_TILE
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    if (a.ksplit > 1) {
+        int64_t mn = (int64_t)p.M * p.N;
+        unsigned gx = (unsigned)((mn + 255) / 256 > 2048 ? 2048 : (mn + 255) / 256);
+        hipLaunchKernelGGL(gett_reduce_kernel, dim3(gx, (unsigned)p.nbatch), dim3(256), 0, stream, a);
+        err = hipGetLastError();
+    }
+    return err;
+}
+
+}  // namespace afesp

@@ -1,0 +1,311 @@
+// kernels.hip -- HBM-bound elementwise / reduction / index kernels of the coupled-cluster path.
+// All tensors are Fortran column-major (first index fastest); lanes run along the fastest index.
+#include <algorithm>
+
+#include "afesp_internal.h"
+
+namespace afesp {
+
+namespace {
+constexpr int TB = 256;
+inline unsigned grid_for(int64_t n, int cap = 4096) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + TB - 1) / TB, cap)); }
+#define GRID_STRIDE(IDX_, n) for (int64_t IDX_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; IDX_ < (n); IDX_ += (int64_t)gridDim.x * blockDim.x)
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+// block-wide sum of up to NV values; result valid in thread 0
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* sm /* [NV*4] */)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        v[q] = wave_sum(v[q]);
+        if (lane == 0) sm[q * 4 + w] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = sm[q * 4] + sm[q * 4 + 1] + sm[q * 4 + 2] + sm[q * 4 + 3];
+    }
+}
+
+__global__ void fill_kernel(double* x, int64_t n, double val) { GRID_STRIDE(i, n) x[i] = val; }
+__global__ void axpby_kernel(double* y, double a, const double* x, double b, int64_t n)
+{
+    GRID_STRIDE(i, n) y[i] = a * x[i] + (b != 0.0 ? b * y[i] : 0.0);
+}
+__global__ void div_kernel(double* out, const double* num, const double* den, int64_t n) { GRID_STRIDE(i, n) out[i] = num[i] / den[i]; }
+__global__ void sub_kernel(double* out, const double* a, const double* b, int64_t n) { GRID_STRIDE(i, n) out[i] = a[i] - b[i]; }
+
+// out = 2 x - x(with index pair swapped).  which=0: pair (0,1); which=1: pair (2,3).   (linalg.fpp:158-274, immutable form)
+__global__ void antisym_pair_kernel(double* out, const double* in, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int which)
+{
+    const int64_t n = d0 * d1 * d2 * d3;
+    GRID_STRIDE(x, n)
+    {
+        int64_t i0 = x % d0, r = x / d0, i1 = r % d1;
+        r /= d1;
+        int64_t i2 = r % d2, i3 = r / d2;
+        int64_t y = which == 0 ? i1 + d0 * (i0 + d1 * (i2 + d2 * i3)) : i0 + d0 * (i1 + d1 * (i3 + d2 * i2));
+        out[x] = 2.0 * in[x] - in[y];
+    }
+}
+
+// asym_t2 = 2 t2 - t2(jiab) (ccsd.f90:1063-1064);  c = t2 + t1 t1 (ccsd.f90:1071-1079)
+__global__ void asym_c_kernel(double* asym, double* c, const double* t1, const double* t2, int o, int v)
+{
+    const int64_t n = (int64_t)o * o * v * v;
+    GRID_STRIDE(x, n)
+    {
+        int i = (int)(x % o);
+        int64_t r = x / o;
+        int j = (int)(r % o);
+        r /= o;
+        int a = (int)(r % v), b = (int)(r / v);
+        double t = t2[x];
+        asym[x] = 2.0 * t - t2[j + (int64_t)o * (i + (int64_t)o * (a + (int64_t)v * b))];
+        c[x] = t + t1[i + o * a] * t1[j + o * b];
+    }
+}
+
+// t2 = (r2(ijab) + r2(jiba) + v_oovv) / D2   (ccsd.f90:1720-1728)
+__global__ void t2_update_kernel(double* t2, const double* r2, const double* voovv, const double* D2, int o, int v)
+{
+    const int64_t n = (int64_t)o * o * v * v;
+    GRID_STRIDE(x, n)
+    {
+        int i = (int)(x % o);
+        int64_t r = x / o;
+        int j = (int)(r % o);
+        r /= o;
+        int a = (int)(r % v), b = (int)(r / v);
+        int64_t y = j + (int64_t)o * (i + (int64_t)o * (b + (int64_t)v * a));
+        t2[x] = (r2[x] + r2[y] + voovv[x]) / D2[x];
+    }
+}
+
+// ccsd.f90:436-445
+__global__ void denominators_kernel(double* D1, double* D2, const double* e, int o, int v)
+{
+    const int64_t n = (int64_t)o * o * v * v;
+    GRID_STRIDE(x, n)
+    {
+        int i = (int)(x % o);
+        int64_t r = x / o;
+        int j = (int)(r % o);
+        r /= o;
+        int a = (int)(r % v), b = (int)(r / v);
+        D2[x] = e[i] + e[j] - e[a + o] - e[b + o];
+        if (j == 0 && b == 0) D1[i + o * a] = e[i] - e[a + o];
+    }
+}
+
+// ccsd.f90:1764-1782: two sums, then t2_old = t2 (:1804).  Deterministic: fixed grid, per-block partials, ordered final sum.
+constexpr int RED_BLOCKS = 512;
+__global__ __launch_bounds__(TB) void cc_energy_kernel(double* partial, const double* voovv, const double* t1, const double* t2,
+                                                       double* t2_old, int o, int v)
+{
+    __shared__ double sm[8];
+    const int64_t n = (int64_t)o * o * v * v;
+    double acc[2] = {0.0, 0.0};
+    GRID_STRIDE(x, n)
+    {
+        int i = (int)(x % o);
+        int64_t r = x / o;
+        int j = (int)(r % o);
+        r /= o;
+        int a = (int)(r % v), b = (int)(r / v);
+        double t = t2[x];
+        double vx = voovv[i + (int64_t)o * (j + (int64_t)o * (b + (int64_t)v * a))];
+        acc[0] += (2.0 * voovv[x] - vx) * (t + t1[i + o * a] * t1[j + o * b]);
+        double d = t - t2_old[x];
+        acc[1] += d * d;
+        t2_old[x] = t;
+    }
+    block_sum<2>(acc, sm);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = acc[0];
+        partial[RED_BLOCKS + blockIdx.x] = acc[1];
+    }
+}
+// mp2.f90:418-440 on the <ij|ab> slice
+__global__ __launch_bounds__(TB) void mp2_energy_kernel(double* partial, const double* voovv, const double* D2, int o, int v)
+{
+    __shared__ double sm[4];
+    const int64_t n = (int64_t)o * o * v * v;
+    double acc[1] = {0.0};
+    GRID_STRIDE(x, n)
+    {
+        int i = (int)(x % o);
+        int64_t r = x / o;
+        int j = (int)(r % o);
+        r /= o;
+        int a = (int)(r % v), b = (int)(r / v);
+        double vx = voovv[i + (int64_t)o * (j + (int64_t)o * (b + (int64_t)v * a))];
+        acc[0] += voovv[x] * (2.0 * voovv[x] - vx) / D2[x];
+    }
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+}
+// out[q] (+)= sum_b partial[q*nblk + b], fixed order
+__global__ void final_sum_kernel(double* out, const double* partial, int nblk, int nq, int accumulate)
+{
+    __shared__ double sm[4];
+    for (int q = 0; q < nq; ++q) {
+        double acc[1] = {0.0};
+        for (int b = threadIdx.x; b < nblk; b += blockDim.x) acc[0] += partial[q * nblk + b];
+        block_sum<1>(acc, sm);
+        if (threadIdx.x == 0) out[q] = (accumulate ? out[q] : 0.0) + acc[0];
+        __syncthreads();
+    }
+}
+
+// partial[j*RED_BLOCKS + blk] = block's share of <x, y_j>
+__global__ __launch_bounds__(TB) void dots_kernel(double* partial, const double* x, const double* ybase, int64_t ystride, int64_t n)
+{
+    __shared__ double sm[4];
+    const double* y = ybase + (int64_t)blockIdx.y * ystride;
+    double acc[1] = {0.0};
+    GRID_STRIDE(i, n) acc[0] += x[i] * y[i];
+    block_sum<1>(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.y * RED_BLOCKS + blockIdx.x] = acc[0];
+}
+__global__ void lincomb_kernel(double* out, const double* xbase, int64_t xstride, const double* coef, int nx, int64_t n)
+{
+    GRID_STRIDE(i, n)
+    {
+        double s = 0.0;
+        for (int j = 0; j < nx; ++j) s += coef[j] * xbase[j * xstride + i];
+        out[i] = s;
+    }
+}
+
+__device__ __forceinline__ int64_t tri(int64_t i, int64_t j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// integrals.f90:196-210 applied per element: full(i,j,k,l) = packed[tri(tri(i,j),tri(k,l))]
+__global__ void unpack_eri_kernel(double* full, const double* packed, int n)
+{
+    const int64_t n4 = (int64_t)n * n * n * n;
+    GRID_STRIDE(x, n4)
+    {
+        int i = (int)(x % n);
+        int64_t r = x / n;
+        int j = (int)(r % n);
+        r /= n;
+        int k = (int)(r % n), l = (int)(r / n);
+        full[x] = packed[tri(tri(i, j), tri(k, l))];
+    }
+}
+// mp2.f90:388-410: packed[tri(pq, rs)] = full(s,r,q,p); one thread per (pq >= rs) pair
+__global__ void pack_eri_kernel(double* packed, const double* full, int n)
+{
+    const int64_t np = (int64_t)n * (n + 1) / 2;
+    const int64_t tot = np * np;
+    GRID_STRIDE(x, tot)
+    {
+        int64_t rs = x % np, pq = x / np;
+        if (rs > pq) continue;
+        // invert the triangular index
+        int64_t p = (int64_t)((sqrt(8.0 * (double)pq + 1.0) - 1.0) * 0.5);
+        while (p * (p + 1) / 2 > pq) --p;
+        while ((p + 1) * (p + 2) / 2 <= pq) ++p;
+        int64_t q = pq - p * (p + 1) / 2;
+        int64_t r = (int64_t)((sqrt(8.0 * (double)rs + 1.0) - 1.0) * 0.5);
+        while (r * (r + 1) / 2 > rs) --r;
+        while ((r + 1) * (r + 2) / 2 <= rs) ++r;
+        int64_t s = rs - r * (r + 1) / 2;
+        packed[pq * (pq + 1) / 2 + rs] = full[s + (int64_t)n * (r + (int64_t)n * (q + (int64_t)n * p))];
+    }
+}
+// ccsd.f90:496-512: out(p,q,r,s) = <p+b0 q+b1 | r+b2 s+b3> = (pr|qs) read from the packed chemist array
+__global__ void slice_phys_kernel(double* out, const double* packed, int d0, int d1, int d2, int d3, int b0, int b1, int b2, int b3)
+{
+    const int64_t n = (int64_t)d0 * d1 * d2 * d3;
+    GRID_STRIDE(x, n)
+    {
+        int p = (int)(x % d0);
+        int64_t r_ = x / d0;
+        int q = (int)(r_ % d1);
+        r_ /= d1;
+        int r = (int)(r_ % d2), s = (int)(r_ / d2);
+        out[x] = packed[tri(tri(p + b0, r + b2), tri(q + b1, s + b3))];
+    }
+}
+}  // namespace
+
+#define LAUNCH(kernel, grid, ...)                                               \
+    do {                                                                        \
+        hipLaunchKernelGGL(kernel, grid, dim3(TB), 0, cx.stream, __VA_ARGS__);  \
+        AFESP_HIP(hipGetLastError());                                           \
+    } while (0)
+
+void k_fill(Context& cx, double* x, int64_t n, double val) { if (n > 0) LAUNCH(fill_kernel, dim3(grid_for(n)), x, n, val); }
+void k_copy(Context& cx, double* dst, const double* src, int64_t n)
+{
+    if (n > 0) AFESP_HIP(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, cx.stream));
+}
+void k_axpby(Context& cx, double* y, double a, const double* x, double b, int64_t n) { if (n > 0) LAUNCH(axpby_kernel, dim3(grid_for(n)), y, a, x, b, n); }
+void k_div(Context& cx, double* out, const double* num, const double* den, int64_t n) { if (n > 0) LAUNCH(div_kernel, dim3(grid_for(n)), out, num, den, n); }
+void k_sub(Context& cx, double* out, const double* a, const double* b, int64_t n) { if (n > 0) LAUNCH(sub_kernel, dim3(grid_for(n)), out, a, b, n); }
+void k_antisym_pair(Context& cx, double* out, const double* in, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int which)
+{
+    int64_t n = d0 * d1 * d2 * d3;
+    if (n > 0) LAUNCH(antisym_pair_kernel, dim3(grid_for(n)), out, in, d0, d1, d2, d3, which);
+}
+void k_asym_c(Context& cx, double* asym, double* c, const double* t1, const double* t2, int o, int v)
+{
+    LAUNCH(asym_c_kernel, dim3(grid_for((int64_t)o * o * v * v)), asym, c, t1, t2, o, v);
+}
+void k_t2_update(Context& cx, double* t2, const double* r2, const double* v_oovv, const double* D2, int o, int v)
+{
+    LAUNCH(t2_update_kernel, dim3(grid_for((int64_t)o * o * v * v)), t2, r2, v_oovv, D2, o, v);
+}
+void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v)
+{
+    LAUNCH(denominators_kernel, dim3(grid_for((int64_t)o * o * v * v)), D1, D2, e, o, v);
+}
+// partial sums live at cx.scal + 64 (2*RED_BLOCKS doubles reserved by the context)
+static double* partials(Context& cx) { return cx.scal + 64; }
+
+void k_cc_energy(Context& cx, double* out2, const double* v_oovv, const double* t1, const double* t2, double* t2_old, int o, int v)
+{
+    LAUNCH(cc_energy_kernel, dim3(RED_BLOCKS), partials(cx), v_oovv, t1, t2, t2_old, o, v);
+    LAUNCH(final_sum_kernel, dim3(1), out2, partials(cx), RED_BLOCKS, 2, 0);
+}
+void k_mp2_energy(Context& cx, double* out1, const double* v_oovv, const double* D2, int o, int v)
+{
+    LAUNCH(mp2_energy_kernel, dim3(RED_BLOCKS), partials(cx), v_oovv, D2, o, v);
+    LAUNCH(final_sum_kernel, dim3(1), out1, partials(cx), RED_BLOCKS, 1, 0);
+}
+void k_dots(Context& cx, double* out, const double* x, const double* ybase, int64_t ystride, int ny, int64_t n, bool accumulate)
+{
+    if (ny <= 0) return;
+    if (ny > 16) throw Error(3, "k_dots: too many vectors");
+    LAUNCH(dots_kernel, dim3(RED_BLOCKS, ny), partials(cx), x, ybase, ystride, n);
+    LAUNCH(final_sum_kernel, dim3(1), out, partials(cx), RED_BLOCKS, ny, accumulate ? 1 : 0);
+}
+void k_lincomb(Context& cx, double* out, const double* xbase, int64_t xstride, const double* coef_dev, int nx, int64_t n)
+{
+    if (n > 0) LAUNCH(lincomb_kernel, dim3(grid_for(n)), out, xbase, xstride, coef_dev, nx, n);
+}
+void k_unpack_eri(Context& cx, double* full, const double* packed, int n)
+{
+    LAUNCH(unpack_eri_kernel, dim3(grid_for((int64_t)n * n * n * n, 65536)), full, packed, n);
+}
+void k_pack_eri(Context& cx, double* packed, const double* full, int n)
+{
+    int64_t np = (int64_t)n * (n + 1) / 2;
+    LAUNCH(pack_eri_kernel, dim3(grid_for(np * np, 65536)), packed, full, n);
+}
+void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1, int d2, int d3, int b0, int b1, int b2, int b3)
+{
+    int64_t n = (int64_t)d0 * d1 * d2 * d3;
+    if (n > 0) LAUNCH(slice_phys_kernel, dim3(grid_for(n, 65536)), out, packed, d0, d1, d2, d3, b0, b1, b2, b3);
+}
+
+}  // namespace afesp

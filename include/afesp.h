@@ -1,0 +1,103 @@
+/*
+ * afesp.h -- C-ABI of libafesp_hip.so: the MI355X (gfx950) coupled-cluster engine behind the AFESP hot path.
+ *
+ * The reference (brianz98/A-Fortran-Electronic-Structure-Program) has no FFI: the path is entered by three
+ * use-associated calls in src/main.F90:98,105,112.  This header is the boundary a Fortran host binds with
+ * ISO_C_BINDING (interface block + binding in INTEGRATION.md): flat column-major fp64 arrays plus extents, exactly
+ * what the reference already did for its own accelerator variant (do_ccsd_t_spinorb_acc, src/ccsd.f90:1924-1938).
+ *
+ * Conventions
+ *   - every array is Fortran column-major, fp64, index order as declared in the reference
+ *     (t1(o,v), t2(o,o,v,v): first index fastest; virtual indices 1..v with the o offset removed, src/ccsd.f90:429,438)
+ *   - packed ERI arrays use the reference's 8-fold order (src/integrals.f90:187-210): ij = i(i-1)/2+j (i>=j, 1-based),
+ *     ijkl = ij(ij-1)/2+kl (ij>=kl); length npair(npair+1)/2, npair = n(n+1)/2
+ *   - canon_coeff is (MO, AO): row = MO, column = AO (src/hf.f90:102,127)
+ *   - host pointers are borrowed for the duration of the call; device memory is owned by the context
+ *   - every function returns 0 on success; non-zero -> afesp_last_error(ctx) (the Fortran host maps it to error(),
+ *     src/error_handling.f90:7-20).  Without a usable GPU afesp_ctx_create fails: there is no CPU fallback.
+ *   - extents are int64_t / int (the reference's int32 packed-index limit n<=99, src/integrals.f90:21, is lifted)
+ */
+#ifndef AFESP_H
+#define AFESP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct afesp_ctx afesp_ctx;
+
+/* Context = one GPU (HIP device `device`), one stream, resident tensors.  One context per process per GPU. */
+int afesp_ctx_create(int device, afesp_ctx** out);
+void afesp_ctx_destroy(afesp_ctx* ctx);
+const char* afesp_last_error(const afesp_ctx* ctx);
+int afesp_version(void);
+int64_t afesp_neri(int64_t nbasis); /* packed length, src/integrals.f90:175-176 */
+
+/* Replaces `call do_mp2_spatial(sys, int_store)` (src/main.F90:98, src/mp2.f90:261-449).
+ *   in : nbasis n, nocc o, canon_coeff[n*n] (MO,AO), canon_levels[n], eri_packed[neri] (AO basis)
+ *   out: eri_mo_packed[neri] (may be NULL: the MO integrals then stay on the device only), *e_mp2
+ * The transformed integrals stay resident in the context for afesp_ccsd_init(..., eri_mo_packed = NULL). */
+int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* canon_coeff, const double* canon_levels,
+                    const double* eri_packed, double* eri_mo_packed, double* e_mp2);
+
+/* Replaces init_cc + init_diis_cc_t (src/ccsd.f90:313-316, :404-615).
+ *   eri_mo_packed: packed MO integrals from the host, or NULL to use the ones afesp_ao2mo_mp2 left on the device.
+ *   diis_n_errmat: sys%ccsd_diis_n_errmat (<2 switches DIIS off, src/ccsd.f90:593-595). */
+int afesp_ccsd_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, const double* eri_mo_packed, const double* canon_levels,
+                    int diis_n_errmat);
+
+/* One pass of the loop body src/ccsd.f90:340-360: save t for DIIS, update_restricted_intermediates,
+ * update_amplitudes_restricted, update_cc_energy.  *rms_sq is the UN-rooted sum of (dT2)^2 the reference stores and
+ * prints (src/ccsd.f90:1806); *converged follows src/ccsd.f90:1805. */
+int afesp_ccsd_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* energy, double* rms_sq, int* converged);
+/* update_cc_energy alone on the current amplitudes (the "MP1" line, src/ccsd.f90:325). */
+int afesp_ccsd_energy(afesp_ctx* ctx, double e_tol, double t_tol, double* energy, double* rms_sq, int* converged);
+/* update_diis_cc (src/ccsd.f90:395, :617-676). */
+int afesp_ccsd_diis(afesp_ctx* ctx);
+/* The whole solver loop src/ccsd.f90:325-396.  iter_energy / iter_rms_sq (length maxiter+1, may be NULL) receive the
+ * iteration table incl. entry 0 = "MP1".  *niter = iterations taken, or -1 if not converged within maxiter. */
+int afesp_ccsd_solve(afesp_ctx* ctx, int maxiter, double e_tol, double t_tol, double* iter_energy, double* iter_rms_sq,
+                     int* niter);
+/* Converged amplitudes (what move_alloc hands to int_store_cc, src/ccsd.f90:386-387). */
+int afesp_ccsd_get_amplitudes(afesp_ctx* ctx, double* t1, double* t2);
+int afesp_ccsd_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2);
+/* Named device tensor -> host (tests / debugging).  Names: v_oovv v_ovov v_vvov v_oovo v_oooo v_vvvv I_vo I_vv I_oo_p
+ * I_oo c_oovv asym_t2 x_voov I_oooo I_ovov I_voov I_vovv_p I_ooov_p r1 r2 D1 D2 t1 t2 */
+int afesp_ccsd_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t capacity);
+/* intermediates / amplitude equations separately (src/ccsd.f90:350,357), for term-by-term parity tests */
+int afesp_ccsd_update_intermediates(afesp_ctx* ctx);
+int afesp_ccsd_update_amplitudes(afesp_ctx* ctx);
+
+/* Replaces `call do_ccsd_t_spatial(...)` (src/main.F90:112, src/ccsd.f90:2018-2293) on the amplitudes resident in ctx.
+ * The (i<=j<=k) triples are numbered 0..afesp_ccsd_t_ntriples-1; [t_begin, t_end) selects this rank's shard (the sums
+ * of all shards are what one RCCL all-reduce combines; the D base term 1+2|t1|^2+asym.c, src/ccsd.f90:2243, is added by
+ * the shard that holds triple 0).
+ *   out[0] = E[T]  (src/ccsd.f90:2218-2219)     out[1] = E(T) incl. the z term (:2220 as in R/CR mode = the correct (T))
+ *   out[2] = D[T]  (:2230-2231, :2243)          out[3] = D(T) (:2232) */
+int64_t afesp_ccsd_t_ntriples(int64_t nocc);
+int afesp_ccsd_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[4]);
+
+/* Operator layer (src/linalg.fpp), exported for parity tests against the oracle.
+ * afesp_gemm    = dgemm_wrapper (src/linalg.fpp:58-89): C(m x n) = alpha op(A) op(B) + beta C, host arrays.
+ * afesp_permute4 = omp_reshape (src/linalg.fpp:99-156): out(perm) = beta*out + in; has_beta=0 zeroes `out` first. */
+int afesp_gemm(afesp_ctx* ctx, char transA, char transB, int64_t m, int64_t n, int64_t k, double alpha, const double* A,
+               const double* B, double beta, double* C);
+int afesp_permute4(afesp_ctx* ctx, const int64_t dims[4], const char order[4], const double* in, double* out, int has_beta,
+                   double beta);
+/* General labelled contraction on host arrays (tests): C[lc] = alpha sum A[la] B[lb] + beta C[lc], dense col-major. */
+int afesp_contract(afesp_ctx* ctx, double alpha, const double* A, const char* la, const int64_t* dimsA, const double* B,
+                   const char* lb, const int64_t* dimsB, double beta, double* C, const char* lc, const int64_t* dimsC,
+                   int force_split, int force_tm, int force_tn);
+
+/* ---- device-resident entry points used by bench.py (inputs generated in HBM; nothing crosses PCIe in the timed region)
+ * Fill the context with the SURVEY.md 8(d) synthetic system: identity C, ladder orbital energies, hashed ERIs of
+ * magnitude `scale` carrying the 8-fold symmetry, written straight into the physicist slices. */
+int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double scale, uint64_t seed, int diis_n_errmat);
+/* Kernel-only timing helpers: average HIP-event milliseconds per launch over `reps` launches on the context stream. */
+int afesp_time_pp_ladder(afesp_ctx* ctx, int reps, double* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,120 @@
+"""GPU parity of AO->MO, CCSD and (T) against the oracle and the reference's bundled outputs, through the C-ABI."""
+import numpy as np
+import pytest
+
+import molecules
+import orc
+
+pytestmark = pytest.mark.gpu
+
+INTERMEDIATES = ["asym_t2", "c_oovv", "I_vo", "I_vv", "I_oo_p", "I_oo", "I_oooo", "I_ovov", "I_voov", "I_vovv_p", "x_voov",
+                 "I_ooov_p"]
+SLICES = ["v_oovv", "v_ovov", "v_vvov", "v_oovo", "v_oooo", "v_vvvv", "D1", "D2"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from afesp_amd.capi import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("name", ["h2o-cc-pvdz", "n2-cc-pvdz", "f2-cc-pvdz"])
+def test_molecule_full_path_matches_reference(eng, name):
+    si, ints, res, gold = molecules.load(name)
+    g = dict(molecules.SURVEY_GOLD[name])
+    n, o = ints.nbasis, ints.nel // 2
+    v = n - o
+    # --- AO->MO + MP2 (mp2.f90:261-449): packed MO integrals bit-for-bit comparable to the oracle within rounding
+    e_mp2, eri_mo = eng.do_mp2_spatial(n, o, res.canon_coeff, res.canon_levels, ints.eri)
+    ref_mo = orc.ao2mo(n, res.canon_coeff, ints.eri)
+    assert np.max(np.abs(eri_mo - ref_mo)) < 1e-11
+    assert abs(e_mp2 - g["mp2_corr"]) < 1e-9
+    # --- CCSD from the device-resident integrals
+    eng.ccsd_init(o, v, res.canon_levels, None, si.ccsd_diis_n_errmat)
+    cc = orc.OracleCC(o, v, ref_mo, res.canon_levels, si.ccsd_diis_n_errmat)
+    for s in SLICES:
+        assert np.max(np.abs(eng.tensor(s) - cc.field(s))) < 1e-11, s
+    nit, en, rm = eng.do_ccsd_spatial(si.ccsd_maxiter, si.ccsd_e_tol, si.ccsd_t_tol)
+    onit, oen, orm = cc.solve(si.ccsd_maxiter, si.ccsd_e_tol, si.ccsd_t_tol)
+    assert nit == onit
+    assert np.max(np.abs(en[:nit + 1] - oen[:nit + 1])) < 1e-10
+    assert abs(en[nit] - g["ccsd_corr"]) < 1e-8          # north_star tolerance: 1e-8 Eh
+    if gold:
+        # the reference's own iteration table (ccsd.f90:362-363), printed with 12 decimals
+        assert nit == gold["cc_iters"][-1][0]
+        for (git, ge, gde, grms) in gold["cc_iters"]:
+            assert abs(en[git] - ge) < 1e-10 and abs(rm[git] - grms) < 1e-10
+    t1, t2 = eng.amplitudes()
+    assert np.max(np.abs(t1 - cc.t1)) < 1e-9 and np.max(np.abs(t2 - cc.t2)) < 1e-9
+    # --- (T)
+    out = eng.do_ccsd_t_spatial()
+    ref = cc.triples(res.canon_levels)
+    assert np.max(np.abs(out - ref)) < 1e-10
+    ec = en[nit]
+    assert abs(ec + out[0] - g["ccsd_bt_corr"]) < 1e-8
+    assert abs(ec + out[1] - g["ccsd_pt_corr"]) < 1e-8
+    assert abs(ec + out[1] / out[3] - g["r_ccsd_pt_corr"]) < 1e-8
+    assert abs(out[2] - g["d_bt"]) < 1e-8 and abs(out[3] - g["d_pt"]) < 1e-8
+    # sharded evaluation (what the ranks of a multi-GPU run do) sums to the same numbers
+    nt = eng.ntriples()
+    parts = sum(eng.do_ccsd_t_spatial(b, min(b + 13, nt)) for b in range(0, nt, 13))
+    assert np.max(np.abs(parts - out)) < 1e-12
+
+
+def test_one_iteration_term_by_term(eng):
+    """Every intermediate and both residuals after one update from non-trivial amplitudes (t1 != 0)."""
+    o, v = 4, 9
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05)
+    cc = orc.OracleCC(o, v, eri, e, 8)
+    eng.ccsd_init(o, v, e, eri, 8)
+    rng = np.random.default_rng(5)
+    t1 = 0.05 * rng.standard_normal((o, v))
+    t2 = 0.05 * rng.standard_normal((o, o, v, v))
+    t2 = 0.5 * (t2 + t2.transpose(1, 0, 3, 2))
+    cc.t1[...] = t1
+    cc.t2[...] = t2
+    eng.set_amplitudes(t1, t2)
+    cc.L.orc_cc_intermediates(cc.h)
+    eng.update_intermediates()
+    for name in INTERMEDIATES:
+        assert np.max(np.abs(eng.tensor(name) - cc.field(name))) < 1e-12, name
+    cc.L.orc_cc_amplitudes(cc.h)
+    eng.update_amplitudes()
+    for name in ["r1", "r2"]:
+        assert np.max(np.abs(eng.tensor(name) - cc.field(name))) < 1e-12, name
+    g1, g2 = eng.amplitudes()
+    assert np.max(np.abs(g1 - cc.t1)) < 1e-12 and np.max(np.abs(g2 - cc.t2)) < 1e-12
+
+
+def test_h2o_tz_shape_synthetic(eng):
+    """BASELINE config 2 shape (o=5, v=53) on the SURVEY 8(d) synthetic integrals: CCSD path + (T) vs oracle."""
+    o, v = 5, 53
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.02)
+    cc = orc.OracleCC(o, v, eri, e, 8)
+    eng.ccsd_init(o, v, e, eri, 8)
+    nit, en, rm = eng.do_ccsd_spatial(60, 1e-6, 1e-7)
+    onit, oen, orm = cc.solve(60, 1e-6, 1e-7)
+    assert nit == onit and nit > 0
+    assert np.max(np.abs(en[:nit + 1] - oen[:nit + 1])) < 1e-10
+    out = eng.do_ccsd_t_spatial()
+    ref = cc.triples(e)
+    assert np.max(np.abs(out - ref)) < 1e-9
+
+
+def test_ccsd_without_diis_and_nonconvergence_is_silent(eng):
+    o, v = 3, 6
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05)
+    eng.ccsd_init(o, v, e, eri, 1)        # n_errmat < 2 switches DIIS off (ccsd.f90:593-595)
+    cc = orc.OracleCC(o, v, eri, e, 1)
+    nit, en, rm = eng.do_ccsd_spatial(3, 1e-14, 1e-14)
+    onit, oen, _ = cc.solve(3, 1e-14, 1e-14)
+    assert nit == -1 and onit == -1       # falls through the loop like ccsd.f90:396
+    assert np.max(np.abs(en - oen)) < 1e-12
+
+
+def test_errors_are_reported_not_swallowed(eng):
+    from afesp_amd.capi import AfespError
+    with pytest.raises(AfespError):
+        eng.ccsd_init(0, 5, np.zeros(5), np.zeros(int(orc.lib().orc_neri(5))), 8)

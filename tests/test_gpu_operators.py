@@ -1,0 +1,99 @@
+"""GPU parity of the operator layer (gather-GEMM, permute) against the oracle / numpy, through the C-ABI."""
+import itertools
+
+import numpy as np
+import pytest
+
+import orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from afesp_amd.capi import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+def _rand(rng, *shape):
+    return np.asfortranarray(rng.uniform(-1.0, 1.0, size=shape))
+
+
+def test_mfma_layout_identity_times_asymmetric(eng):
+    # A = I with an asymmetric B catches a transposed C/D register map (cdna_hip_programming.md section 3)
+    n = 48
+    B = np.asfortranarray(np.arange(n * n, dtype=float).reshape(n, n) * 0.001 + np.arange(n)[:, None] * 0.37)
+    C = eng.gemm("N", "N", n, n, n, np.eye(n), B)
+    assert np.array_equal(C, B)
+    C2 = eng.gemm("N", "N", n, n, n, B, np.eye(n))
+    assert np.array_equal(C2, B)
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 1, 1), (5, 7, 3), (16, 16, 4), (33, 65, 17), (128, 128, 64), (130, 257, 45),
+                                   (25, 361, 361), (400, 96, 512), (3, 1000, 9)])
+@pytest.mark.parametrize("ta,tb", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+def test_dgemm_wrapper_parity(eng, m, n, k, ta, tb):
+    rng = np.random.default_rng(m * 1000 + n * 10 + k)
+    A = _rand(rng, *((k, m) if ta == "T" else (m, k)))
+    B = _rand(rng, *((n, k) if tb == "T" else (k, n)))
+    C0 = _rand(rng, m, n)
+    ref = np.ascontiguousarray(C0.ravel(order="F")).copy()
+    orc.lib().orc_gemm(int(ta == "T"), int(tb == "T"), m, n, k, 0.75, np.ascontiguousarray(A.ravel(order="F")),
+                       np.ascontiguousarray(B.ravel(order="F")), -0.5, ref)
+    got = eng.gemm(ta, tb, m, n, k, A, B, C0, alpha=0.75, beta=-0.5)
+    # fp64, tolerance: K products of |x|<=1 accumulated in a different order -> a few ulp * K
+    assert np.max(np.abs(got.ravel(order="F") - ref)) < 1e-13 * max(k, 1) + 1e-14
+
+
+def test_gemm_k_zero_and_beta_zero_ignores_nan(eng):
+    C0 = np.full((4, 5), np.nan, order="F")
+    A = np.ones((4, 3), order="F")
+    B = np.ones((3, 5), order="F")
+    got = eng.gemm("N", "N", 4, 5, 3, A, B, C0, alpha=1.0, beta=0.0)
+    assert np.array_equal(got, np.full((4, 5), 3.0))
+
+
+@pytest.mark.parametrize("split,tm,tn", [(1, 1, 1), (3, 1, 4), (4, 4, 4), (2, 2, 2), (7, 4, 1), (0, 0, 0)])
+def test_contract_tile_shapes_and_split_k(eng, split, tm, tn):
+    rng = np.random.default_rng(7)
+    o, v = 5, 11
+    t2 = _rand(rng, o, o, v, v)
+    I = _rand(rng, o, v, o, v)
+    C0 = _rand(rng, o, o, v, v)
+    ref = C0 - 2.0 * np.einsum("mjae,iemb->ijab", t2, I)
+    got = eng.contract(-2.0, t2, "mjae", I, "iemb", 1.0, C0, "ijab", force_split=split, force_tm=tm, force_tn=tn)
+    assert np.max(np.abs(got - ref)) < 1e-12
+
+
+def test_contract_gemv_shapes(eng):
+    rng = np.random.default_rng(3)
+    o, v = 4, 9
+    w = _rand(rng, o, o, v, v)
+    t1 = _rand(rng, o, v)
+    got = eng.contract(1.0, w, "miea", t1, "me", 0.0, np.zeros((v, o), order="F"), "ai")
+    assert np.max(np.abs(got - np.einsum("miea,me->ai", w, t1))) < 1e-12
+    got = eng.contract(1.0, t1, "me", w, "miea", 0.0, np.zeros((v, o), order="F"), "ai")
+    assert np.max(np.abs(got - np.einsum("miea,me->ai", w, t1))) < 1e-12
+
+
+@pytest.mark.parametrize("order", ["".join(p) for p in itertools.permutations("1234")])
+def test_omp_reshape_all_24_orders(eng, order):
+    rng = np.random.default_rng(11)
+    x = _rand(rng, 3, 4, 5, 6)
+    dims = (orc.i64 * 4)(*x.shape)
+    oshape = tuple(x.shape[int(c) - 1] for c in order)
+    ref = np.zeros(x.size)
+    orc.lib().orc_permute4(dims, order.encode(), np.ascontiguousarray(x.ravel(order="F")), ref, 0, 0.0)
+    got = eng.omp_reshape(x, order)
+    assert np.array_equal(got.ravel(order="F"), ref)
+    # crib from SURVEY.md 8(a): '3124' means out(k,i,j,l) = in(i,j,k,l)
+    if order == "3124":
+        assert got[2, 1, 3, 4] == x[1, 3, 2, 4]
+    # beta form
+    y0 = _rand(rng, *oshape)
+    ref2 = np.ascontiguousarray(y0.ravel(order="F")).copy()
+    orc.lib().orc_permute4(dims, order.encode(), np.ascontiguousarray(x.ravel(order="F")), ref2, 1, 0.5)
+    got2 = eng.omp_reshape(x, order, out_arr=y0, beta=0.5)
+    assert np.array_equal(got2.ravel(order="F"), ref2)
