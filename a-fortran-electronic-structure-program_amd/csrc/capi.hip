@@ -388,6 +388,46 @@ int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double sca
     });
 }
 
+int afesp_set_tuning(int group_m, int force_tm, int force_tn, int force_split)
+{
+    g_group_m = group_m; g_force_tm = force_tm; g_force_tn = force_tn; g_force_split = force_split;
+    return 0;
+}
+
+// Device-only timing of one labelled contraction on hashed operands (tuning / roofline measurements).
+int afesp_bench_contract(afesp_ctx* ctx, const char* la, const int64_t* dimsA, const char* lb, const int64_t* dimsB,
+                         const char* lc, const int64_t* dimsC, int reps, double* ms_per_launch)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        auto mk = [&](const char* l, const int64_t* dims, uint64_t seed) {
+            Tensor t;
+            t.rank = (int)strlen(l);
+            int64_t s = 1;
+            for (int i = 0; i < t.rank; ++i) { t.dim[i] = dims[i]; t.stride[i] = s; s *= dims[i]; }
+            t.d = cx.alloc(s);
+            hipLaunchKernelGGL(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, t.d, s, 1.0, seed);
+            return t;
+        };
+        Tensor tA = mk(la, dimsA, 1), tB = mk(lb, dimsB, 2), tC = mk(lc, dimsC, 3);
+        hipEvent_t a, b;
+        AFESP_HIP(hipEventCreate(&a));
+        AFESP_HIP(hipEventCreate(&b));
+        contract(cx, 1.0, tA, la, tB, lb, 0.0, tC, lc);
+        AFESP_HIP(hipEventRecord(a, cx.stream));
+        for (int r = 0; r < reps; ++r) contract(cx, 1.0, tA, la, tB, lb, 0.0, tC, lc);
+        AFESP_HIP(hipEventRecord(b, cx.stream));
+        AFESP_HIP(hipEventSynchronize(b));
+        float ms = 0.f;
+        AFESP_HIP(hipEventElapsedTime(&ms, a, b));
+        if (ms_per_launch) *ms_per_launch = (double)ms / (reps > 0 ? reps : 1);
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+        cx.release(tA.d); cx.release(tB.d); cx.release(tC.d);
+    });
+}
+
 int afesp_time_pp_ladder(afesp_ctx* ctx, int reps, double* ms_per_launch)
 {
     return guarded(ctx, [&] {

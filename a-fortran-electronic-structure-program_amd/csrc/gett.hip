@@ -33,13 +33,18 @@ struct TileImg {
     __device__ static __forceinline__ int k_of(int t, int r) { return KC ? (t & 15) : t / BMN + (NT / BMN) * r; }
 };
 
-// Per-thread constant part of the gather addresses of one operand.
+// Per-thread gather state of one operand.  The K-offsets of step t+2, the data of step t+1 and the MFMAs of step t
+// are in flight together: offsets are fetched one step ahead of the data they address, so no load is waited for
+// before the MFMAs of the current step have been issued.
+// Rows/columns beyond M/N read a clamped (valid) address and produce garbage only in rows/columns of C that are never
+// stored; only the K tail has to be zeroed, which stash() does for the single partial step.
 template <int BMN, bool KC>
 struct Stager {
     using T = TileImg<BMN, KC>;
     static constexpr int NROW = KC ? T::PER : 1;
+    static constexpr int NKO = KC ? 1 : T::PER;
     int64_t rowoff[NROW];
-    bool rowok[NROW];
+    int64_t ko[NKO];
     const double* base;
     const int64_t* offK;
     int K;
@@ -53,32 +58,33 @@ struct Stager {
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
             int mn = mn0 + T::mn_of(t, r);
-            rowok[r] = mn < MN;
             rowoff[r] = offMN[mn < MN ? mn : MN - 1];
         }
     }
-    __device__ __forceinline__ void fetch(double (&reg)[T::PER], int k0, int kend, int t) const
+    // offsets of the K step starting at k0 (clamped: always a valid table entry)
+    __device__ __forceinline__ void fetch_ko(int k0, int t)
     {
-        if (KC) {
-            int k = k0 + T::k_of(t, 0);
-            bool kok = k < kend;
-            int64_t ko = offK[kok ? k : K - 1];
 #pragma unroll
-            for (int r = 0; r < T::PER; ++r) reg[r] = (kok && rowok[r]) ? base[rowoff[r] + ko] : 0.0;
-        } else {
-#pragma unroll
-            for (int r = 0; r < T::PER; ++r) {
-                int k = k0 + T::k_of(t, r);
-                bool kok = k < kend;
-                int64_t ko = offK[kok ? k : K - 1];
-                reg[r] = (kok && rowok[0]) ? base[rowoff[0] + ko] : 0.0;
-            }
+        for (int r = 0; r < NKO; ++r) {
+            int k = k0 + T::k_of(t, r);
+            ko[r] = offK[k < K ? k : K - 1];
         }
     }
-    __device__ __forceinline__ void stash(double* s, const double (&reg)[T::PER], int t) const
+    __device__ __forceinline__ void fetch(double (&reg)[T::PER]) const
     {
 #pragma unroll
-        for (int r = 0; r < T::PER; ++r) s[T::at(T::mn_of(t, r), T::k_of(t, r))] = reg[r];
+        for (int r = 0; r < T::PER; ++r) reg[r] = base[rowoff[KC ? r : 0] + ko[KC ? 0 : r]];
+    }
+    __device__ __forceinline__ void stash(double* s, const double (&reg)[T::PER], int t, int k0, int kend, bool tail) const
+    {
+        if (tail) {
+#pragma unroll
+            for (int r = 0; r < T::PER; ++r)
+                s[T::at(T::mn_of(t, r), T::k_of(t, r))] = (k0 + T::k_of(t, r) < kend) ? reg[r] : 0.0;
+        } else {
+#pragma unroll
+            for (int r = 0; r < T::PER; ++r) s[T::at(T::mn_of(t, r), T::k_of(t, r))] = reg[r];
+        }
     }
 };
 
@@ -88,6 +94,7 @@ struct GettKernelArgs {
     int kchunk;   // K range per split, multiple of BK
     double* ws;   // partial sums [z][split][M][N] when ksplit > 1
     int mtiles, ntiles;
+    int gm;       // m-tiles per group (tile walk order)
 };
 
 // XCD-aware bijective remap (cdna_hip_programming.md T1): blocks b, b+8, b+16... share an XCD (and its L2);
@@ -110,8 +117,12 @@ __global__ __launch_bounds__(NT) void gett_kernel(GettKernelArgs a)
     const GettProblem& p = a.p;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave & 1, wn = wave >> 1;
+    // Grouped order: a group is `gm` m-tiles x all n-tiles walked m-fastest, so that the ~32 workgroups co-resident on
+    // one XCD form a near-square patch of C and both operand panels are re-used out of that XCD's L2.
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile % a.mtiles) * BM, n0 = (tile / a.mtiles) * BN;
+    const int width = a.gm * a.ntiles, grp = tile / width, first = grp * a.gm;
+    const int gsz = min(a.mtiles - first, a.gm), rem = tile - grp * width;
+    const int m0 = (first + rem % gsz) * BM, n0 = (rem / gsz) * BN;
     const int z = blockIdx.z, split = blockIdx.y;
     const int kbeg = split * a.kchunk;
     const int kend = min(p.K, kbeg + a.kchunk);
@@ -130,45 +141,79 @@ __global__ __launch_bounds__(NT) void gett_kernel(GettKernelArgs a)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    double ra[TA::PER], rb[TB::PER];
+    // Register ring of depth 2: while the MFMAs of step kt run, the data of steps kt+1 (set P) and kt+2 (set Q) and the
+    // offsets of step kt+3 are in flight; set P is written to LDS after the MFMAs.  Two K steps (~8k cycles of MFMA at
+    // TM=TN=4) cover the loaded HBM latency with a single wave per SIMD.
+    double ra0[TA::PER], rb0[TB::PER], ra1[TA::PER], rb1[TB::PER];
     const int nk = (kend - kbeg + BK - 1) / BK;
+    const bool ragged = ((kend - kbeg) % BK) != 0;   // the last step is partial
     if (nk > 0) {
-        stA.fetch(ra, kbeg, kend, t);
-        stB.fetch(rb, kbeg, kend, t);
-        stA.stash(lds, ra, t);
-        stB.stash(lds + TA::SIZE, rb, t);
+        stA.fetch_ko(kbeg, t);
+        stB.fetch_ko(kbeg, t);
+        stA.fetch(ra0);
+        stB.fetch(rb0);
+        stA.fetch_ko(kbeg + BK, t);
+        stB.fetch_ko(kbeg + BK, t);
+        stA.stash(lds, ra0, t, kbeg, kend, ragged && nk == 1);
+        stB.stash(lds + TA::SIZE, rb0, t, kbeg, kend, ragged && nk == 1);
+        stA.fetch(ra1);                       // step 1 (clamped if it does not exist)
+        stB.fetch(rb1);
+        stA.fetch_ko(kbeg + 2 * BK, t);
+        stB.fetch_ko(kbeg + 2 * BK, t);
     }
     __syncthreads();
 
     const int fa = wm * 16 * TM + (lane & 15), fb = wn * 16 * TN + (lane & 15), fk = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            stA.fetch(ra, kbeg + (kt + 1) * BK, kend, t);
-            stB.fetch(rb, kbeg + (kt + 1) * BK, kend, t);
-        }
-        const double* cA = lds + cur * STAGE;
-        const double* cB = cA + TA::SIZE;
+    // MFMAs of K sub-step s (4 k values) of the LDS buffer at cA/cB
+    auto mfma_sub = [&](const double* cA, const double* cB, int s) {
+        double af[TM], bf[TN];
 #pragma unroll
-        for (int s = 0; s < BK / 4; ++s) {
-            double af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i) af[i] = cA[TA::at(fa + 16 * i, 4 * s + fk)];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = cA[TA::at(fa + 16 * i, 4 * s + fk)];
+        for (int j = 0; j < TN; ++j) bf[j] = cB[TB::at(fb + 16 * j, 4 * s + fk)];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = cB[TB::at(fb + 16 * j, 4 * s + fk)];
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            stA.stash(lds + (cur ^ 1) * STAGE, ra, t);
-            stB.stash(lds + (cur ^ 1) * STAGE + TA::SIZE, rb, t);
-        }
-        __syncthreads();
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+    // One K step.  LDS buffer `cur` is consumed; register set (pa,pb) holds step kt+1 and is written to the other LDS
+    // buffer; set (qa,qb) receives step kt+2.  The memory instructions are dealt out between the four MFMA groups (and
+    // pinned there with sched_barrier) so that with one wave per SIMD the matrix pipe is not left idle while a block of
+    // address arithmetic, global loads or LDS stores issues.
+#define AFESP_GETT_STEP(qa, qb, pa, pb)                                                         \
+    {                                                                                           \
+        const int cur = kt & 1;                                                                 \
+        const double* cA = lds + cur * STAGE;                                                   \
+        const double* cB = cA + TA::SIZE;                                                       \
+        const bool ld = kt + 2 < nk, st = kt + 1 < nk;                                          \
+        const bool tail = ragged && (kt + 2 == nk);                                             \
+        if (ld) stA.fetch(qa);                                                                  \
+        mfma_sub(cA, cB, 0);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (ld) stB.fetch(qb);                                                                  \
+        mfma_sub(cA, cB, 1);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (ld) {                                                                               \
+            stA.fetch_ko(kbeg + (kt + 3) * BK, t);                                              \
+            stB.fetch_ko(kbeg + (kt + 3) * BK, t);                                              \
+        }                                                                                       \
+        if (st) stA.stash(lds + (cur ^ 1) * STAGE, pa, t, kbeg + (kt + 1) * BK, kend, tail);    \
+        mfma_sub(cA, cB, 2);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (st) stB.stash(lds + (cur ^ 1) * STAGE + TA::SIZE, pb, t, kbeg + (kt + 1) * BK, kend, tail); \
+        mfma_sub(cA, cB, 3);                                                                    \
+        __syncthreads();                                                                        \
     }
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        AFESP_GETT_STEP(ra0, rb0, ra1, rb1)
+        ++kt;
+        AFESP_GETT_STEP(ra1, rb1, ra0, rb0)
+        --kt;
+    }
+    if (kt < nk) AFESP_GETT_STEP(ra0, rb0, ra1, rb1)
+#undef AFESP_GETT_STEP
 
     // epilogue: lane l, register r of accumulator (i,j) is C[m0 + wm*16*TM + 16i + (l>>4) + 4r][n0 + ... + (l&15)]
     const int nl = n0 + wn * 16 * TN + (lane & 15);
@@ -244,6 +289,9 @@ static void launch_tile(const GettKernelArgs& a, dim3 grid, hipStream_t st)
     else hipLaunchKernelGGL((gett_kernel<TM, TN, false, false>), grid, dim3(NT), 0, st, a);
 }
 
+int g_group_m = 0;   // >0 overrides the tile-walk group size (tuning knob, see afesp_set_tuning)
+int g_force_tm = 0, g_force_tn = 0, g_force_split = 0;
+
 static int pick_t(int extent)
 {
     if (extent <= 32) return 1;
@@ -257,6 +305,9 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     if (p.M <= 0 || p.N <= 0 || p.nbatch <= 0) return hipSuccess;
     GettKernelArgs a;
     a.p = p;
+    if (!force_tm) force_tm = g_force_tm;
+    if (!force_tn) force_tn = g_force_tn;
+    if (!force_split) force_split = g_force_split;
     const int tm = force_tm ? force_tm : pick_t(p.M), tn = force_tn ? force_tn : pick_t(p.N);
     const int BM = 32 * tm, BN = 32 * tn;
     a.mtiles = (p.M + BM - 1) / BM;
@@ -283,6 +334,8 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     a.ksplit = (ksteps + steps_per - 1) / steps_per;
     if (a.ksplit < 1) a.ksplit = 1;
     a.ws = ws.ptr;
+    a.gm = g_group_m > 0 ? g_group_m : (a.ntiles >= 8 ? 4 : a.ntiles >= 4 ? 8 : a.ntiles >= 2 ? 16 : 32);
+    if (a.gm > a.mtiles) a.gm = a.mtiles;
     dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)a.ksplit, (unsigned)p.nbatch);
 #define AFESP_TILE(TM_, TN_) \
     if (tm == TM_ && tn == TN_) launch_tile<TM_, TN_>(a, grid, stream);

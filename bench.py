@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- CCSD iteration + (T) on MI355X through the C-ABI (libafesp_hip.so).
+
+One "step" = one pass of the hot path over one system held in HBM:
+    one CCSD iteration (src/ccsd.f90:340-395: intermediates, amplitudes, energy, DIIS)  -- replicated on every rank
+  + the full (T) correction (src/ccsd.f90:2018-2293), its (i<=j<=k) triples sharded over the ranks,
+    followed by ONE all-reduce (RCCL) of the four scalars E[T], E(T), D[T], D(T).
+Inputs are generated on the device (afesp_synthetic_init); nothing crosses PCIe inside the timed region.
+
+Workloads (BASELINE.json configs):
+  h2o_tz  config 2 shape: H2O/cc-pVTZ extents o=5, v=53 (its eri.dat is not bundled -> synthetic integrals)
+  cfg5    config 5: synthetic o=20, v=200
+  n2      config 3 extents o=7, v=21 (synthetic integrals; the real N2 inputs are exercised by tests/)
+value = algorithmic fp64 FLOP of the step / step time, summed over the job (strong scaling: total work fixed).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "a-fortran-electronic-structure-program_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {"h2o_tz": (5, 53), "cfg5": (20, 200), "n2": (7, 21), "f2": (9, 19), "mid": (10, 100)}
+MFMA_F64_PEAK_TFLOPS = 78.6      # v_mfma_f64_16x16x4_f64: 32 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def flops_iter(o, v):
+    """sum over every contraction site of one CCSD iteration."""
+    return (2 * o**2 * v**4 + 14 * o**3 * v**3 + 2 * o**4 * v**2 + 2 * o**4 * v + 18 * o**2 * v**3 + 2 * o * v**3
+            + 14 * o**3 * v**2)
+
+
+def flops_t_sym(o, v):
+    """(T) with the i<=j<=k restriction (the algorithm timed here): SURVEY.md 8(d)."""
+    return (o * (o + 1) * (o + 2) // 6) * 12 * v**3 * (v + o)
+
+
+def flops_t_ref(o, v):
+    """(T) as the reference formulates it: all o^3 ordered triples."""
+    return o**3 * 12 * v**3 * (v + o)
+
+
+def hash_uniform(k, seed):
+    """numpy twin of the device generator in csrc/capi.hip (splitmix64)."""
+    x = (k.astype(np.uint64) + np.uint64(seed)) + np.uint64(0x9E3779B97F4A7C15)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    x ^= x >> np.uint64(31)
+    return (x >> np.uint64(11)).astype(np.float64) / 9007199254740992.0
+
+
+def synthetic_host(o, v, scale, seed):
+    n = o + v
+    npair = n * (n + 1) // 2
+    ne = npair * (npair + 1) // 2
+    with np.errstate(over="ignore"):
+        eri = scale * (2.0 * hash_uniform(np.arange(ne, dtype=np.uint64), seed) - 1.0)
+    e = np.concatenate([-2.0 + np.arange(o) / max(o - 1, 1), 1.0 + 2.0 * np.arange(v) / max(v - 1, 1)])
+    return e, eri
+
+
+def cpu_baseline(o, v, scale, seed, eng, budget_s=25.0):
+    """Time the CPU restatement (oracle/, kind "port") on a bounded sample of the same workload."""
+    import orc
+    L = orc.lib()
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    try:
+        omp = ctypes.CDLL("libgomp.so.1")
+        omp.omp_set_num_threads(threads)
+    except OSError:
+        pass
+    n = o + v
+    if n <= 64:
+        e, eri = synthetic_host(o, v, scale, seed)
+        cc = orc.OracleCC(o, v, eri, e, 8)
+        t0 = time.perf_counter()
+        L.orc_cc_diis_save(cc.h)
+        L.orc_cc_intermediates(cc.h)
+        L.orc_cc_amplitudes(cc.h)
+        L.orc_cc_energy(cc.h, 1e-6, 1e-7)
+        L.orc_cc_diis_update(cc.h)
+        t_iter = time.perf_counter() - t0
+        # (T): as many ordered triples as fit the budget, extrapolated to the reference's o^3
+        t0 = time.perf_counter()
+        cc.triples(e, 0, 1)
+        per = max(time.perf_counter() - t0, 1e-6)
+        ns = int(max(threads, min(o**3, budget_s / per * threads * 0.5)))
+        ns = min(ns, o**3)
+        t0 = time.perf_counter()
+        cc.triples(e, 0, ns)
+        t_t = (time.perf_counter() - t0) * (o**3 / ns)
+        sample = f"1 full CCSD iteration + {ns}/{o**3} ordered (i,j,k) triples of (T), scaled to o^3"
+        return {"value": t_iter + t_t, "unit": "s/step", "ccsd_iter_s": t_iter, "t_s": t_t, "cores": threads,
+                "kind": "port", "sample": sample,
+                "gflops": (flops_iter(o, v) + flops_t_ref(o, v)) / (t_iter + t_t) / 1e9}
+    # large system: the reference formulation cannot run here (n<=99); time slabs of the restatement
+    t1, t2 = eng.amplitudes()
+    f = lambda a: np.ascontiguousarray(a.ravel(order="F"))
+    e = np.concatenate([-2.0 + np.arange(o) / max(o - 1, 1), 1.0 + 2.0 * np.arange(v) / max(v - 1, 1)])
+    vvov, oovo, oovv = f(eng.tensor("v_vvov")), f(eng.tensor("v_oovo")), f(eng.tensor("v_oovv"))
+    out = np.zeros(4)
+    ns = threads
+    t0 = time.perf_counter()
+    L.orc_ccsd_t(o, v, e, f(t1), f(t2), vvov, oovo, oovv, 0, ns, out)
+    t_t = (time.perf_counter() - t0) * (o**3 / ns)
+    # pp-ladder slab: ncol columns (a,b) of the o^2 x v^2 x v^2 product (ccsd.f90:1669)
+    c = f(eng.tensor("c_oovv")).reshape(o * o, v * v, order="F")
+    ncol = 64
+    vv = np.zeros((v * v, ncol))
+    vv[:] = 0.01
+    t0 = time.perf_counter()
+    res = np.zeros(o * o * ncol)
+    L.orc_gemm(0, 0, o * o, ncol, v * v, 0.5, np.ascontiguousarray(c.ravel(order="F")), np.ascontiguousarray(vv.ravel(order="F")),
+               0.0, res)
+    t_lad = (time.perf_counter() - t0) * (v * v / ncol)
+    t_iter = t_lad * flops_iter(o, v) / (2 * o**2 * v**4)
+    sample = (f"(T): {ns}/{o**3} ordered triples scaled to o^3; CCSD iteration: {ncol}/{v*v} columns of the pp-ladder scaled "
+              "to v^2 and to the iteration's full flop count (extrapolated)")
+    return {"value": t_iter + t_t, "unit": "s/step", "ccsd_iter_s": t_iter, "t_s": t_t, "cores": threads, "kind": "port",
+            "sample": sample, "gflops": (flops_iter(o, v) + flops_t_ref(o, v)) / (t_iter + t_t) / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="h2o_tz", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scale", type=float, default=0.02)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(local)
+
+    from afesp_amd.capi import Engine
+    o, v = WORKLOADS[args.workload]
+    seed = 12345
+    eng = Engine(local)
+    eng.synthetic_init(o, v, args.scale, seed, 8)
+    eng.ccsd_energy()                                   # the "MP1" line: primes t2_old
+    nt = eng.ntriples()
+    lo, hi = rank * nt // world, (rank + 1) * nt // world   # contiguous shard of the i<=j<=k list
+    red = torch.zeros(4, dtype=torch.float64, device=f"cuda:{local}")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_iter = t_trip = 0.0
+    last = None
+
+    def step(timed):
+        nonlocal t_iter, t_trip, last
+        t0 = time.perf_counter()
+        eng.ccsd_iterate()
+        eng.ccsd_diis()
+        t1 = time.perf_counter()
+        part = eng.do_ccsd_t_spatial(lo, hi)
+        red.copy_(torch.from_numpy(part))
+        if dist is not None:
+            dist.all_reduce(red)                       # the only collective of the path: 4 doubles over xGMI
+        last = red.cpu().numpy()
+        t2 = time.perf_counter()
+        if timed:
+            t_iter += t1 - t0
+            t_trip += t2 - t1
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed, t_iter, t_trip], dtype=torch.float64, device=f"cuda:{local}")
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, t_iter, t_trip = [float(x) for x in tt.cpu()]
+    sec_per_step = elapsed / args.steps
+    flop_step = flops_iter(o, v) + flops_t_sym(o, v)
+
+    if rank == 0:
+        # dominant contraction of the iteration (pp-ladder, ccsd.f90:1669), timed with HIP events on the engine's stream
+        ms_lad = eng.time_pp_ladder(20 if o * v < 2000 else 5)
+        lad_flop = 2 * o**2 * v**4
+        lad_bytes = 8 * (v**4 + 2 * o**2 * v**2)
+        ai = lad_flop / lad_bytes
+        if ai > MFMA_F64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+            roof = {"bound": "mfma", "achieved": lad_flop / (ms_lad * 1e-3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s"}
+        else:
+            roof = {"bound": "hbm", "achieved": lad_bytes / (ms_lad * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof["kernel"] = "gett_kernel (pp-ladder 0.5*c_oovv(ij,ef)*v_vvvv(ef,ab))"
+        roof["ms_per_launch"] = ms_lad
+        line = {
+            "metric": "CCSD iter wall-time (s) + (T) wall-time (s); fp64 TFLOP/s vs MFMA peak",
+            "value": flop_step / sec_per_step / 1e12, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: nocc={o} nvirt={v}, synthetic hashed ERIs scale {args.scale}; "
+                                   "step = 1 CCSD iteration (replicated) + full (T) over i<=j<=k sharded across ranks",
+                       "nocc": o, "nvirt": v, "triples": int(nt), "parallelism": f"(T) ijk-shard x{world}, CCSD replicas"},
+            "ccsd_iter_s": t_iter / args.steps, "t_s": t_trip / args.steps,
+            "flop_per_step": flop_step, "fraction_of_mfma_peak": flop_step / sec_per_step / 1e12 / (MFMA_F64_PEAK_TFLOPS * world),
+            "e_t": [float(x) for x in last],
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(o, v, args.scale, seed, eng)
+        print(json.dumps(line))
+    barrier()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
