@@ -53,11 +53,14 @@ struct Context {
     double* scal = nullptr;               // small device scratch for reductions (64 doubles)
     double* scal_host = nullptr;          // pinned mirror
     std::map<std::string, Plan> plans;
+    std::map<std::string, std::pair<void*, size_t>> cache;   // named scratch buffers kept across calls (not zeroed)
     std::string last_error;
 
     double* alloc(int64_t n);             // zero-initialised doubles
     int64_t* alloc_i64(int64_t n);
     void release(void* p);                // early free of an `owned` buffer
+    double* scratch(const std::string& name, int64_t ndoubles);   // cached, uninitialised, grows on demand
+    void drop_scratch();
     Tensor tensor(std::initializer_list<int64_t> dims);
     void sync();
     ~Context();

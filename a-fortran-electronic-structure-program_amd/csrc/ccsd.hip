@@ -74,6 +74,7 @@ void ccsd_free(Context& cx, CCState& s)
                       s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_vovv_p.d, s.I_ooov_p.d, s.amp_s, s.hist_t,
                       s.hist_e, s.coef};
     for (double* b : bufs) cx.release(b);
+    cx.drop_scratch();
     s = CCState();
 }
 

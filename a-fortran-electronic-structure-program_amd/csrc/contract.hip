@@ -22,6 +22,27 @@ double* Context::alloc(int64_t n)
     return (double*)p;
 }
 int64_t* Context::alloc_i64(int64_t n) { return (int64_t*)alloc(n); }
+double* Context::scratch(const std::string& name, int64_t n)
+{
+    const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(double);
+    auto it = cache.find(name);
+    if (it != cache.end() && it->second.second >= bytes) return (double*)it->second.first;
+    if (it != cache.end()) {
+        AFESP_HIP(hipStreamSynchronize(stream));
+        (void)hipFree(it->second.first);
+        cache.erase(it);
+    }
+    void* p = nullptr;
+    AFESP_HIP(hipMalloc(&p, bytes));
+    cache[name] = {p, bytes};
+    return (double*)p;
+}
+void Context::drop_scratch()
+{
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto& kv : cache) (void)hipFree(kv.second.first);
+    cache.clear();
+}
 void Context::release(void* p)
 {
     if (!p) return;
@@ -43,6 +64,7 @@ Context::~Context()
 {
     if (stream) (void)hipStreamSynchronize(stream);
     for (void* p : owned) (void)hipFree(p);
+    for (auto& kv : cache) (void)hipFree(kv.second.first);
     if (scal_host) (void)hipHostFree(scal_host);
     if (stream) (void)hipStreamDestroy(stream);
 }

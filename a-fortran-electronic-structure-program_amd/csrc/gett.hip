@@ -20,16 +20,15 @@ namespace afesp {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
-constexpr int NT = 256;
 
-template <int BMN, bool KC>
+template <int BMN, bool KC, int NT>
 struct TileImg {
     static constexpr int LD = KC ? (BK + 2) : (BMN + 16);
     static constexpr int SIZE = KC ? BMN * LD : BK * LD;
     static constexpr int PER = BMN * BK / NT;  // elements staged per thread per K step
     __device__ static __forceinline__ int at(int mn, int k) { return KC ? mn * LD + k : k * LD + mn; }
     // staging map: which (mn,k) of the tile thread t handles as its r-th element
-    __device__ static __forceinline__ int mn_of(int t, int r) { return KC ? (t >> 4) + 16 * r : t % BMN; }
+    __device__ static __forceinline__ int mn_of(int t, int r) { return KC ? (t >> 4) + (NT / 16) * r : t % BMN; }
     __device__ static __forceinline__ int k_of(int t, int r) { return KC ? (t & 15) : t / BMN + (NT / BMN) * r; }
 };
 
@@ -38,9 +37,9 @@ struct TileImg {
 // before the MFMAs of the current step have been issued.
 // Rows/columns beyond M/N read a clamped (valid) address and produce garbage only in rows/columns of C that are never
 // stored; only the K tail has to be zeroed, which stash() does for the single partial step.
-template <int BMN, bool KC>
+template <int BMN, bool KC, int NT>
 struct Stager {
-    using T = TileImg<BMN, KC>;
+    using T = TileImg<BMN, KC, NT>;
     static constexpr int NROW = KC ? T::PER : 1;
     static constexpr int NKO = KC ? 1 : T::PER;
     int64_t rowoff[NROW];
@@ -105,18 +104,19 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-template <int TM, int TN, bool AKC, bool BKC>
-__global__ __launch_bounds__(NT) void gett_kernel(GettKernelArgs a)
+template <int WM, int WN, int TM, int TN, bool AKC, bool BKC>
+__global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
 {
-    constexpr int BM = 32 * TM, BN = 32 * TN;
-    using TA = TileImg<BM, AKC>;
-    using TB = TileImg<BN, BKC>;
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
+    using TA = TileImg<BM, AKC, NT>;
+    using TB = TileImg<BN, BKC, NT>;
     __shared__ double lds[2 * (TA::SIZE + TB::SIZE)];
     constexpr int STAGE = TA::SIZE + TB::SIZE;   // buffer b: A image at lds + b*STAGE, B image right behind it
 
     const GettProblem& p = a.p;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % WM, wn = wave / WM;
     // Grouped order: a group is `gm` m-tiles x all n-tiles walked m-fastest, so that the ~32 workgroups co-resident on
     // one XCD form a near-square patch of C and both operand panels are re-used out of that XCD's L2.
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(NT) void gett_kernel(GettKernelArgs a)
     const double* Ab = p.A + (p.batchA ? p.batchA[z] : 0);
     const double* Bb = p.B + (p.batchB ? p.batchB[z] : 0);
 
-    Stager<BM, AKC> stA;
-    Stager<BN, BKC> stB;
+    Stager<BM, AKC, NT> stA;
+    Stager<BN, BKC, NT> stB;
     stA.init(Ab, p.offAm, p.offAk, m0, p.M, p.K, t);
     stB.init(Bb, p.offBn, p.offBk, n0, p.N, p.K, t);
 
@@ -164,23 +164,28 @@ __global__ __launch_bounds__(NT) void gett_kernel(GettKernelArgs a)
     __syncthreads();
 
     const int fa = wm * 16 * TM + (lane & 15), fb = wn * 16 * TN + (lane & 15), fk = lane >> 4;
-    // MFMAs of K sub-step s (4 k values) of the LDS buffer at cA/cB
-    auto mfma_sub = [&](const double* cA, const double* cB, int s) {
-        double af[TM], bf[TN];
+    // Fragment registers are double-buffered too: the ds_reads of K sub-step s+1 are issued before the MFMAs of
+    // sub-step s, and the reads of the NEXT step's sub-step 0 are issued right after the barrier, underneath the MFMAs
+    // of this step's last sub-step -- so no MFMA ever waits for LDS latency except in the prologue.
+    double af0[TM], bf0[TN], af1[TM], bf1[TN];
+    auto frag = [&](double (&af)[TM], double (&bf)[TN], const double* cA, const double* cB, int s) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = cA[TA::at(fa + 16 * i, 4 * s + fk)];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j] = cB[TB::at(fb + 16 * j, 4 * s + fk)];
+    };
+    auto mfma = [&](const double (&af)[TM], const double (&bf)[TN]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
-    // One K step.  LDS buffer `cur` is consumed; register set (pa,pb) holds step kt+1 and is written to the other LDS
-    // buffer; set (qa,qb) receives step kt+2.  The memory instructions are dealt out between the four MFMA groups (and
-    // pinned there with sched_barrier) so that with one wave per SIMD the matrix pipe is not left idle while a block of
-    // address arithmetic, global loads or LDS stores issues.
+    if (nk > 0) frag(af0, bf0, lds, lds + TA::SIZE, 0);
+    // One K step.  On entry set 0 holds sub-step 0 of LDS buffer `cur`.  Register set (pa,pb) holds the gathered data of
+    // step kt+1 and is written to the other LDS buffer; set (qa,qb) receives step kt+2.  The single barrier sits between
+    // sub-steps 2 and 3: every read of buffer `cur` has been issued before it and every write of buffer cur^1 is
+    // complete, so after it the next step's first fragments can be read while sub-step 3 still multiplies.
 #define AFESP_GETT_STEP(qa, qb, pa, pb)                                                         \
     {                                                                                           \
         const int cur = kt & 1;                                                                 \
@@ -188,22 +193,25 @@ __global__ __launch_bounds__(NT) void gett_kernel(GettKernelArgs a)
         const double* cB = cA + TA::SIZE;                                                       \
         const bool ld = kt + 2 < nk, st = kt + 1 < nk;                                          \
         const bool tail = ragged && (kt + 2 == nk);                                             \
+        frag(af1, bf1, cA, cB, 1);                                                              \
         if (ld) stA.fetch(qa);                                                                  \
-        mfma_sub(cA, cB, 0);                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
+        mfma(af0, bf0);                                                                         \
+        frag(af0, bf0, cA, cB, 2);                                                              \
         if (ld) stB.fetch(qb);                                                                  \
-        mfma_sub(cA, cB, 1);                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
+        mfma(af1, bf1);                                                                         \
+        frag(af1, bf1, cA, cB, 3);                                                              \
         if (ld) {                                                                               \
             stA.fetch_ko(kbeg + (kt + 3) * BK, t);                                              \
             stB.fetch_ko(kbeg + (kt + 3) * BK, t);                                              \
         }                                                                                       \
-        if (st) stA.stash(lds + (cur ^ 1) * STAGE, pa, t, kbeg + (kt + 1) * BK, kend, tail);    \
-        mfma_sub(cA, cB, 2);                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        if (st) stB.stash(lds + (cur ^ 1) * STAGE + TA::SIZE, pb, t, kbeg + (kt + 1) * BK, kend, tail); \
-        mfma_sub(cA, cB, 3);                                                                    \
+        if (st) {                                                                               \
+            stA.stash(lds + (cur ^ 1) * STAGE, pa, t, kbeg + (kt + 1) * BK, kend, tail);        \
+            stB.stash(lds + (cur ^ 1) * STAGE + TA::SIZE, pb, t, kbeg + (kt + 1) * BK, kend, tail); \
+        }                                                                                       \
+        mfma(af0, bf0);                                                                         \
         __syncthreads();                                                                        \
+        if (st) frag(af0, bf0, lds + (cur ^ 1) * STAGE, lds + (cur ^ 1) * STAGE + TA::SIZE, 0); \
+        mfma(af1, bf1);                                                                         \
     }
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
@@ -279,19 +287,21 @@ __global__ __launch_bounds__(256) void gett_reduce_kernel(GettKernelArgs a)
     }
 }
 
-template <int TM, int TN>
-static void launch_tile(const GettKernelArgs& a, dim3 grid, hipStream_t st)
+template <int WM, int WN, int TM, int TN>
+static void launch_cfg(const GettKernelArgs& a, dim3 grid, hipStream_t st)
 {
     const bool ak = a.p.a_kcontig, bk = a.p.b_kcontig;
-    if (ak && bk) hipLaunchKernelGGL((gett_kernel<TM, TN, true, true>), grid, dim3(NT), 0, st, a);
-    else if (ak) hipLaunchKernelGGL((gett_kernel<TM, TN, true, false>), grid, dim3(NT), 0, st, a);
-    else if (bk) hipLaunchKernelGGL((gett_kernel<TM, TN, false, true>), grid, dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((gett_kernel<TM, TN, false, false>), grid, dim3(NT), 0, st, a);
+    const dim3 blk(64 * WM * WN);
+    if (ak && bk) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, true, true>), grid, blk, 0, st, a);
+    else if (ak) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, true, false>), grid, blk, 0, st, a);
+    else if (bk) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, false, true>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, false, false>), grid, blk, 0, st, a);
 }
 
 int g_group_m = 0;   // >0 overrides the tile-walk group size (tuning knob, see afesp_set_tuning)
 int g_force_tm = 0, g_force_tn = 0, g_force_split = 0;
 
+// Block tile extent (rows or columns) for a requested code: 1 -> 32, 2 -> 64, 4 -> 128; 8 = 128 with 8 waves.
 static int pick_t(int extent)
 {
     if (extent <= 32) return 1;
@@ -309,7 +319,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     if (!force_tn) force_tn = g_force_tn;
     if (!force_split) force_split = g_force_split;
     const int tm = force_tm ? force_tm : pick_t(p.M), tn = force_tn ? force_tn : pick_t(p.N);
-    const int BM = 32 * tm, BN = 32 * tn;
+    const int BM = tm == 8 ? 128 : 32 * tm, BN = tn == 8 ? 128 : 32 * tn;
     a.mtiles = (p.M + BM - 1) / BM;
     a.ntiles = (p.N + BN - 1) / BN;
     const int64_t tiles = (int64_t)a.mtiles * a.ntiles * p.nbatch;
@@ -337,12 +347,15 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     a.gm = g_group_m > 0 ? g_group_m : (a.ntiles >= 8 ? 4 : a.ntiles >= 4 ? 8 : a.ntiles >= 2 ? 16 : 32);
     if (a.gm > a.mtiles) a.gm = a.mtiles;
     dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)a.ksplit, (unsigned)p.nbatch);
-#define AFESP_TILE(TM_, TN_) \
-    if (tm == TM_ && tn == TN_) launch_tile<TM_, TN_>(a, grid, stream);
-    AFESP_TILE(1, 1) AFESP_TILE(1, 2) AFESP_TILE(1, 4)
-    AFESP_TILE(2, 1) AFESP_TILE(2, 2) AFESP_TILE(2, 4)
-    AFESP_TILE(4, 1) AFESP_TILE(4, 2) AFESP_TILE(4, 4)
-#undef AFESP_TILE
+    // tile code (tm,tn) -> wave grid x per-wave MFMA grid.  (4,4) is the 8-wave 128x128 tile: two waves per SIMD share
+    // the matrix pipe, so one wave's gather/LDS phases are covered by the other's MFMAs.
+#define AFESP_CFG(TM_, TN_, WM_, WN_, PM_, PN_) \
+    if (tm == TM_ && tn == TN_) launch_cfg<WM_, WN_, PM_, PN_>(a, grid, stream);
+    AFESP_CFG(1, 1, 2, 2, 1, 1) AFESP_CFG(1, 2, 2, 2, 1, 2) AFESP_CFG(1, 4, 2, 2, 1, 4)
+    AFESP_CFG(2, 1, 2, 2, 2, 1) AFESP_CFG(2, 2, 2, 2, 2, 2) AFESP_CFG(2, 4, 2, 2, 2, 4)
+    AFESP_CFG(4, 1, 2, 2, 4, 1) AFESP_CFG(4, 2, 2, 2, 4, 2) AFESP_CFG(4, 4, 2, 4, 4, 2)
+    AFESP_CFG(8, 8, 2, 2, 4, 4)
+#undef AFESP_CFG
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     if (a.ksplit > 1) {

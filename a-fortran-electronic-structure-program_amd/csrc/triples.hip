@@ -8,8 +8,13 @@
 // ALL ordered triples with the reference's x_bar = 4/3 x(abc) - 2 x(acb) + 2/3 x(cab) (:2314-2318) therefore equals
 // the sum with the symmetrised x_bar = [4 x(abc) + x(bca) + x(cab) - 2 x(acb) - 2 x(bac) - 2 x(cba)]/3 (the weight
 // of a permutation class is what matters once all (ijk) are summed), and that per-triple functional is invariant
-// under permuting (ijk).  Here: only i<=j<=k is visited, with multiplicity 6/3/1; each distinct ordered X is ONE
-// (v x v) . (v x v^2) MFMA GEMM plus one (v^2 x o) . (o x v) GEMM, batched over a chunk of triples.
+// under permuting (ijk).  Here: only i<=j<=k is visited, with multiplicity 6/3/1.
+// The hole halves can be re-dealt among the six terms (only their sum matters): pairing the particle half of term 1 with
+// the hole half of term 3 gives
+//     X^{ijk}(a,b,c) = sum_d t2(i,j,a,d) <cb|kd>  -  sum_l t2(l,k,b,c) <ij|al>
+// whose two halves share the row index (b,c; k) and the column index (a; i,j): ONE GEMM over the concatenated summation
+// index kappa = d (+) l of length v+o, with no read-modify-write pass for the hole term.  All ordered triples of a
+// chunk that share k go into one launch: rows (b,c), columns (a, pair list), K = v+o.
 #include <algorithm>
 #include <cmath>
 
@@ -26,73 +31,138 @@ struct TripleMeta {
     int64_t woff;
 };
 
-// W(a,b,c) = X0(a,b,c) + X1(b,a,c) + X2(c,b,a) + X3(a,c,b) + X4(b,c,a) + X5(c,a,b)      ccsd.f90:2168-2173
-__global__ __launch_bounds__(256) void triples_w_kernel(double* __restrict__ Wpool, const double* __restrict__ Xpool,
-                                                        const TripleMeta* __restrict__ meta, int v)
-{
-    const TripleMeta m = meta[blockIdx.y];
-    const int64_t v3 = (int64_t)v * v * v;
-    double* W = Wpool + m.woff;
-    const double* X0 = Xpool + m.xoff[0]; const double* X1 = Xpool + m.xoff[1]; const double* X2 = Xpool + m.xoff[2];
-    const double* X3 = Xpool + m.xoff[3]; const double* X4 = Xpool + m.xoff[4]; const double* X5 = Xpool + m.xoff[5];
-    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < v3; x += (int64_t)gridDim.x * blockDim.x) {
-        const int a = (int)(x % v), b = (int)((x / v) % v), c = (int)(x / ((int64_t)v * v));
-#define AT(p, q, r) ((p) + (int64_t)v * ((q) + (int64_t)v * (r)))
-        W[x] = X0[x] + X1[AT(b, a, c)] + X2[AT(c, b, a)] + X3[AT(a, c, b)] + X4[AT(b, c, a)] + X5[AT(c, a, b)];
-    }
-}
-
 struct TriplesIn {
     const double* e;
     const double* t1;
-    const double* t2;
-    const double* v_oovv;
+    const double* voovv_s;   // voovv_s(x,y,p,q) = v_oovv(p,q,x,y): contiguous v x v slice per occupied pair
+    const double* t2_s;      // t2_s(x,y,p,q)    = t2(p,q,x,y)
+    const double* t2;        // natural layout, for the D base term only
     int o, v;
 };
 
-// Per element: D (ccsd.f90:2175), z (:2178-2179), y (:2183-2184), symmetrised bars, four sums (:2218-2233).
-__global__ __launch_bounds__(256) void triples_e_kernel(double* __restrict__ partial, const double* __restrict__ Wpool,
-                                                        const TripleMeta* __restrict__ meta, TriplesIn in, int nblk_total)
+// The six simultaneous index permutations of ccsd.f90:2168-2173, in the order of the six term pairs:
+// (abc) (bac) (cba) (acb) (bca) (cab); SIG[s][d] = which of (a,b,c) sits in position d.
+__device__ __constant__ int SIG[6][3] = {{0, 1, 2}, {1, 0, 2}, {2, 1, 0}, {0, 2, 1}, {1, 2, 0}, {2, 0, 1}};
+constexpr int TT = 8;                 // cube edge
+constexpr int CUBE = TT * TT * TT;    // 512 elements
+constexpr int PATCH = TT * TT;
+
+// Fused "orbit" kernel.  The virtual index space is cut into 8x8x8 cubes; a workgroup owns the orbit of one cube
+// under the six permutations -- the only set that is closed under every index permutation the formulas use:
+//   W(a,b,c)   = sum_s X_s(sigma_s(a,b,c))                                   ccsd.f90:2168-2173
+//   t_bar      = [4W(abc) + W(bca) + W(cab) - 2W(acb) - 2W(bac) - 2W(cba)] / 3D   (symmetrised form of :2314-2318)
+// Every X element is read from HBM exactly once (coalesced along its own leading index) and W never leaves LDS.
+__global__ __launch_bounds__(256) void triples_orbit_kernel(double* __restrict__ partial, const double* __restrict__ Xpool,
+                                                            const TripleMeta* __restrict__ meta,
+                                                            const int* __restrict__ orbits, TriplesIn in, int nblk_total)
 {
-    __shared__ double sm[16];
+    __shared__ double stage[6 * CUBE + 512];   // X cubes of one term; later the V / T2 patches and t1 rows
+    __shared__ double wl[6 * CUBE];            // W on the six cubes of the orbit
+    __shared__ int srcq[6][6];                 // srcq[s][q]: which staged cube holds sigma_s applied to cube q
+    __shared__ int dup[6];                     // 1 if cube q repeats an earlier cube of the orbit (degenerate orbit)
+    __shared__ double red[16];
     const TripleMeta m = meta[blockIdx.y];
-    const int o = in.o, v = in.v;
-    const int64_t v3 = (int64_t)v * v * v;
-    const double* W = Wpool + m.woff;
-    const int i = m.i, j = m.j, k = m.k;
-    const double eo = in.e[i] + in.e[j] + in.e[k];
+    const int o = in.o, v = in.v, t = threadIdx.x;
+    const int packed = orbits[blockIdx.x];
+    const int tile[3] = {packed & 1023, (packed >> 10) & 1023, (packed >> 20) & 1023};
+    // tile coordinates of cube q: position d holds tile[SIG[q][d]]
+    if (t < 36) {
+        const int s = t / 6, q = t % 6;
+        // sigma_s applied to cube q: position d of the source holds position SIG[s][d] of cube q
+        int want[3];
+        for (int d = 0; d < 3; ++d) want[d] = tile[SIG[q][SIG[s][d]]];
+        int found = 0;
+        for (int r = 5; r >= 0; --r)
+            if (tile[SIG[r][0]] == want[0] && tile[SIG[r][1]] == want[1] && tile[SIG[r][2]] == want[2]) found = r;
+        srcq[s][q] = found;
+        if (s == 0) dup[q] = (found != q);   // sigma_0 is the identity: first cube with the same coordinates
+    }
+    const int64_t vv = (int64_t)v * v;
+    double wreg[12];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) wreg[r] = 0.0;
+    for (int s = 0; s < 6; ++s) {
+        const double* X = Xpool + m.xoff[s];
+        __syncthreads();   // previous term's readers are done with `stage` (also publishes srcq on the first pass)
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const int el = t + 256 * r, q = el >> 9, loc = el & 511;
+            const int g0 = tile[SIG[q][0]] * TT + (loc & 7), g1 = tile[SIG[q][1]] * TT + ((loc >> 3) & 7),
+                      g2 = tile[SIG[q][2]] * TT + (loc >> 6);
+            const bool ok = g0 < v && g1 < v && g2 < v;
+            stage[el] = ok ? X[g0 + (int64_t)v * g1 + vv * g2] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const int el = t + 256 * r, q = el >> 9, loc = el & 511;
+            const int l[3] = {loc & 7, (loc >> 3) & 7, loc >> 6};
+            wreg[r] += stage[srcq[s][q] * CUBE + l[SIG[s][0]] + TT * l[SIG[s][1]] + PATCH * l[SIG[s][2]]];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 12; ++r) wl[t + 256 * r] = wreg[r];
+    __syncthreads();
+    // patches: vp[pair][sx][sy][lx + 8 ly] = V_pair(x in tile[sx], y in tile[sy]); pairs (j,k), (i,k), (i,j)
+    double* vp = stage;                  // 3*9*64
+    double* tp = stage + 27 * PATCH;     // 3*9*64
+    double* t1r = stage + 54 * PATCH;    // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l)
+    const int occ[3] = {m.i, m.j, m.k};
+    const int pairp[3] = {m.j, m.i, m.i}, pairq[3] = {m.k, m.k, m.j};
+    for (int el = t; el < 27 * PATCH; el += 256) {
+        const int pr = el / (9 * PATCH), rest = el % (9 * PATCH), sx = rest / (3 * PATCH), sy = (rest / PATCH) % 3, loc = rest % PATCH;
+        const int gx = tile[sx] * TT + (loc & 7), gy = tile[sy] * TT + (loc >> 3);
+        const bool ok = gx < v && gy < v;
+        const int64_t off = gx + (int64_t)v * gy + vv * (pairp[pr] + (int64_t)o * pairq[pr]);
+        vp[el] = ok ? in.voovv_s[off] : 0.0;
+        tp[el] = ok ? in.t2_s[off] : 0.0;
+    }
+    if (t < 72) {
+        const int oc = t / 24, sl = (t / 8) % 3, l = t & 7, g = tile[sl] * TT + l;
+        t1r[t] = g < v ? in.t1[occ[oc] + o * g] : 0.0;
+    }
+    __syncthreads();
+    const double eo = in.e[m.i] + in.e[m.j] + in.e[m.k];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#define T1(p, x) in.t1[(p) + o * (x)]
-#define T2(p, q, x, y) in.t2[(p) + (int64_t)o * ((q) + (int64_t)o * ((x) + (int64_t)v * (y)))]
-#define VO(p, q, x, y) in.v_oovv[(p) + (int64_t)o * ((q) + (int64_t)o * ((x) + (int64_t)v * (y)))]
-#define ZZ(x, y, z) (T1(i, x) * VO(j, k, y, z) + T1(j, y) * VO(i, k, x, z) + T1(k, z) * VO(i, j, x, y))
-    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < v3; x += (int64_t)gridDim.x * blockDim.x) {
-        const int a = (int)(x % v), b = (int)((x / v) % v), c = (int)(x / ((int64_t)v * v));
-        const double D = eo - in.e[a + o] - in.e[b + o] - in.e[c + o];
-        const double w = W[x];
-        const double wb = (4.0 * w + W[AT(b, c, a)] + W[AT(c, a, b)] - 2.0 * (W[AT(a, c, b)] + W[AT(b, a, c)] + W[AT(c, b, a)])) / 3.0;
-        const double zb = (4.0 * ZZ(a, b, c) + ZZ(b, c, a) + ZZ(c, a, b) - 2.0 * (ZZ(a, c, b) + ZZ(b, a, c) + ZZ(c, b, a))) / 3.0;
-        const double y = T1(i, a) * T1(j, b) * T1(k, c) + T1(i, a) * T2(j, k, b, c) + T1(j, b) * T2(i, k, a, c) + T1(k, c) * T2(i, j, a, b);
+#pragma unroll 2
+    for (int r = 0; r < 12; ++r) {
+        const int el = t + 256 * r, q = el >> 9, loc = el & 511;
+        if (dup[q]) continue;
+        const int l[3] = {loc & 7, (loc >> 3) & 7, loc >> 6};
+        const int sl[3] = {SIG[q][0], SIG[q][1], SIG[q][2]};   // tile slot of a, b, c
+        const int ga = tile[sl[0]] * TT + l[0], gb = tile[sl[1]] * TT + l[1], gc = tile[sl[2]] * TT + l[2];
+        if (ga >= v || gb >= v || gc >= v) continue;
+        const double D = eo - in.e[ga + o] - in.e[gb + o] - in.e[gc + o];
+        // W at sigma_s(a,b,c): cube srcq[s][q], local coordinates permuted
+#define WAT(s) wl[srcq[s][q] * CUBE + l[SIG[s][0]] + TT * l[SIG[s][1]] + PATCH * l[SIG[s][2]]]
+        const double w = wl[el];
+        const double wb = (4.0 * w + WAT(4) + WAT(5) - 2.0 * (WAT(3) + WAT(1) + WAT(2))) / 3.0;
+        // Z(x,y,z) = t1(i,x) V_jk(y,z) + t1(j,y) V_ik(x,z) + t1(k,z) V_ij(x,y)      ccsd.f90:2178-2179 (numerator)
+#define T1R(oc, d) t1r[(oc) * 24 + sl[d] * 8 + l[d]]
+#define VP(arr, pr, dx, dy) arr[((pr) * 9 + sl[dx] * 3 + sl[dy]) * PATCH + l[dx] + TT * l[dy]]
+#define ZAT(x, y, z) (T1R(0, x) * VP(vp, 0, y, z) + T1R(1, y) * VP(vp, 1, x, z) + T1R(2, z) * VP(vp, 2, x, y))
+        const double zb = (4.0 * ZAT(0, 1, 2) + ZAT(1, 2, 0) + ZAT(2, 0, 1) - 2.0 * (ZAT(0, 2, 1) + ZAT(1, 0, 2) + ZAT(2, 1, 0))) / 3.0;
+        // y (ccsd.f90:2183-2184)
+        const double y = T1R(0, 0) * T1R(1, 1) * T1R(2, 2) + T1R(0, 0) * VP(tp, 0, 1, 2) + T1R(1, 1) * VP(tp, 1, 0, 2) +
+                         T1R(2, 2) * VP(tp, 2, 0, 1);
         const double tbar = wb / D, zbar = zb / D;
         acc[0] += tbar * w;
         acc[1] += zbar * w;
         acc[2] += tbar * y;
         acc[3] += zbar * y;
     }
-    // block reduction (wave shuffle, then 4 waves through LDS)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = t & 63, wv = t >> 6;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        double s = acc[q];
+        double sdl = acc[q];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) sm[q * 4 + wv] = s;
+        for (int off = 32; off > 0; off >>= 1) sdl += __shfl_down(sdl, off, 64);
+        if (lane == 0) red[q * 4 + wv] = sdl;
     }
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const int q = threadIdx.x;
+    if (t < 4) {
         const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-        partial[(int64_t)q * nblk_total + blk] = m.mult * (sm[q * 4] + sm[q * 4 + 1] + sm[q * 4 + 2] + sm[q * 4 + 3]);
+        partial[(int64_t)t * nblk_total + blk] = m.mult * (red[t * 4] + red[t * 4 + 1] + red[t * 4 + 2] + red[t * 4 + 3]);
     }
 }
 
@@ -110,29 +180,31 @@ __global__ __launch_bounds__(256) void triples_sum_kernel(double* out, const dou
     if (threadIdx.x == 0) out[q] += sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-// ccsd.f90:2243: 1 + 2 sum t1^2 + sum asym_t2 * c_oovv
-__global__ __launch_bounds__(256) void triples_dbase_kernel(double* out, TriplesIn in)
+// ccsd.f90:2243: 1 + 2 sum t1^2 + sum asym_t2 * c_oovv.  One partial per block; the ordered sum is done by triples_sum_kernel.
+__global__ __launch_bounds__(256) void triples_dbase_kernel(double* partial, TriplesIn in, int nblk_total)
 {
     __shared__ double sm[4];
     const int o = in.o, v = in.v;
     const int64_t n = (int64_t)o * o * v * v;
     double s = 0.0;
-    for (int64_t x = threadIdx.x; x < n; x += blockDim.x) {
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
         int i = (int)(x % o);
         int64_t r = x / o;
         int j = (int)(r % o);
         r /= o;
         int a = (int)(r % v), b = (int)(r / v);
-        double t = in.t2[x];
-        s += (2.0 * t - T2(j, i, a, b)) * (t + T1(i, a) * T1(j, b));
+        double tv = in.t2[x];
+        double tx = in.t2[j + (int64_t)o * (i + (int64_t)o * (a + (int64_t)v * b))];
+        s += (2.0 * tv - tx) * (tv + in.t1[i + o * a] * in.t1[j + o * b]);
+        if (j == 0 && b == 0) s += 2.0 * in.t1[i + o * a] * in.t1[i + o * a];
     }
-    for (int x = threadIdx.x; x < o * v; x += blockDim.x) s += 2.0 * in.t1[x] * in.t1[x];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        out[2] += 1.0 + sm[0] + sm[1] + sm[2] + sm[3];   // D(T) = out[2] + out[3], so the base term enters once
+        for (int q = 0; q < 4; ++q) partial[(int64_t)q * nblk_total + blockIdx.x] = 0.0;
+        partial[(int64_t)2 * nblk_total + blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3] + (blockIdx.x == 0 ? 1.0 : 0.0);
     }
 }
 
@@ -144,61 +216,113 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     const int64_t ntot = triples_count(o);
     t_begin = std::max<int64_t>(0, t_begin);
     t_end = std::min<int64_t>(ntot, t_end);
-    // operand layouts with the summed index first (the reference does the same, ccsd.f90:2056-2066)
-    Tensor t2r = cx.tensor({V, V, O, O});   // t2r(d,a,j,i) = t2(i,j,a,d)
-    Tensor t2h = cx.tensor({O, V, V, O});   // t2h(l,a,b,i) = t2(l,i,b,a)
-    Tensor vr = cx.tensor({V, V, V, O});    // vr(d,b,c,k)  = <cb|kd> = v_vvov(c,b,k,d)
-    Tensor orr = cx.tensor({O, V, O, O});   // or(l,c,j,k)  = <kj|cl> = v_oovo(k,j,c,l)
-    permute_add(cx, 1.0, s.t2, "ijad", 0.0, t2r, "daji");
-    permute_add(cx, 1.0, s.t2, "liba", 0.0, t2h, "labi");
-    permute_add(cx, 1.0, s.v_vvov, "cbkd", 0.0, vr, "dbck");
-    permute_add(cx, 1.0, s.v_oovo, "kjcl", 0.0, orr, "lcjk");
+    // concatenated operands, summed index kappa = [d ; l] first (the reference also moves the summed index first, :2056-2066)
+    //   vt(kappa,b,c,k): kappa<v: <cb|kd> = v_vvov(c,b,k,d);  kappa=v+l: t2(l,k,b,c)
+    //   tt(kappa,a,j,i): kappa<v: t2(i,j,a,d);                kappa=v+l: -<ij|al> = -v_oovo(i,j,a,l)
+    const int64_t Kc = V + O;
+    Tensor vt = view(cx.scratch("t_vt", Kc * v2 * O), {Kc, V, V, O}), tt = view(cx.scratch("t_tt", Kc * V * O * O), {Kc, V, O, O});
+    auto sub = [&](const Tensor& full, int64_t row0, int64_t nrows) {
+        Tensor t = full;
+        t.d = full.d + row0;
+        t.dim[0] = nrows;
+        return t;
+    };
+    permute_add(cx, 1.0, s.v_vvov, "cbkd", 0.0, sub(vt, 0, V), "dbck");
+    permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vt, V, O), "lbck");
+    permute_add(cx, 1.0, s.t2, "ijad", 0.0, sub(tt, 0, V), "daji");
+    permute_add(cx, -1.0, s.v_oovo, "ijal", 0.0, sub(tt, V, O), "laji");
+    Tensor vs = view(cx.scratch("t_vs", v2 * O * O), {V, V, O, O});    // vs(x,y,p,q)  = v_oovv(p,q,x,y)
+    Tensor ts = view(cx.scratch("t_ts", v2 * O * O), {V, V, O, O});    // ts(x,y,p,q)  = t2(p,q,x,y)
+    permute_add(cx, 1.0, s.v_oovv, "pqxy", 0.0, vs, "xypq");
+    permute_add(cx, 1.0, s.t2, "pqxy", 0.0, ts, "xypq");
+    // offset tables shared by every launch: kappa, and the (b,c) rows of vt / X
+    std::vector<int64_t> hk((size_t)Kc), hAm((size_t)v2), hCm((size_t)v2);
+    for (int64_t x = 0; x < Kc; ++x) hk[(size_t)x] = x;
+    for (int64_t c = 0; c < V; ++c)
+        for (int64_t b = 0; b < V; ++b) {
+            hAm[(size_t)(b + V * c)] = Kc * (b + V * c);
+            hCm[(size_t)(b + V * c)] = V * b + v2 * c;
+        }
+    int64_t* d_k = cx.alloc_i64(Kc);
+    int64_t* d_Am = cx.alloc_i64(v2);
+    int64_t* d_Cm = cx.alloc_i64(v2);
+    AFESP_HIP(hipMemcpyAsync(d_k, hk.data(), sizeof(int64_t) * Kc, hipMemcpyHostToDevice, cx.stream));
+    AFESP_HIP(hipMemcpyAsync(d_Am, hAm.data(), sizeof(int64_t) * v2, hipMemcpyHostToDevice, cx.stream));
+    AFESP_HIP(hipMemcpyAsync(d_Cm, hCm.data(), sizeof(int64_t) * v2, hipMemcpyHostToDevice, cx.stream));
+    cx.sync();
     k_fill(cx, cx.scal, 4, 0.0);
-    TriplesIn in{s.e, s.t1.d, s.t2.d, s.v_oovv.d, o, v};
+    TriplesIn in{s.e, s.t1.d, vs.d, ts.d, s.t2.d, o, v};
 
-    // chunk size from a memory budget: 6 X blocks + 1 W block of v^3 doubles per triple
-    const int64_t per = 7 * v3 * (int64_t)sizeof(double);
-    int64_t nb = std::max<int64_t>(1, ((int64_t)6 << 30) / per);
-    nb = std::min<int64_t>(nb, 2048);
+    // orbits of 8x8x8 cubes under index permutation: tile triples A <= B <= C
+    const int nt8 = (v + TT - 1) / TT;
+    std::vector<int> orb;
+    for (int A = 0; A < nt8; ++A)
+        for (int B = A; B < nt8; ++B)
+            for (int C = B; C < nt8; ++C) orb.push_back(A | (B << 10) | (C << 20));
+    const int norb = (int)orb.size();
+    int* orb_d = (int*)cx.alloc((int64_t)(norb + 1) / 2 + 1);
+    AFESP_HIP(hipMemcpyAsync(orb_d, orb.data(), sizeof(int) * norb, hipMemcpyHostToDevice, cx.stream));
+
+    // chunk size from a memory budget: 6 X blocks of v^3 doubles per triple (W never leaves LDS)
+    const int64_t per = 6 * v3 * (int64_t)sizeof(double);
+    // ~48 ordered triples per k-group keep the GEMM column count in the thousands; more buys nothing
+    int64_t budget = (int64_t)24 << 30;
+    int64_t nb = std::max<int64_t>(1, budget / per);
+    nb = std::min<int64_t>(nb, 4096);
     nb = std::min<int64_t>(nb, std::max<int64_t>(1, t_end - t_begin));
-    double* Xpool = cx.alloc(6 * nb * v3);
-    double* Wpool = cx.alloc(nb * v3);
+    double* Xpool = cx.scratch("t_xpool", 6 * nb * v3);
     TripleMeta* meta_d = (TripleMeta*)cx.alloc((int64_t)(nb * sizeof(TripleMeta) / sizeof(double) + 1));
-    int64_t* boff = cx.alloc_i64(6 * nb * 5);   // bA_p, bB_p, bC, bA_h, bB_h
-    const int eblocks = (int)std::max<int64_t>(1, std::min<int64_t>((v3 + 255) / 256, 256));
-    double* partial = cx.alloc(4 * nb * eblocks);
+    int64_t* d_n = cx.alloc_i64(2 * 6 * nb * V);   // per chunk: column tables offBn | offCn of every k-group
+    const int64_t npart = std::max<int64_t>((int64_t)norb * nb, 512);
+    double* partial = cx.scratch("t_partial", 4 * npart);
 
     // enumerate i<=j<=k in a fixed order and walk the requested range chunk by chunk
     std::vector<TripleMeta> meta;
-    std::vector<int64_t> hA, hB, hC, hAh, hBh;
+    struct Ord { int p, q, r; int64_t buf; };
+    std::vector<Ord> ords;   // distinct ordered triples of the chunk, buf = index of its v^3 block in Xpool
     int64_t flat = 0;
     auto flush = [&]() {
         if (meta.empty()) return;
-        const int nx = (int)hC.size(), nt = (int)meta.size();
-        std::vector<int64_t> pack;
-        pack.reserve((size_t)nx * 5);
-        pack.insert(pack.end(), hA.begin(), hA.end());
-        pack.insert(pack.end(), hB.begin(), hB.end());
-        pack.insert(pack.end(), hC.begin(), hC.end());
-        pack.insert(pack.end(), hAh.begin(), hAh.end());
-        pack.insert(pack.end(), hBh.begin(), hBh.end());
-        AFESP_HIP(hipMemcpyAsync(boff, pack.data(), pack.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
+        const int nt = (int)meta.size();
+        // group the ordered triples by their last index r (= the occupied index carried by vt)
+        std::vector<int64_t> hBn, hCn;
+        std::vector<std::pair<int, std::pair<int64_t, int64_t>>> groups;   // r, (table start, N)
+        for (int r = 0; r < o; ++r) {
+            const int64_t start = (int64_t)hBn.size();
+            for (const Ord& od : ords)
+                if (od.r == r)
+                    for (int64_t a = 0; a < V; ++a) {
+                        hBn.push_back(Kc * (a + V * (od.q + O * od.p)));   // tt(:, a, q, p)
+                        hCn.push_back(a + v3 * od.buf);
+                    }
+            const int64_t N = (int64_t)hBn.size() - start;
+            if (N > 0) groups.push_back({r, {start, N}});
+        }
+        const int64_t ntab = (int64_t)hBn.size();
+        AFESP_HIP(hipMemcpyAsync(d_n, hBn.data(), sizeof(int64_t) * ntab, hipMemcpyHostToDevice, cx.stream));
+        AFESP_HIP(hipMemcpyAsync(d_n + ntab, hCn.data(), sizeof(int64_t) * ntab, hipMemcpyHostToDevice, cx.stream));
         AFESP_HIP(hipMemcpyAsync(meta_d, meta.data(), meta.size() * sizeof(TripleMeta), hipMemcpyHostToDevice, cx.stream));
         cx.sync();
-        // X(a,b,c) = sum_d t2r(d,a | q,p) vr(d,b,c | r)                     particle half of ccsd.f90:2168
-        Tensor Ablk = view(t2r.d, {V, V}), Bblk = view(vr.d, {V, V, V}), Xblk = view(Xpool, {V, V, V});
-        contract(cx, 1.0, Ablk, "da", Bblk, "dbc", 0.0, Xblk, "abc", nx, boff, boff + nx, boff + 2 * nx);
-        // X(a,b,c) -= sum_l t2h(l,a,b | p) or(l,c | q,r)                      hole half
-        Tensor Ah = view(t2h.d, {O, V, V}), Bh = view(orr.d, {O, V});
-        contract(cx, -1.0, Ah, "lab", Bh, "lc", 1.0, Xblk, "abc", nx, boff + 3 * nx, boff + 4 * nx, boff + 2 * nx);
-        hipLaunchKernelGGL(triples_w_kernel, dim3(eblocks, nt), dim3(256), 0, cx.stream, Wpool, Xpool, meta_d, v);
+        for (auto& g : groups) {
+            GettProblem gp;
+            gp.A = vt.d + Kc * v2 * g.first;   // vt(:,:,:,r)
+            gp.B = tt.d;
+            gp.C = Xpool;
+            gp.offAm = d_Am; gp.offAk = d_k; gp.offBk = d_k; gp.offBn = d_n + g.second.first;
+            gp.offCm = d_Cm; gp.offCn = d_n + ntab + g.second.first;
+            gp.M = (int)v2; gp.N = (int)g.second.second; gp.K = (int)Kc;
+            gp.alpha = 1.0; gp.beta = 0.0;
+            gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
+            gp.a_kcontig = gp.b_kcontig = true;
+            AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+        }
+        hipLaunchKernelGGL(triples_orbit_kernel, dim3(norb, nt), dim3(256), 0, cx.stream, partial, Xpool, meta_d, orb_d, in,
+                           norb * nt);
         AFESP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(triples_e_kernel, dim3(eblocks, nt), dim3(256), 0, cx.stream, partial, Wpool, meta_d, in, eblocks * nt);
-        AFESP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, eblocks * nt);
+        hipLaunchKernelGGL(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, norb * nt);
         AFESP_HIP(hipGetLastError());
         cx.sync();
-        meta.clear(); hA.clear(); hB.clear(); hC.clear(); hAh.clear(); hBh.clear();
+        meta.clear(); ords.clear();
     };
     for (int i = 0; i < o && flat < t_end; ++i)
         for (int j = i; j < o && flat < t_end; ++j)
@@ -207,27 +331,25 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
                 TripleMeta m;
                 m.i = i; m.j = j; m.k = k; m.pad = 0;
                 m.mult = (i == j && j == k) ? 1.0 : (i == j || j == k) ? 3.0 : 6.0;
-                m.woff = (int64_t)meta.size() * v3;
+                m.woff = 0;
                 const int P[6][3] = {{i, j, k}, {j, i, k}, {k, j, i}, {i, k, j}, {j, k, i}, {k, i, j}};
                 for (int q = 0; q < 6; ++q) {
                     int found = -1;
                     for (int r = 0; r < q; ++r)
                         if (P[r][0] == P[q][0] && P[r][1] == P[q][1] && P[r][2] == P[q][2]) { found = r; break; }
                     if (found >= 0) { m.xoff[q] = m.xoff[found]; continue; }
-                    const int p_ = P[q][0], q_ = P[q][1], r_ = P[q][2];
-                    m.xoff[q] = (int64_t)hC.size() * v3;
-                    hC.push_back(m.xoff[q]);
-                    hA.push_back(v2 * (q_ + O * p_));          // t2r(:,:,q,p)
-                    hB.push_back(v3 * r_);                      // vr(:,:,:,r)
-                    hAh.push_back(O * v2 * p_);                 // t2h(:,:,:,p)
-                    hBh.push_back(O * V * (q_ + O * r_));       // or(:,:,q,r)
+                    const int64_t buf = (int64_t)ords.size();
+                    m.xoff[q] = buf * v3;
+                    ords.push_back({P[q][0], P[q][1], P[q][2], buf});
                 }
                 meta.push_back(m);
                 if ((int64_t)meta.size() == nb) flush();
             }
     flush();
     if (t_begin == 0) {
-        hipLaunchKernelGGL(triples_dbase_kernel, dim3(1), dim3(256), 0, cx.stream, cx.scal, in);
+        hipLaunchKernelGGL(triples_dbase_kernel, dim3(256), dim3(256), 0, cx.stream, partial, in, 256);
+        AFESP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, 256);
         AFESP_HIP(hipGetLastError());
     }
     double* h = host_scalars(cx, 4);
@@ -235,8 +357,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     out_host[1] = h[0] + h[1];     // E(T)            ccsd.f90:2220
     out_host[2] = h[2];            // D[T]
     out_host[3] = h[2] + h[3];     // D(T)            ccsd.f90:2232
-    cx.release(Xpool); cx.release(Wpool); cx.release(meta_d); cx.release(boff); cx.release(partial);
-    cx.release(t2r.d); cx.release(t2h.d); cx.release(vr.d); cx.release(orr.d);
+    cx.release(meta_d); cx.release(d_n); cx.release(orb_d); cx.release(d_k); cx.release(d_Am); cx.release(d_Cm);
 }
 
 }  // namespace afesp
