@@ -319,7 +319,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     if (!force_tn) force_tn = g_force_tn;
     if (!force_split) force_split = g_force_split;
     const int tm = force_tm ? force_tm : pick_t(p.M), tn = force_tn ? force_tn : pick_t(p.N);
-    const int BM = tm == 8 ? 128 : 32 * tm, BN = tn == 8 ? 128 : 32 * tn;
+    const int BM = tm == 16 ? 256 : tm == 8 ? 128 : 32 * tm, BN = tn == 16 ? 256 : tn == 8 ? 128 : 32 * tn;
     a.mtiles = (p.M + BM - 1) / BM;
     a.ntiles = (p.N + BN - 1) / BN;
     const int64_t tiles = (int64_t)a.mtiles * a.ntiles * p.nbatch;
@@ -354,7 +354,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     AFESP_CFG(1, 1, 2, 2, 1, 1) AFESP_CFG(1, 2, 2, 2, 1, 2) AFESP_CFG(1, 4, 2, 2, 1, 4)
     AFESP_CFG(2, 1, 2, 2, 2, 1) AFESP_CFG(2, 2, 2, 2, 2, 2) AFESP_CFG(2, 4, 2, 2, 2, 4)
     AFESP_CFG(4, 1, 2, 2, 4, 1) AFESP_CFG(4, 2, 2, 2, 4, 2) AFESP_CFG(4, 4, 2, 4, 4, 2)
-    AFESP_CFG(8, 8, 2, 2, 4, 4)
+    AFESP_CFG(8, 8, 2, 2, 4, 4) AFESP_CFG(16, 8, 4, 2, 4, 4) AFESP_CFG(8, 16, 2, 4, 4, 4)
 #undef AFESP_CFG
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;

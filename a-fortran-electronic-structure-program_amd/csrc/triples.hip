@@ -19,152 +19,11 @@
 #include <cmath>
 
 #include "ccsd.h"
+#include "triples_orbit.h"
 
 namespace afesp {
 
 int64_t triples_count(int o) { return (int64_t)o * (o + 1) * (o + 2) / 6; }
-
-struct TripleMeta {
-    int i, j, k, pad;
-    double mult;
-    int64_t xoff[6];   // element offsets of X^{ijk}, X^{jik}, X^{kji}, X^{ikj}, X^{jki}, X^{kij} in the X pool
-    int64_t woff;
-};
-
-struct TriplesIn {
-    const double* e;
-    const double* t1;
-    const double* voovv_s;   // voovv_s(x,y,p,q) = v_oovv(p,q,x,y): contiguous v x v slice per occupied pair
-    const double* t2_s;      // t2_s(x,y,p,q)    = t2(p,q,x,y)
-    const double* t2;        // natural layout, for the D base term only
-    int o, v;
-};
-
-// The six simultaneous index permutations of ccsd.f90:2168-2173, in the order of the six term pairs:
-// (abc) (bac) (cba) (acb) (bca) (cab); SIG[s][d] = which of (a,b,c) sits in position d.
-__device__ __constant__ int SIG[6][3] = {{0, 1, 2}, {1, 0, 2}, {2, 1, 0}, {0, 2, 1}, {1, 2, 0}, {2, 0, 1}};
-constexpr int TT = 8;                 // cube edge
-constexpr int CUBE = TT * TT * TT;    // 512 elements
-constexpr int PATCH = TT * TT;
-
-// Fused "orbit" kernel.  The virtual index space is cut into 8x8x8 cubes; a workgroup owns the orbit of one cube
-// under the six permutations -- the only set that is closed under every index permutation the formulas use:
-//   W(a,b,c)   = sum_s X_s(sigma_s(a,b,c))                                   ccsd.f90:2168-2173
-//   t_bar      = [4W(abc) + W(bca) + W(cab) - 2W(acb) - 2W(bac) - 2W(cba)] / 3D   (symmetrised form of :2314-2318)
-// Every X element is read from HBM exactly once (coalesced along its own leading index) and W never leaves LDS.
-__global__ __launch_bounds__(256) void triples_orbit_kernel(double* __restrict__ partial, const double* __restrict__ Xpool,
-                                                            const TripleMeta* __restrict__ meta,
-                                                            const int* __restrict__ orbits, TriplesIn in, int nblk_total)
-{
-    __shared__ double stage[6 * CUBE + 512];   // X cubes of one term; later the V / T2 patches and t1 rows
-    __shared__ double wl[6 * CUBE];            // W on the six cubes of the orbit
-    __shared__ int srcq[6][6];                 // srcq[s][q]: which staged cube holds sigma_s applied to cube q
-    __shared__ int dup[6];                     // 1 if cube q repeats an earlier cube of the orbit (degenerate orbit)
-    __shared__ double red[16];
-    const TripleMeta m = meta[blockIdx.y];
-    const int o = in.o, v = in.v, t = threadIdx.x;
-    const int packed = orbits[blockIdx.x];
-    const int tile[3] = {packed & 1023, (packed >> 10) & 1023, (packed >> 20) & 1023};
-    // tile coordinates of cube q: position d holds tile[SIG[q][d]]
-    if (t < 36) {
-        const int s = t / 6, q = t % 6;
-        // sigma_s applied to cube q: position d of the source holds position SIG[s][d] of cube q
-        int want[3];
-        for (int d = 0; d < 3; ++d) want[d] = tile[SIG[q][SIG[s][d]]];
-        int found = 0;
-        for (int r = 5; r >= 0; --r)
-            if (tile[SIG[r][0]] == want[0] && tile[SIG[r][1]] == want[1] && tile[SIG[r][2]] == want[2]) found = r;
-        srcq[s][q] = found;
-        if (s == 0) dup[q] = (found != q);   // sigma_0 is the identity: first cube with the same coordinates
-    }
-    const int64_t vv = (int64_t)v * v;
-    double wreg[12];
-#pragma unroll
-    for (int r = 0; r < 12; ++r) wreg[r] = 0.0;
-    for (int s = 0; s < 6; ++s) {
-        const double* X = Xpool + m.xoff[s];
-        __syncthreads();   // previous term's readers are done with `stage` (also publishes srcq on the first pass)
-#pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            const int el = t + 256 * r, q = el >> 9, loc = el & 511;
-            const int g0 = tile[SIG[q][0]] * TT + (loc & 7), g1 = tile[SIG[q][1]] * TT + ((loc >> 3) & 7),
-                      g2 = tile[SIG[q][2]] * TT + (loc >> 6);
-            const bool ok = g0 < v && g1 < v && g2 < v;
-            stage[el] = ok ? X[g0 + (int64_t)v * g1 + vv * g2] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            const int el = t + 256 * r, q = el >> 9, loc = el & 511;
-            const int l[3] = {loc & 7, (loc >> 3) & 7, loc >> 6};
-            wreg[r] += stage[srcq[s][q] * CUBE + l[SIG[s][0]] + TT * l[SIG[s][1]] + PATCH * l[SIG[s][2]]];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 12; ++r) wl[t + 256 * r] = wreg[r];
-    __syncthreads();
-    // patches: vp[pair][sx][sy][lx + 8 ly] = V_pair(x in tile[sx], y in tile[sy]); pairs (j,k), (i,k), (i,j)
-    double* vp = stage;                  // 3*9*64
-    double* tp = stage + 27 * PATCH;     // 3*9*64
-    double* t1r = stage + 54 * PATCH;    // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l)
-    const int occ[3] = {m.i, m.j, m.k};
-    const int pairp[3] = {m.j, m.i, m.i}, pairq[3] = {m.k, m.k, m.j};
-    for (int el = t; el < 27 * PATCH; el += 256) {
-        const int pr = el / (9 * PATCH), rest = el % (9 * PATCH), sx = rest / (3 * PATCH), sy = (rest / PATCH) % 3, loc = rest % PATCH;
-        const int gx = tile[sx] * TT + (loc & 7), gy = tile[sy] * TT + (loc >> 3);
-        const bool ok = gx < v && gy < v;
-        const int64_t off = gx + (int64_t)v * gy + vv * (pairp[pr] + (int64_t)o * pairq[pr]);
-        vp[el] = ok ? in.voovv_s[off] : 0.0;
-        tp[el] = ok ? in.t2_s[off] : 0.0;
-    }
-    if (t < 72) {
-        const int oc = t / 24, sl = (t / 8) % 3, l = t & 7, g = tile[sl] * TT + l;
-        t1r[t] = g < v ? in.t1[occ[oc] + o * g] : 0.0;
-    }
-    __syncthreads();
-    const double eo = in.e[m.i] + in.e[m.j] + in.e[m.k];
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
-    for (int r = 0; r < 12; ++r) {
-        const int el = t + 256 * r, q = el >> 9, loc = el & 511;
-        if (dup[q]) continue;
-        const int l[3] = {loc & 7, (loc >> 3) & 7, loc >> 6};
-        const int sl[3] = {SIG[q][0], SIG[q][1], SIG[q][2]};   // tile slot of a, b, c
-        const int ga = tile[sl[0]] * TT + l[0], gb = tile[sl[1]] * TT + l[1], gc = tile[sl[2]] * TT + l[2];
-        if (ga >= v || gb >= v || gc >= v) continue;
-        const double D = eo - in.e[ga + o] - in.e[gb + o] - in.e[gc + o];
-        // W at sigma_s(a,b,c): cube srcq[s][q], local coordinates permuted
-#define WAT(s) wl[srcq[s][q] * CUBE + l[SIG[s][0]] + TT * l[SIG[s][1]] + PATCH * l[SIG[s][2]]]
-        const double w = wl[el];
-        const double wb = (4.0 * w + WAT(4) + WAT(5) - 2.0 * (WAT(3) + WAT(1) + WAT(2))) / 3.0;
-        // Z(x,y,z) = t1(i,x) V_jk(y,z) + t1(j,y) V_ik(x,z) + t1(k,z) V_ij(x,y)      ccsd.f90:2178-2179 (numerator)
-#define T1R(oc, d) t1r[(oc) * 24 + sl[d] * 8 + l[d]]
-#define VP(arr, pr, dx, dy) arr[((pr) * 9 + sl[dx] * 3 + sl[dy]) * PATCH + l[dx] + TT * l[dy]]
-#define ZAT(x, y, z) (T1R(0, x) * VP(vp, 0, y, z) + T1R(1, y) * VP(vp, 1, x, z) + T1R(2, z) * VP(vp, 2, x, y))
-        const double zb = (4.0 * ZAT(0, 1, 2) + ZAT(1, 2, 0) + ZAT(2, 0, 1) - 2.0 * (ZAT(0, 2, 1) + ZAT(1, 0, 2) + ZAT(2, 1, 0))) / 3.0;
-        // y (ccsd.f90:2183-2184)
-        const double y = T1R(0, 0) * T1R(1, 1) * T1R(2, 2) + T1R(0, 0) * VP(tp, 0, 1, 2) + T1R(1, 1) * VP(tp, 1, 0, 2) +
-                         T1R(2, 2) * VP(tp, 2, 0, 1);
-        const double tbar = wb / D, zbar = zb / D;
-        acc[0] += tbar * w;
-        acc[1] += zbar * w;
-        acc[2] += tbar * y;
-        acc[3] += zbar * y;
-    }
-    const int lane = t & 63, wv = t >> 6;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        double sdl = acc[q];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sdl += __shfl_down(sdl, off, 64);
-        if (lane == 0) red[q * 4 + wv] = sdl;
-    }
-    __syncthreads();
-    if (t < 4) {
-        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-        partial[(int64_t)t * nblk_total + blk] = m.mult * (red[t * 4] + red[t * 4 + 1] + red[t * 4 + 2] + red[t * 4 + 3]);
-    }
-}
 
 // out[q] += sum_b partial[q][b] in a fixed order
 __global__ __launch_bounds__(256) void triples_sum_kernel(double* out, const double* partial, int nblk)

@@ -1,0 +1,175 @@
+// triples_orbit.h -- device side of the (T) combine: W assembly, bars and the four sums in one pass over the X blocks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace afesp {
+
+struct TripleMeta {
+    int i, j, k, pad;
+    double mult;       // number of distinct ordered permutations of (i,j,k): 6, 3 or 1
+    int64_t xoff[6];   // element offsets of X^{ijk}, X^{jik}, X^{kji}, X^{ikj}, X^{jki}, X^{kij} in the X pool
+    int64_t woff;
+};
+
+struct TriplesIn {
+    const double* e;
+    const double* t1;
+    const double* voovv_s;   // voovv_s(x,y,p,q) = v_oovv(p,q,x,y): contiguous v x v slice per occupied pair
+    const double* t2_s;      // t2_s(x,y,p,q)    = t2(p,q,x,y)
+    const double* t2;        // natural layout, for the D base term only
+    int o, v;
+};
+
+constexpr int TT = 8;                 // cube edge
+constexpr int CUBE = TT * TT * TT;    // 512 elements
+constexpr int PATCH = TT * TT;
+
+// The six simultaneous index permutations of ccsd.f90:2168-2173 in the order of the six term pairs:
+// (abc) (bac) (cba) (acb) (bca) (cab); sig(s,d) = which of (a,b,c) sits in position d of term s.
+__host__ __device__ constexpr int sig(int s, int d)
+{
+    return s == 0 ? d : s == 1 ? (d == 0 ? 1 : d == 1 ? 0 : 2) : s == 2 ? 2 - d : s == 3 ? (d == 0 ? 0 : d == 1 ? 2 : 1)
+                      : s == 4 ? (d + 1) % 3 : (d + 2) % 3;
+}
+// XOR-swizzled cube image: any one coordinate may run along the lanes without bank conflicts
+__device__ __forceinline__ int cidx(int p0, int p1, int p2) { return ((p0 ^ p1 ^ p2) & 7) | (p1 << 3) | (p2 << 6); }
+
+// Fused "orbit" kernel.  The virtual index space is cut into 8x8x8 cubes; a workgroup owns the orbit of one cube
+// under the six permutations -- the smallest set closed under every index permutation the formulas use:
+//   W(a,b,c) = sum_s X_s(sigma_s(a,b,c))                                              ccsd.f90:2168-2173
+//   t_bar    = [4W(abc) + W(bca) + W(cab) - 2W(acb) - 2W(bac) - 2W(cba)] / 3D         symmetrised :2314-2318
+// Every X element is read from HBM exactly once (coalesced along its own leading index) and W never leaves LDS.
+// Thread t owns elements el = t + 256 r (r = 0..11): cube q = r/2 is a compile-time constant after unrolling, so
+// every permuted index below resolves to a fixed register.
+__global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restrict__ partial, const double* __restrict__ Xpool,
+                                                            const TripleMeta* __restrict__ meta,
+                                                            const int* __restrict__ orbits, TriplesIn in, int nblk_total)
+{
+    __shared__ double stage[6 * CUBE + 512];   // X cubes of one term; later the V / T2 patches and t1 rows
+    __shared__ double wl[6 * CUBE];            // W on the six cubes of the orbit
+    __shared__ int srcq[6][6];                 // srcq[s][q]: which cube of the orbit is sigma_s applied to cube q
+    __shared__ int dup[6];                     // 1 if cube q repeats an earlier cube (degenerate orbit)
+    __shared__ double red[16];
+    const TripleMeta m = meta[blockIdx.y];
+    const int o = in.o, v = in.v, t = threadIdx.x;
+    const int packed = orbits[blockIdx.x];
+    const int tile[3] = {packed & 1023, (packed >> 10) & 1023, (packed >> 20) & 1023};
+    if (t < 36) {
+        const int s = t / 6, q = t % 6;
+        int want[3];
+        for (int d = 0; d < 3; ++d) want[d] = tile[sig(q, sig(s, d))];   // position d of the source cube
+        int found = 0;
+        for (int r = 5; r >= 0; --r)
+            if (tile[sig(r, 0)] == want[0] && tile[sig(r, 1)] == want[1] && tile[sig(r, 2)] == want[2]) found = r;
+        srcq[s][q] = found;
+        if (s == 0) dup[q] = (found != q);
+    }
+    const int64_t vv = (int64_t)v * v;
+    // local coordinates of this thread's two elements per cube (half = 0, 1)
+    const int l0 = t & 7, l1 = (t >> 3) & 7, l2h[2] = {t >> 6, (t >> 6) + 4};
+    double wreg[12];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) wreg[r] = 0.0;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const double* X = Xpool + m.xoff[s];
+        double xin[12];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const int q = r >> 1, l2 = l2h[r & 1];
+            const int g0 = tile[sig(q, 0)] * TT + l0, g1 = tile[sig(q, 1)] * TT + l1, g2 = tile[sig(q, 2)] * TT + l2;
+            const bool ok = g0 < v && g1 < v && g2 < v;
+            const double x = X[ok ? g0 + (int64_t)v * g1 + vv * g2 : 0];
+            xin[r] = ok ? x : 0.0;
+        }
+        __syncthreads();   // the previous term's readers are done with `stage` (also publishes srcq on the first pass)
+#pragma unroll
+        for (int r = 0; r < 12; ++r) stage[(r >> 1) * CUBE + cidx(l0, l1, l2h[r & 1])] = xin[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            const int q = r >> 1;
+            const int l[3] = {l0, l1, l2h[r & 1]};
+            wreg[r] += stage[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 12; ++r) wl[(r >> 1) * CUBE + cidx(l0, l1, l2h[r & 1])] = wreg[r];
+    __syncthreads();
+    // patches: vp[pair][sx][sy][lx + 8 ly] = V_pair(x in tile[sx], y in tile[sy]); pairs (j,k), (i,k), (i,j)
+    double* vp = stage;                  // 3*9*64
+    double* tp = stage + 27 * PATCH;     // 3*9*64
+    double* t1r = stage + 54 * PATCH;    // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l)
+    const int occ[3] = {m.i, m.j, m.k};
+    const int pairp[3] = {m.j, m.i, m.i}, pairq[3] = {m.k, m.k, m.j};
+    for (int el = t; el < 27 * PATCH; el += 256) {
+        const int pr = el / (9 * PATCH), rest = el % (9 * PATCH), sx = rest / (3 * PATCH), sy = (rest / PATCH) % 3, loc = rest % PATCH;
+        const int gx = tile[sx] * TT + (loc & 7), gy = tile[sy] * TT + (loc >> 3);
+        const bool ok = gx < v && gy < v;
+        const int64_t off = ok ? gx + (int64_t)v * gy + vv * (pairp[pr] + (int64_t)o * pairq[pr]) : 0;
+        const double a = in.voovv_s[off], b = in.t2_s[off];
+        vp[el] = ok ? a : 0.0;
+        tp[el] = ok ? b : 0.0;
+    }
+    if (t < 72) {
+        const int oc = t / 24, sl = (t / 8) % 3, l = t & 7, g = tile[sl] * TT + l;
+        t1r[t] = g < v ? in.t1[occ[oc] + o * g] : 0.0;
+    }
+    __syncthreads();
+    const double eo = in.e[m.i] + in.e[m.j] + in.e[m.k];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // q stays a run-time (wave-uniform) loop counter here: fully unrolled, the scheduler hoists every LDS read of all
+    // twelve elements and spills; the permutation of cube q then only enters through scalar address arithmetic.
+#pragma unroll 1
+    for (int q = 0; q < 6; ++q) {
+        if (dup[q]) continue;
+        const int sa = sig(q, 0), sb = sig(q, 1), sc = sig(q, 2);   // tile slot of a, b, c in cube q
+        const int ta = sa == 0 ? tile[0] : sa == 1 ? tile[1] : tile[2];
+        const int tb = sb == 0 ? tile[0] : sb == 1 ? tile[1] : tile[2];
+        const int tc = sc == 0 ? tile[0] : sc == 1 ? tile[1] : tile[2];
+        const int slot[3] = {sa, sb, sc};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int l[3] = {l0, l1, l2h[h]};
+            const int ga = ta * TT + l[0], gb = tb * TT + l[1], gc = tc * TT + l[2];
+            const bool live = ga < v && gb < v && gc < v;
+            const double D = eo - in.e[(ga < v ? ga : 0) + o] - in.e[(gb < v ? gb : 0) + o] - in.e[(gc < v ? gc : 0) + o];
+#define WAT(s) wl[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])]
+            const double w = wl[q * CUBE + cidx(l[0], l[1], l[2])];
+            const double wb = (4.0 * w + WAT(4) + WAT(5) - 2.0 * (WAT(3) + WAT(1) + WAT(2))) / 3.0;
+            // Z(x,y,z) = t1(i,x) V_jk(y,z) + t1(j,y) V_ik(x,z) + t1(k,z) V_ij(x,y)      ccsd.f90:2178-2179 (numerator)
+#define T1R(oc, d) t1r[(oc) * 24 + slot[d] * 8 + l[d]]
+#define VP(arr, pr, dx, dy) arr[((pr) * 9 + slot[dx] * 3 + slot[dy]) * PATCH + l[dx] + TT * l[dy]]
+#define ZAT(x, y, z) (T1R(0, x) * VP(vp, 0, y, z) + T1R(1, y) * VP(vp, 1, x, z) + T1R(2, z) * VP(vp, 2, x, y))
+            const double zb = (4.0 * ZAT(0, 1, 2) + ZAT(1, 2, 0) + ZAT(2, 0, 1) - 2.0 * (ZAT(0, 2, 1) + ZAT(1, 0, 2) + ZAT(2, 1, 0))) / 3.0;
+            // y (ccsd.f90:2183-2184)
+            const double y = T1R(0, 0) * T1R(1, 1) * T1R(2, 2) + T1R(0, 0) * VP(tp, 0, 1, 2) + T1R(1, 1) * VP(tp, 1, 0, 2) +
+                             T1R(2, 2) * VP(tp, 2, 0, 1);
+            const double tbar = live ? wb / D : 0.0, zbar = live ? zb / D : 0.0;
+            acc[0] += tbar * w;
+            acc[1] += zbar * w;
+            acc[2] += tbar * y;
+            acc[3] += zbar * y;
+#undef WAT
+#undef T1R
+#undef VP
+#undef ZAT
+        }
+    }
+    const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double sdl = acc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sdl += __shfl_down(sdl, off, 64);
+        if (lane == 0) red[q * 4 + wv] = sdl;
+    }
+    __syncthreads();
+    if (t < 4) {
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        partial[(int64_t)t * nblk_total + blk] = m.mult * (red[t * 4] + red[t * 4 + 1] + red[t * 4 + 2] + red[t * 4 + 3]);
+    }
+}
+
+}  // namespace afesp

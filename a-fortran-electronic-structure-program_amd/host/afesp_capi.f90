@@ -1,0 +1,126 @@
+!> ISO_C_BINDING view of include/afesp.h -- the thin C-ABI between the Fortran host and the HIP engine.
+!> Every routine returns a status (0 = ok); the host maps non-zero to its error() (reference: src/error_handling.f90:7-20).
+module afesp_capi
+   use, intrinsic :: iso_c_binding
+   implicit none
+   private
+   public :: afesp_ctx_create, afesp_ctx_destroy, afesp_last_error, afesp_ao2mo_mp2, afesp_ccsd_init, afesp_ccsd_energy, &
+             afesp_ccsd_iterate, afesp_ccsd_diis, afesp_ccsd_get_amplitudes, afesp_ccsd_t, afesp_ccsd_t_ntriples, &
+             afesp_neri, afesp_error_text
+
+   interface
+      function afesp_ctx_create(device, ctx) bind(C, name='afesp_ctx_create') result(rc)
+         import :: c_int, c_ptr
+         integer(c_int), value :: device
+         type(c_ptr), intent(out) :: ctx
+         integer(c_int) :: rc
+      end function
+      subroutine afesp_ctx_destroy(ctx) bind(C, name='afesp_ctx_destroy')
+         import :: c_ptr
+         type(c_ptr), value :: ctx
+      end subroutine
+      function afesp_last_error(ctx) bind(C, name='afesp_last_error') result(msg)
+         import :: c_ptr
+         type(c_ptr), value :: ctx
+         type(c_ptr) :: msg
+      end function
+      function afesp_neri(nbasis) bind(C, name='afesp_neri') result(n)
+         import :: c_int64_t
+         integer(c_int64_t), value :: nbasis
+         integer(c_int64_t) :: n
+      end function
+      !> replaces `call do_mp2_spatial(sys, int_store)` (reference src/main.F90:98)
+      function afesp_ao2mo_mp2(ctx, nbasis, nocc, canon_coeff, canon_levels, eri_packed, eri_mo_packed, e_mp2) &
+         bind(C, name='afesp_ao2mo_mp2') result(rc)
+         import :: c_int, c_int64_t, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int64_t), value :: nbasis, nocc
+         real(c_double), intent(in) :: canon_coeff(*), canon_levels(*), eri_packed(*)
+         type(c_ptr), value :: eri_mo_packed          ! c_null_ptr keeps the MO integrals on the device only
+         real(c_double), intent(out) :: e_mp2
+         integer(c_int) :: rc
+      end function
+      !> replaces init_cc + init_diis_cc_t (reference src/ccsd.f90:313-316)
+      function afesp_ccsd_init(ctx, nocc, nvirt, eri_mo_packed, canon_levels, diis_n_errmat) &
+         bind(C, name='afesp_ccsd_init') result(rc)
+         import :: c_int, c_int64_t, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int64_t), value :: nocc, nvirt
+         type(c_ptr), value :: eri_mo_packed
+         real(c_double), intent(in) :: canon_levels(*)
+         integer(c_int), value :: diis_n_errmat
+         integer(c_int) :: rc
+      end function
+      !> update_cc_energy on the current amplitudes (reference src/ccsd.f90:325)
+      function afesp_ccsd_energy(ctx, e_tol, t_tol, energy, rms_sq, converged) bind(C, name='afesp_ccsd_energy') result(rc)
+         import :: c_int, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         real(c_double), value :: e_tol, t_tol
+         real(c_double), intent(out) :: energy, rms_sq
+         integer(c_int), intent(out) :: converged
+         integer(c_int) :: rc
+      end function
+      !> one pass of the loop body (reference src/ccsd.f90:340-360)
+      function afesp_ccsd_iterate(ctx, e_tol, t_tol, energy, rms_sq, converged) bind(C, name='afesp_ccsd_iterate') result(rc)
+         import :: c_int, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         real(c_double), value :: e_tol, t_tol
+         real(c_double), intent(out) :: energy, rms_sq
+         integer(c_int), intent(out) :: converged
+         integer(c_int) :: rc
+      end function
+      !> update_diis_cc (reference src/ccsd.f90:395)
+      function afesp_ccsd_diis(ctx) bind(C, name='afesp_ccsd_diis') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int) :: rc
+      end function
+      function afesp_ccsd_get_amplitudes(ctx, t1, t2) bind(C, name='afesp_ccsd_get_amplitudes') result(rc)
+         import :: c_int, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         real(c_double), intent(out) :: t1(*), t2(*)
+         integer(c_int) :: rc
+      end function
+      function afesp_ccsd_t_ntriples(nocc) bind(C, name='afesp_ccsd_t_ntriples') result(n)
+         import :: c_int64_t
+         integer(c_int64_t), value :: nocc
+         integer(c_int64_t) :: n
+      end function
+      !> replaces `call do_ccsd_t_spatial(...)` (reference src/main.F90:112); out = E[T], E(T), D[T], D(T)
+      function afesp_ccsd_t(ctx, t_begin, t_end, out) bind(C, name='afesp_ccsd_t') result(rc)
+         import :: c_int, c_int64_t, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int64_t), value :: t_begin, t_end
+         real(c_double), intent(out) :: out(4)
+         integer(c_int) :: rc
+      end function
+   end interface
+
+contains
+
+   !> Copy the engine's last error message into a Fortran string.
+   function afesp_error_text(ctx) result(text)
+      type(c_ptr), intent(in) :: ctx
+      character(len=:), allocatable :: text
+      type(c_ptr) :: p
+      character(kind=c_char), pointer :: chars(:)
+      integer :: n
+      p = afesp_last_error(ctx)
+      text = ''
+      if (.not. c_associated(p)) return
+      call c_f_pointer(p, chars, [4096])
+      n = 0
+      do while (n < 4096)
+         if (chars(n + 1) == c_null_char) exit
+         n = n + 1
+      end do
+      allocate (character(len=n) :: text)
+      block
+         integer :: i
+         do i = 1, n
+            text(i:i) = chars(i)
+         end do
+      end block
+   end function
+
+end module afesp_capi

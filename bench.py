@@ -153,13 +153,14 @@ def main():
         torch.cuda.set_device(local)
 
     from afesp_amd.capi import Engine
+    from afesp_amd.dist import shard_range
     o, v = WORKLOADS[args.workload]
     seed = 12345
     eng = Engine(local)
     eng.synthetic_init(o, v, args.scale, seed, 8)
     eng.ccsd_energy()                                   # the "MP1" line: primes t2_old
     nt = eng.ntriples()
-    lo, hi = rank * nt // world, (rank + 1) * nt // world   # contiguous shard of the i<=j<=k list
+    lo, hi = shard_range(nt, rank, world)                   # contiguous shard of the i<=j<=k list
     red = torch.zeros(4, dtype=torch.float64, device=f"cuda:{local}")
 
     def barrier():

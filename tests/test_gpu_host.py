@@ -1,0 +1,63 @@
+"""The Fortran host (els_amd: els.in in, reference-format stdout out) driving the HIP engine through ISO_C_BINDING."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import molecules
+from afesp_amd import inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "a-fortran-electronic-structure-program_amd", "host", "els_amd")
+
+
+def run_host(tmp_path, name, calc_type, env_extra=None):
+    src = os.path.join(molecules.GOLDEN, name)
+    for f in ("s.dat", "t.dat", "v.dat", "eri.dat", "geom.dat", "guess_in.dat"):
+        if os.path.exists(os.path.join(src, f)):
+            shutil.copy(os.path.join(src, f), tmp_path)
+    text = open(os.path.join(src, "els.in")).read().replace("CRCCSD(T)_spatial", calc_type)
+    (tmp_path / "els.in").write_text(text)
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    res = subprocess.run([EXE], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    (tmp_path / "els.out").write_text(res.stdout)
+    return res, inputs.parse_els_out(str(tmp_path / "els.out"))
+
+
+@pytest.mark.parametrize("name", ["n2-cc-pvdz", "f2-cc-pvdz", "h2o-cc-pvdz"])
+def test_host_rccsd_t_matches_reference_output(tmp_path, name):
+    if not os.path.exists(EXE):
+        pytest.fail("els_amd is not built (python __graft_entry__.py build)")
+    res, got = run_host(tmp_path, name, "RCCSD(T)_spatial")
+    assert res.returncode == 0, res.stderr
+    g = molecules.SURVEY_GOLD[name]
+    # the reference prints F15.10; north_star tolerance for correlation energies is 1e-8 Eh
+    assert abs(got["rhf_total"] - g["rhf_total"]) < 2e-9
+    for key in ("mp2_corr", "ccsd_corr", "ccsd_bt_corr", "ccsd_pt_corr", "r_ccsd_pt_corr", "d_bt", "d_pt", "t1_diag"):
+        assert abs(got[key] - g[key]) < 1e-8, (key, got[key], g[key])
+    gold = inputs.parse_els_out(os.path.join(molecules.GOLDEN, name, "els.out")) if name != "h2o-cc-pvdz" else None
+    if gold:
+        assert [r[0] for r in got["cc_iters"]] == [r[0] for r in gold["cc_iters"]]
+        for a, b in zip(got["cc_iters"], gold["cc_iters"]):
+            assert abs(a[1] - b[1]) < 2e-11 and abs(a[3] - b[3]) < 2e-11     # printed with 12 decimals
+        assert abs(got["total"] - (gold["rhf_total"] + gold["r_ccsd_pt_corr"])) < 2e-8
+
+
+def test_host_plain_ccsd_t_compat_printout(tmp_path):
+    """Plain CCSD(T)_spatial: default prints the correct (T); AFESP_T_COMPAT=1 reproduces the reference's printout,
+    whose CCSD(T) line equals CCSD[T] (src/ccsd.f90:2211-2215)."""
+    g = molecules.SURVEY_GOLD["h2o-cc-pvdz"]
+    res, got = run_host(tmp_path, "h2o-cc-pvdz", "CCSD(T)_spatial")
+    assert res.returncode == 0, res.stderr
+    assert abs(got["ccsd_pt_corr"] - g["ccsd_pt_corr"]) < 1e-8 and abs(got["ccsd_bt_corr"] - g["ccsd_bt_corr"]) < 1e-8
+    res, got = run_host(tmp_path, "h2o-cc-pvdz", "CCSD(T)_spatial", {"AFESP_T_COMPAT": "1"})
+    assert res.returncode == 0, res.stderr
+    assert abs(got["ccsd_pt_corr"] - g["ccsd_bt_corr"]) < 1e-8
+
+
+def test_host_rejects_unknown_calc_type(tmp_path):
+    res, _ = run_host(tmp_path, "h2o-cc-pvdz", "CCSDT_spatial")
+    assert res.returncode != 0 and "Unrecognised calculation type" in res.stderr

@@ -1,0 +1,72 @@
+"""CPU-side checks: C-ABI exports, header/library agreement, input parsing, the Fortran host's RHF."""
+import os
+import re
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import molecules
+from afesp_amd import capi, inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = capi.load_library()
+    header = open(os.path.join(ROOT, "include", "afesp.h")).read()
+    declared = set(re.findall(r"\b(afesp_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(capi.EXPORTS) <= declared
+    assert lib.afesp_neri(28) == 82621
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.AfespError):
+        capi.Engine(0)
+
+
+def test_namelist_defaults_and_calc_types(tmp_path):
+    p = tmp_path / "els.in"
+    p.write_text('&elsinput\ncalc_type="RCCSD[T]_spatial",\nccsd_maxiter = 7\n/\n')
+    si = inputs.read_els_in(str(p))
+    assert si.ccsd_maxiter == 7 and si.scf_read_guess is False and si.ccsd_diis_n_errmat == 8
+    assert si.ccsd_t_renorm and not si.ccsd_t_paren and si.level == "CCSD(T)"
+    p.write_text('&elsinput\ncalc_type="nonsense"\n/\n')
+    with pytest.raises(ValueError):
+        inputs.read_els_in(str(p))
+
+
+def test_packed_reader_matches_eri_index_rule():
+    si, ints, res, gold = molecules.load("h2o-cc-pvdz")
+    n = ints.nbasis
+    assert ints.eri.size == inputs.neri(n)
+    # first data line of eri.dat is (1 1|1 1)
+    first = float(open(os.path.join(molecules.GOLDEN, "h2o-cc-pvdz", "eri.dat")).readline().split()[4])
+    assert ints.eri[0] == first
+    assert inputs.eri_index(3, 1, 2, 0) == inputs.eri_index(0, 2, 1, 3)
+
+
+def test_fortran_host_rhf_on_cpu(tmp_path):
+    exe = os.path.join(ROOT, "a-fortran-electronic-structure-program_amd", "host", "els_amd")
+    if not os.path.exists(exe):
+        pytest.skip("els_amd not built")
+    src = os.path.join(molecules.GOLDEN, "f2-cc-pvdz")
+    for f in ("s.dat", "t.dat", "v.dat", "eri.dat", "geom.dat"):
+        shutil.copy(os.path.join(src, f), tmp_path)
+    (tmp_path / "els.in").write_text(open(os.path.join(src, "els.in")).read().replace("CRCCSD(T)_spatial", "RHF"))
+    res = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    (tmp_path / "o").write_text(res.stdout)
+    got = inputs.parse_els_out(str(tmp_path / "o"))
+    gold = inputs.parse_els_out(os.path.join(src, "els.out"))
+    assert abs(got["rhf_total"] - gold["rhf_total"]) < 2e-9
+    assert len(got["scf_iters"]) == len(gold["scf_iters"])
+    for a, b in zip(got["scf_iters"], gold["scf_iters"]):
+        assert abs(a[1] - b[1]) < 5e-9

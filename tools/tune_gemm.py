@@ -15,7 +15,7 @@ shapes = {
 which = sys.argv[1:] or list(shapes)
 for name in which:
     la, dA, lb, dB, lc, dC, fl = shapes[name]
-    for (gm, tm, tn) in [(0,4,4), (0,8,8), (0,4,2), (0,2,4), (0,2,2)]:
+    for (gm, tm, tn) in [(0,4,4), (0,16,8), (0,8,16)]:
         eng.set_tuning(gm, tm, tn, 0)
         ms = eng.bench_contract(la, dA, lb, dB, lc, dC, reps=3)
         print(f"{name:12s} gm={gm:2d} tm={tm} tn={tn}: {ms:9.3f} ms  {fl/ms/1e9:7.2f} TF", flush=True)
