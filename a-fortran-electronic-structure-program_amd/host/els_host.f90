@@ -16,7 +16,7 @@ contains
       write (err, '(1X, A)') 'Programme stops in procedure: '//trim(where)//'.'
       write (err, '(1X, A)') 'Reason: '//trim(why)//'.'
       write (err, '(1X, A)') 'EXITING...'
-      stop '999'
+      error stop '999'   ! the reference uses a plain STOP (exit status 0); a failing run should fail its caller
    end subroutine
    function seconds() result(t)
       real(dp) :: t
