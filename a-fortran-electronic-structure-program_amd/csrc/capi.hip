@@ -90,6 +90,7 @@ void afesp_ctx_destroy(afesp_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cx.device);
+    triples_plan_free(ctx->cc);
     delete ctx;
 }
 

@@ -21,7 +21,9 @@ struct CCState {
     double *coef = nullptr;     // device coefficients
     std::vector<double> B;      // host copy of the error overlap matrix (nerr x nerr, full)
     double energy = 0.0, energy_old = 0.0, rms = 0.0;
+    void* tplan = nullptr;      // cached (T) launch plan (triples.hip)
 };
+void triples_plan_free(CCState& s);
 
 // eri_mo_dev: packed chemist MO integrals ON DEVICE (length neri(o+v)); e_host: orbital energies (host)
 void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, const double* e_host, int diis_nerr);

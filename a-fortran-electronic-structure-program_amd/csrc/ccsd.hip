@@ -75,6 +75,7 @@ void ccsd_free(Context& cx, CCState& s)
                       s.hist_e, s.coef};
     for (double* b : bufs) cx.release(b);
     cx.drop_scratch();
+    triples_plan_free(s);
     s = CCState();
 }
 

@@ -67,85 +67,59 @@ __global__ __launch_bounds__(256) void triples_dbase_kernel(double* partial, Tri
     }
 }
 
-void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host)
+// Everything about a (T) evaluation that depends only on (o, v, triple range): chunking, per-chunk GEMM column tables,
+// per-triple metadata, the cube-orbit list.  Built once, kept in device memory, reused by every later call.
+struct TriplesPlan {
+    int o = 0, v = 0;
+    int64_t t_begin = -1, t_end = -1, nb = 0;
+    int norb = 0;
+    struct Group { int r; int64_t start, N; };
+    struct Chunk { int nt; int64_t meta_off, tab_off, ntab; std::vector<Group> groups; };
+    std::vector<Chunk> chunks;
+    int64_t* tables = nullptr;     // [kappa | Am | Cm | per chunk: offBn, offCn]
+    int64_t off_k = 0, off_Am = 0, off_Cm = 0;
+    TripleMeta* meta = nullptr;
+    int* orbits = nullptr;
+};
+
+static TriplesPlan* plan_for(Context& cx, CCState& s, int64_t t_begin, int64_t t_end)
 {
-    if (!s.ready) throw Error(1, "ccsd_triples: no converged CCSD state in this context");
+    TriplesPlan* p = (TriplesPlan*)s.tplan;
+    if (p && p->o == s.o && p->v == s.v && p->t_begin == t_begin && p->t_end == t_end) return p;
+    delete p;
+    p = new TriplesPlan();
+    s.tplan = p;
     const int o = s.o, v = s.v;
-    const int64_t O = o, V = v, v2 = V * V, v3 = V * V * V;
-    const int64_t ntot = triples_count(o);
-    t_begin = std::max<int64_t>(0, t_begin);
-    t_end = std::min<int64_t>(ntot, t_end);
-    // concatenated operands, summed index kappa = [d ; l] first (the reference also moves the summed index first, :2056-2066)
-    //   vt(kappa,b,c,k): kappa<v: <cb|kd> = v_vvov(c,b,k,d);  kappa=v+l: t2(l,k,b,c)
-    //   tt(kappa,a,j,i): kappa<v: t2(i,j,a,d);                kappa=v+l: -<ij|al> = -v_oovo(i,j,a,l)
-    const int64_t Kc = V + O;
-    Tensor vt = view(cx.scratch("t_vt", Kc * v2 * O), {Kc, V, V, O}), tt = view(cx.scratch("t_tt", Kc * V * O * O), {Kc, V, O, O});
-    auto sub = [&](const Tensor& full, int64_t row0, int64_t nrows) {
-        Tensor t = full;
-        t.d = full.d + row0;
-        t.dim[0] = nrows;
-        return t;
-    };
-    permute_add(cx, 1.0, s.v_vvov, "cbkd", 0.0, sub(vt, 0, V), "dbck");
-    permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vt, V, O), "lbck");
-    permute_add(cx, 1.0, s.t2, "ijad", 0.0, sub(tt, 0, V), "daji");
-    permute_add(cx, -1.0, s.v_oovo, "ijal", 0.0, sub(tt, V, O), "laji");
-    Tensor vs = view(cx.scratch("t_vs", v2 * O * O), {V, V, O, O});    // vs(x,y,p,q)  = v_oovv(p,q,x,y)
-    Tensor ts = view(cx.scratch("t_ts", v2 * O * O), {V, V, O, O});    // ts(x,y,p,q)  = t2(p,q,x,y)
-    permute_add(cx, 1.0, s.v_oovv, "pqxy", 0.0, vs, "xypq");
-    permute_add(cx, 1.0, s.t2, "pqxy", 0.0, ts, "xypq");
-    // offset tables shared by every launch: kappa, and the (b,c) rows of vt / X
-    std::vector<int64_t> hk((size_t)Kc), hAm((size_t)v2), hCm((size_t)v2);
-    for (int64_t x = 0; x < Kc; ++x) hk[(size_t)x] = x;
-    for (int64_t c = 0; c < V; ++c)
-        for (int64_t b = 0; b < V; ++b) {
-            hAm[(size_t)(b + V * c)] = Kc * (b + V * c);
-            hCm[(size_t)(b + V * c)] = V * b + v2 * c;
-        }
-    int64_t* d_k = cx.alloc_i64(Kc);
-    int64_t* d_Am = cx.alloc_i64(v2);
-    int64_t* d_Cm = cx.alloc_i64(v2);
-    AFESP_HIP(hipMemcpyAsync(d_k, hk.data(), sizeof(int64_t) * Kc, hipMemcpyHostToDevice, cx.stream));
-    AFESP_HIP(hipMemcpyAsync(d_Am, hAm.data(), sizeof(int64_t) * v2, hipMemcpyHostToDevice, cx.stream));
-    AFESP_HIP(hipMemcpyAsync(d_Cm, hCm.data(), sizeof(int64_t) * v2, hipMemcpyHostToDevice, cx.stream));
-    cx.sync();
-    k_fill(cx, cx.scal, 4, 0.0);
-    TriplesIn in{s.e, s.t1.d, vs.d, ts.d, s.t2.d, o, v};
-
-    // orbits of 8x8x8 cubes under index permutation: tile triples A <= B <= C
-    const int nt8 = (v + TT - 1) / TT;
-    std::vector<int> orb;
-    for (int A = 0; A < nt8; ++A)
-        for (int B = A; B < nt8; ++B)
-            for (int C = B; C < nt8; ++C) orb.push_back(A | (B << 10) | (C << 20));
-    const int norb = (int)orb.size();
-    int* orb_d = (int*)cx.alloc((int64_t)(norb + 1) / 2 + 1);
-    AFESP_HIP(hipMemcpyAsync(orb_d, orb.data(), sizeof(int) * norb, hipMemcpyHostToDevice, cx.stream));
-
-    // chunk size from a memory budget: 6 X blocks of v^3 doubles per triple (W never leaves LDS)
+    const int64_t O = o, V = v, v2 = V * V, v3 = v2 * V, Kc = V + O;
+    p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end;
+    // chunk size: 6 X blocks of v^3 doubles per triple (W never leaves LDS); a few dozen ordered triples per k-group keep
+    // the GEMM column count in the thousands, more buys nothing
     const int64_t per = 6 * v3 * (int64_t)sizeof(double);
-    // ~48 ordered triples per k-group keep the GEMM column count in the thousands; more buys nothing
-    int64_t budget = (int64_t)24 << 30;
-    int64_t nb = std::max<int64_t>(1, budget / per);
+    int64_t nb = std::max<int64_t>(1, ((int64_t)24 << 30) / per);
     nb = std::min<int64_t>(nb, 4096);
     nb = std::min<int64_t>(nb, std::max<int64_t>(1, t_end - t_begin));
-    double* Xpool = cx.scratch("t_xpool", 6 * nb * v3);
-    TripleMeta* meta_d = (TripleMeta*)cx.alloc((int64_t)(nb * sizeof(TripleMeta) / sizeof(double) + 1));
-    int64_t* d_n = cx.alloc_i64(2 * 6 * nb * V);   // per chunk: column tables offBn | offCn of every k-group
-    const int64_t npart = std::max<int64_t>((int64_t)norb * nb, 512);
-    double* partial = cx.scratch("t_partial", 4 * npart);
-
-    // enumerate i<=j<=k in a fixed order and walk the requested range chunk by chunk
-    std::vector<TripleMeta> meta;
+    p->nb = nb;
+    std::vector<int64_t> tab;
+    p->off_k = 0;
+    for (int64_t x = 0; x < Kc; ++x) tab.push_back(x);
+    p->off_Am = (int64_t)tab.size();
+    for (int64_t c = 0; c < V; ++c)
+        for (int64_t b = 0; b < V; ++b) tab.push_back(Kc * (b + V * c));      // rows (b,c) of vt(:,b,c,k)
+    p->off_Cm = (int64_t)tab.size();
+    for (int64_t c = 0; c < V; ++c)
+        for (int64_t b = 0; b < V; ++b) tab.push_back(V * b + v2 * c);        // rows (b,c) of X(a,b,c)
+    std::vector<TripleMeta> metas;
     struct Ord { int p, q, r; int64_t buf; };
-    std::vector<Ord> ords;   // distinct ordered triples of the chunk, buf = index of its v^3 block in Xpool
-    int64_t flat = 0;
+    std::vector<Ord> ords;
+    std::vector<TripleMeta> cur;
     auto flush = [&]() {
-        if (meta.empty()) return;
-        const int nt = (int)meta.size();
-        // group the ordered triples by their last index r (= the occupied index carried by vt)
+        if (cur.empty()) return;
+        TriplesPlan::Chunk ch;
+        ch.nt = (int)cur.size();
+        ch.meta_off = (int64_t)metas.size();
+        metas.insert(metas.end(), cur.begin(), cur.end());
+        // group the chunk's ordered triples by their last index r (the occupied index carried by vt)
         std::vector<int64_t> hBn, hCn;
-        std::vector<std::pair<int, std::pair<int64_t, int64_t>>> groups;   // r, (table start, N)
         for (int r = 0; r < o; ++r) {
             const int64_t start = (int64_t)hBn.size();
             for (const Ord& od : ords)
@@ -155,34 +129,16 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
                         hCn.push_back(a + v3 * od.buf);
                     }
             const int64_t N = (int64_t)hBn.size() - start;
-            if (N > 0) groups.push_back({r, {start, N}});
+            if (N > 0) ch.groups.push_back({r, start, N});
         }
-        const int64_t ntab = (int64_t)hBn.size();
-        AFESP_HIP(hipMemcpyAsync(d_n, hBn.data(), sizeof(int64_t) * ntab, hipMemcpyHostToDevice, cx.stream));
-        AFESP_HIP(hipMemcpyAsync(d_n + ntab, hCn.data(), sizeof(int64_t) * ntab, hipMemcpyHostToDevice, cx.stream));
-        AFESP_HIP(hipMemcpyAsync(meta_d, meta.data(), meta.size() * sizeof(TripleMeta), hipMemcpyHostToDevice, cx.stream));
-        cx.sync();
-        for (auto& g : groups) {
-            GettProblem gp;
-            gp.A = vt.d + Kc * v2 * g.first;   // vt(:,:,:,r)
-            gp.B = tt.d;
-            gp.C = Xpool;
-            gp.offAm = d_Am; gp.offAk = d_k; gp.offBk = d_k; gp.offBn = d_n + g.second.first;
-            gp.offCm = d_Cm; gp.offCn = d_n + ntab + g.second.first;
-            gp.M = (int)v2; gp.N = (int)g.second.second; gp.K = (int)Kc;
-            gp.alpha = 1.0; gp.beta = 0.0;
-            gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
-            gp.a_kcontig = gp.b_kcontig = true;
-            AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
-        }
-        hipLaunchKernelGGL(triples_orbit_kernel, dim3(norb, nt), dim3(256), 0, cx.stream, partial, Xpool, meta_d, orb_d, in,
-                           norb * nt);
-        AFESP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, norb * nt);
-        AFESP_HIP(hipGetLastError());
-        cx.sync();
-        meta.clear(); ords.clear();
+        ch.ntab = (int64_t)hBn.size();
+        ch.tab_off = (int64_t)tab.size();
+        tab.insert(tab.end(), hBn.begin(), hBn.end());
+        tab.insert(tab.end(), hCn.begin(), hCn.end());
+        p->chunks.push_back(std::move(ch));
+        cur.clear(); ords.clear();
     };
+    int64_t flat = 0;
     for (int i = 0; i < o && flat < t_end; ++i)
         for (int j = i; j < o && flat < t_end; ++j)
             for (int k = j; k < o && flat < t_end; ++k, ++flat) {
@@ -201,10 +157,87 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
                     m.xoff[q] = buf * v3;
                     ords.push_back({P[q][0], P[q][1], P[q][2], buf});
                 }
-                meta.push_back(m);
-                if ((int64_t)meta.size() == nb) flush();
+                cur.push_back(m);
+                if ((int64_t)cur.size() == nb) flush();
             }
     flush();
+    // orbits of 8x8x8 cubes under index permutation: tile triples A <= B <= C
+    const int nt8 = (v + TT - 1) / TT;
+    std::vector<int> orb;
+    for (int A = 0; A < nt8; ++A)
+        for (int B = A; B < nt8; ++B)
+            for (int C = B; C < nt8; ++C) orb.push_back(A | (B << 10) | (C << 20));
+    p->norb = (int)orb.size();
+    p->tables = (int64_t*)cx.scratch("t_tables", (int64_t)tab.size());
+    p->meta = (TripleMeta*)cx.scratch("t_meta", (int64_t)(metas.size() * sizeof(TripleMeta) / sizeof(double) + 1));
+    p->orbits = (int*)cx.scratch("t_orbits", (int64_t)orb.size() / 2 + 1);
+    AFESP_HIP(hipMemcpyAsync(p->tables, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
+    AFESP_HIP(hipMemcpyAsync(p->meta, metas.data(), metas.size() * sizeof(TripleMeta), hipMemcpyHostToDevice, cx.stream));
+    AFESP_HIP(hipMemcpyAsync(p->orbits, orb.data(), orb.size() * sizeof(int), hipMemcpyHostToDevice, cx.stream));
+    cx.sync();   // the host vectors die here
+    return p;
+}
+
+void triples_plan_free(CCState& s)
+{
+    delete (TriplesPlan*)s.tplan;
+    s.tplan = nullptr;
+}
+
+void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host)
+{
+    if (!s.ready) throw Error(1, "ccsd_triples: no converged CCSD state in this context");
+    const int o = s.o, v = s.v;
+    const int64_t O = o, V = v, v2 = V * V, v3 = V * V * V, Kc = V + O;
+    t_begin = std::max<int64_t>(0, t_begin);
+    t_end = std::min<int64_t>(triples_count(o), t_end);
+    TriplesPlan* p = plan_for(cx, s, t_begin, t_end);
+    // concatenated operands, summed index kappa = [d ; l] first (the reference also moves the summed index first, :2056-2066)
+    //   vt(kappa,b,c,k): kappa<v: <cb|kd> = v_vvov(c,b,k,d);  kappa=v+l: t2(l,k,b,c)
+    //   tt(kappa,a,j,i): kappa<v: t2(i,j,a,d);                kappa=v+l: -<ij|al> = -v_oovo(i,j,a,l)
+    Tensor vt = view(cx.scratch("t_vt", Kc * v2 * O), {Kc, V, V, O}), tt = view(cx.scratch("t_tt", Kc * V * O * O), {Kc, V, O, O});
+    auto sub = [&](const Tensor& full, int64_t row0, int64_t nrows) {
+        Tensor t = full;
+        t.d = full.d + row0;
+        t.dim[0] = nrows;
+        return t;
+    };
+    permute_add(cx, 1.0, s.v_vvov, "cbkd", 0.0, sub(vt, 0, V), "dbck");
+    permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vt, V, O), "lbck");
+    permute_add(cx, 1.0, s.t2, "ijad", 0.0, sub(tt, 0, V), "daji");
+    permute_add(cx, -1.0, s.v_oovo, "ijal", 0.0, sub(tt, V, O), "laji");
+    Tensor vs = view(cx.scratch("t_vs", v2 * O * O), {V, V, O, O});    // vs(x,y,p,q)  = v_oovv(p,q,x,y)
+    Tensor ts = view(cx.scratch("t_ts", v2 * O * O), {V, V, O, O});    // ts(x,y,p,q)  = t2(p,q,x,y)
+    permute_add(cx, 1.0, s.v_oovv, "pqxy", 0.0, vs, "xypq");
+    permute_add(cx, 1.0, s.t2, "pqxy", 0.0, ts, "xypq");
+    k_fill(cx, cx.scal, 4, 0.0);
+    TriplesIn in{s.e, s.t1.d, vs.d, ts.d, s.t2.d, o, v};
+    double* Xpool = cx.scratch("t_xpool", 6 * p->nb * v3);
+    double* partial = cx.scratch("t_partial", 4 * std::max<int64_t>((int64_t)p->norb * p->nb, 512));
+    // one stream, no host round trip until the four sums are read back: chunk c+1's GEMMs overwrite the X pool only
+    // after chunk c's orbit kernel has consumed it (stream order)
+    for (const TriplesPlan::Chunk& ch : p->chunks) {
+        const int64_t* tabs = p->tables + ch.tab_off;
+        for (const TriplesPlan::Group& g : ch.groups) {
+            GettProblem gp;
+            gp.A = vt.d + Kc * v2 * g.r;   // vt(:,:,:,r)
+            gp.B = tt.d;
+            gp.C = Xpool;
+            gp.offAm = p->tables + p->off_Am; gp.offAk = p->tables + p->off_k; gp.offBk = p->tables + p->off_k;
+            gp.offBn = tabs + g.start;
+            gp.offCm = p->tables + p->off_Cm; gp.offCn = tabs + ch.ntab + g.start;
+            gp.M = (int)v2; gp.N = (int)g.N; gp.K = (int)Kc;
+            gp.alpha = 1.0; gp.beta = 0.0;
+            gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
+            gp.a_kcontig = gp.b_kcontig = true;
+            AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+        }
+        hipLaunchKernelGGL(triples_orbit_kernel, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,
+                           p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
+        AFESP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, p->norb * ch.nt);
+        AFESP_HIP(hipGetLastError());
+    }
     if (t_begin == 0) {
         hipLaunchKernelGGL(triples_dbase_kernel, dim3(256), dim3(256), 0, cx.stream, partial, in, 256);
         AFESP_HIP(hipGetLastError());
@@ -216,7 +249,6 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     out_host[1] = h[0] + h[1];     // E(T)            ccsd.f90:2220
     out_host[2] = h[2];            // D[T]
     out_host[3] = h[2] + h[3];     // D(T)            ccsd.f90:2232
-    cx.release(meta_d); cx.release(d_n); cx.release(orb_d); cx.release(d_k); cx.release(d_Am); cx.release(d_Cm);
 }
 
 }  // namespace afesp
