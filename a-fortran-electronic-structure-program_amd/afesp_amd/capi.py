@@ -23,7 +23,7 @@ EXPORTS = [
     "afesp_ccsd_init", "afesp_ccsd_iterate", "afesp_ccsd_energy", "afesp_ccsd_diis", "afesp_ccsd_solve",
     "afesp_ccsd_get_amplitudes", "afesp_ccsd_set_amplitudes", "afesp_ccsd_get_tensor", "afesp_ccsd_update_intermediates",
     "afesp_ccsd_update_amplitudes", "afesp_ccsd_t_ntriples", "afesp_ccsd_t", "afesp_gemm", "afesp_permute4",
-    "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder", "afesp_bench_contract", "afesp_set_tuning",
+    "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder", "afesp_bench_contract", "afesp_set_tuning", "afesp_bench_stream",
 ]
 
 
@@ -73,6 +73,7 @@ def load_library():
     L.afesp_bench_contract.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(i64), C.c_char_p, C.POINTER(i64), C.c_char_p,
                                        C.POINTER(i64), C.c_int, C.POINTER(dbl)]
     L.afesp_set_tuning.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.afesp_bench_stream.argtypes = [C.c_void_p, i64, C.c_int, C.POINTER(dbl)]
     _lib = L
     return L
 
@@ -221,6 +222,11 @@ class Engine:
         ms = dbl()
         self._chk(self.L.afesp_bench_contract(self.h, la.encode(), (i64 * len(dA))(*dA), lb.encode(), (i64 * len(dB))(*dB),
                                               lc.encode(), (i64 * len(dC))(*dC), reps, C.byref(ms)))
+        return ms.value
+
+    def bench_stream(self, n, reps=5):
+        ms = dbl()
+        self._chk(self.L.afesp_bench_stream(self.h, n, reps, C.byref(ms)))
         return ms.value
 
     def set_tuning(self, group_m=0, tm=0, tn=0, split=0):

@@ -42,7 +42,7 @@ struct Tensor {
 struct Plan {
     int64_t *offAm, *offAk, *offBk, *offBn, *offCm, *offCn;
     int M, N, K;
-    bool swapped, a_kc, b_kc;
+    bool swapped, a_kc, b_kc, wide;
 };
 
 struct Context {

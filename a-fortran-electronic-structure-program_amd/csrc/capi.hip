@@ -389,8 +389,34 @@ int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double sca
     });
 }
 
+int afesp_bench_stream(afesp_ctx* ctx, int64_t n, int reps, double* ms_per_launch)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        double* x = cx.scratch("bench_x", n);
+        double* y = cx.scratch("bench_y", n);
+        k_fill(cx, x, n, 1.0);
+        k_fill(cx, y, n, 2.0);
+        hipEvent_t a, b;
+        AFESP_HIP(hipEventCreate(&a));
+        AFESP_HIP(hipEventCreate(&b));
+        k_axpby(cx, y, 0.5, x, 0.25, n);
+        AFESP_HIP(hipEventRecord(a, cx.stream));
+        for (int r = 0; r < reps; ++r) k_axpby(cx, y, 0.5, x, 0.25, n);
+        AFESP_HIP(hipEventRecord(b, cx.stream));
+        AFESP_HIP(hipEventSynchronize(b));
+        float ms = 0.f;
+        AFESP_HIP(hipEventElapsedTime(&ms, a, b));
+        if (ms_per_launch) *ms_per_launch = (double)ms / (reps > 0 ? reps : 1);
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    });
+}
+
 int afesp_set_tuning(int group_m, int force_tm, int force_tn, int force_split)
 {
+    g_allow_wide = !(group_m & 0x10000); group_m &= 0xffff;
     g_group_m = group_m; g_force_tm = force_tm; g_force_tn = force_tn; g_force_split = force_split;
     return 0;
 }

@@ -215,6 +215,20 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
         auto tAm = table(M, 0), tAk = table(K, 0), tBk = table(K, 1), tBn = table(N, 1), tCm = table(M, 2), tCn = table(N, 2);
         if (tAm.size() > INT32_MAX || tBn.size() > INT32_MAX || tAk.size() > INT32_MAX) throw Error(3, "contract: extent too large");
         p.M = (int)tAm.size(); p.N = (int)tBn.size(); p.K = (int)tAk.size();
+        // 16-byte staging is legal when every offset is even and the contiguous direction advances in unit-stride pairs
+        auto pairs = [](const std::vector<int64_t>& t) {
+            if (t.size() % 2) return false;
+            for (size_t x = 0; x + 1 < t.size(); x += 2)
+                if ((t[x] & 1) || t[x + 1] != t[x] + 1) return false;
+            return true;
+        };
+        auto evens = [](const std::vector<int64_t>& t) {
+            for (int64_t x : t)
+                if (x & 1) return false;
+            return true;
+        };
+        p.wide = (p.a_kc ? (pairs(tAk) && evens(tAm)) : (pairs(tAm) && evens(tAk))) &&
+                 (p.b_kc ? (pairs(tBk) && evens(tBn)) : (pairs(tBn) && evens(tBk)));
         p.offAm = upload(cx, tAm); p.offAk = upload(cx, tAk); p.offBk = upload(cx, tBk);
         p.offBn = upload(cx, tBn); p.offCm = upload(cx, tCm); p.offCn = upload(cx, tCn);
         it = cx.plans.emplace(key, p).first;
@@ -232,6 +246,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
     g.batchB = p.swapped ? bA0 : bB0;
     g.batchC = bC;
     g.a_kcontig = p.a_kc; g.b_kcontig = p.b_kc;
+    g.wide = p.wide && ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0);
     AFESP_HIP(gett_launch(g, cx.ws, cx.stream, force_split, force_tm, force_tn));
 }
 

@@ -33,6 +33,9 @@ struct GettProblem {
     const int64_t* batchC;
     // layout hints: true = consecutive k are (mostly) consecutive in memory, false = consecutive m (or n) are
     bool a_kcontig, b_kcontig;
+    // every operand offset is even and the contiguous direction of both operands advances in unit-stride pairs:
+    // 16-byte loads/stores are legal (set by the planner after checking the tables)
+    bool wide = false;
 };
 
 // Workspace for split-K partial sums.  The launcher picks the tile shape and the split count itself.
@@ -45,6 +48,6 @@ struct GettWorkspace {
 hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_t stream, int force_split = 0,
                        int force_tm = 0, int force_tn = 0);
 
-extern int g_group_m, g_force_tm, g_force_tn, g_force_split;
+extern int g_group_m, g_force_tm, g_force_tn, g_force_split, g_allow_wide;
 
 }  // namespace afesp

@@ -21,15 +21,22 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;
 
-template <int BMN, bool KC, int NT>
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// W = elements moved per load/store instruction along the operand's contiguous direction (1: 8 B, 2: 16 B).
+// W = 2 halves the global-load, address-arithmetic and ds_write instruction counts -- on gfx950 the f64 MFMA shares its
+// issue/datapath with VALU and VMEM address work, so every instruction removed from the loop is matrix-pipe time won
+// (measured: the loop without its loads and LDS stores runs at 71 TF against 49 TF with them).
+template <int BMN, bool KC, int NT, int W>
 struct TileImg {
     static constexpr int LD = KC ? (BK + 2) : (BMN + 16);
     static constexpr int SIZE = KC ? BMN * LD : BK * LD;
-    static constexpr int PER = BMN * BK / NT;  // elements staged per thread per K step
+    static constexpr int PER = BMN * BK / (NT * W);   // W-element groups staged per thread per K step
+    static constexpr int KG = BK / W, MG = BMN / W;
     __device__ static __forceinline__ int at(int mn, int k) { return KC ? mn * LD + k : k * LD + mn; }
-    // staging map: which (mn,k) of the tile thread t handles as its r-th element
-    __device__ static __forceinline__ int mn_of(int t, int r) { return KC ? (t >> 4) + (NT / 16) * r : t % BMN; }
-    __device__ static __forceinline__ int k_of(int t, int r) { return KC ? (t & 15) : t / BMN + (NT / BMN) * r; }
+    // staging map: first (mn,k) of the r-th group thread t handles
+    __device__ static __forceinline__ int mn_of(int t, int r) { return KC ? (t / KG) + (NT / KG) * r : (t % MG) * W; }
+    __device__ static __forceinline__ int k_of(int t, int r) { return KC ? (t % KG) * W : t / MG + (NT / MG) * r; }
 };
 
 // Per-thread gather state of one operand.  The K-offsets of step t+2, the data of step t+1 and the MFMAs of step t
@@ -37,9 +44,9 @@ struct TileImg {
 // before the MFMAs of the current step have been issued.
 // Rows/columns beyond M/N read a clamped (valid) address and produce garbage only in rows/columns of C that are never
 // stored; only the K tail has to be zeroed, which stash() does for the single partial step.
-template <int BMN, bool KC, int NT>
+template <int BMN, bool KC, int NT, int W>
 struct Stager {
-    using T = TileImg<BMN, KC, NT>;
+    using T = TileImg<BMN, KC, NT, W>;
     static constexpr int NROW = KC ? T::PER : 1;
     static constexpr int NKO = KC ? 1 : T::PER;
     int64_t rowoff[NROW];
@@ -57,7 +64,7 @@ struct Stager {
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
             int mn = mn0 + T::mn_of(t, r);
-            rowoff[r] = offMN[mn < MN ? mn : MN - 1];
+            rowoff[r] = offMN[mn < MN ? mn : MN - W];   // (W = 2: MN is even, so MN - 2 is the last group)
         }
     }
     // offsets of the K step starting at k0 (clamped: always a valid table entry)
@@ -66,23 +73,35 @@ struct Stager {
 #pragma unroll
         for (int r = 0; r < NKO; ++r) {
             int k = k0 + T::k_of(t, r);
-            ko[r] = offK[k < K ? k : K - 1];
+            ko[r] = offK[k < K ? k : K - W];
         }
     }
-    __device__ __forceinline__ void fetch(double (&reg)[T::PER]) const
+    __device__ __forceinline__ void fetch(double (&reg)[T::PER][W]) const
     {
 #pragma unroll
-        for (int r = 0; r < T::PER; ++r) reg[r] = base[rowoff[KC ? r : 0] + ko[KC ? 0 : r]];
+        for (int r = 0; r < T::PER; ++r) {
+            const double* src = base + rowoff[KC ? r : 0] + ko[KC ? 0 : r];
+            if (W == 2) {
+                const v2d x = *reinterpret_cast<const v2d*>(src);   // 16-B aligned by the planner's eligibility test
+                reg[r][0] = x[0];
+                reg[r][W - 1] = x[1];
+            } else {
+                reg[r][0] = *src;
+            }
+        }
     }
-    __device__ __forceinline__ void stash(double* s, const double (&reg)[T::PER], int t, int k0, int kend, bool tail) const
+    __device__ __forceinline__ void stash(double* s, const double (&reg)[T::PER][W], int t, int k0, int kend, bool tail) const
     {
-        if (tail) {
 #pragma unroll
-            for (int r = 0; r < T::PER; ++r)
-                s[T::at(T::mn_of(t, r), T::k_of(t, r))] = (k0 + T::k_of(t, r) < kend) ? reg[r] : 0.0;
-        } else {
-#pragma unroll
-            for (int r = 0; r < T::PER; ++r) s[T::at(T::mn_of(t, r), T::k_of(t, r))] = reg[r];
+        for (int r = 0; r < T::PER; ++r) {
+            const int mn = T::mn_of(t, r), k = T::k_of(t, r);
+            double x0 = reg[r][0], x1 = reg[r][W - 1];
+            if (tail) {
+                x0 = (k0 + k < kend) ? x0 : 0.0;
+                x1 = (k0 + k + (KC ? W - 1 : 0) < kend) ? x1 : 0.0;
+            }
+            if (W == 2) *reinterpret_cast<v2d*>(&s[T::at(mn, k)]) = (v2d){x0, x1};
+            else s[T::at(mn, k)] = x0;
         }
     }
 };
@@ -104,13 +123,13 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-template <int WM, int WN, int TM, int TN, bool AKC, bool BKC>
+template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int W>
 __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
 {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
-    using TA = TileImg<BM, AKC, NT>;
-    using TB = TileImg<BN, BKC, NT>;
+    using TA = TileImg<BM, AKC, NT, W>;
+    using TB = TileImg<BN, BKC, NT, W>;
     __shared__ double lds[2 * (TA::SIZE + TB::SIZE)];
     constexpr int STAGE = TA::SIZE + TB::SIZE;   // buffer b: A image at lds + b*STAGE, B image right behind it
 
@@ -130,8 +149,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
     const double* Ab = p.A + (p.batchA ? p.batchA[z] : 0);
     const double* Bb = p.B + (p.batchB ? p.batchB[z] : 0);
 
-    Stager<BM, AKC, NT> stA;
-    Stager<BN, BKC, NT> stB;
+    Stager<BM, AKC, NT, W> stA;
+    Stager<BN, BKC, NT, W> stB;
     stA.init(Ab, p.offAm, p.offAk, m0, p.M, p.K, t);
     stB.init(Bb, p.offBn, p.offBk, n0, p.N, p.K, t);
 
@@ -144,7 +163,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
     // Register ring of depth 2: while the MFMAs of step kt run, the data of steps kt+1 (set P) and kt+2 (set Q) and the
     // offsets of step kt+3 are in flight; set P is written to LDS after the MFMAs.  Two K steps (~8k cycles of MFMA at
     // TM=TN=4) cover the loaded HBM latency with a single wave per SIMD.
-    double ra0[TA::PER], rb0[TB::PER], ra1[TA::PER], rb1[TB::PER];
+    double ra0[TA::PER][W], rb0[TB::PER][W], ra1[TA::PER][W], rb1[TB::PER][W];
     const int nk = (kend - kbeg + BK - 1) / BK;
     const bool ragged = ((kend - kbeg) % BK) != 0;   // the last step is partial
     if (nk > 0) {
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
                 }
             }
     } else {
-        double* W = a.ws + ((int64_t)z * a.ksplit + split) * (int64_t)p.M * p.N;
+        double* slab = a.ws + ((int64_t)z * a.ksplit + split) * (int64_t)p.M * p.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     int n = nl + 16 * j;
-                    if (n < p.N) W[(int64_t)m * p.N + n] = acc[i][j][r];
+                    if (n < p.N) slab[(int64_t)m * p.N + n] = acc[i][j][r];
                 }
             }
     }
@@ -287,19 +306,19 @@ __global__ __launch_bounds__(256) void gett_reduce_kernel(GettKernelArgs a)
     }
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int W>
 static void launch_cfg(const GettKernelArgs& a, dim3 grid, hipStream_t st)
 {
     const bool ak = a.p.a_kcontig, bk = a.p.b_kcontig;
     const dim3 blk(64 * WM * WN);
-    if (ak && bk) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, true, true>), grid, blk, 0, st, a);
-    else if (ak) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, true, false>), grid, blk, 0, st, a);
-    else if (bk) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, false, true>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, false, false>), grid, blk, 0, st, a);
+    if (ak && bk) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, true, true, W>), grid, blk, 0, st, a);
+    else if (ak) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, true, false, W>), grid, blk, 0, st, a);
+    else if (bk) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, false, true, W>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, false, false, W>), grid, blk, 0, st, a);
 }
 
 int g_group_m = 0;   // >0 overrides the tile-walk group size (tuning knob, see afesp_set_tuning)
-int g_force_tm = 0, g_force_tn = 0, g_force_split = 0;
+int g_force_tm = 0, g_force_tn = 0, g_force_split = 0, g_allow_wide = 1;
 
 // Block tile extent (rows or columns) for a requested code: 1 -> 32, 2 -> 64, 4 -> 128; 8 = 128 with 8 waves.
 static int pick_t(int extent)
@@ -318,7 +337,11 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     if (!force_tm) force_tm = g_force_tm;
     if (!force_tn) force_tn = g_force_tn;
     if (!force_split) force_split = g_force_split;
-    const int tm = force_tm ? force_tm : pick_t(p.M), tn = force_tn ? force_tn : pick_t(p.N);
+    const bool wide = p.wide && g_allow_wide && (p.M % 2 == 0) && (p.N % 2 == 0) && (p.K % 2 == 0) && p.nbatch == 1;
+    int tm = force_tm ? force_tm : pick_t(p.M), tn = force_tn ? force_tn : pick_t(p.N);
+    // tall problems with 16-byte staging: the 256x128 tile (8 waves, 4x4 MFMA grid per wave) halves the staging
+    // instructions per MFMA once more (62 TF against 55 TF for 128x128 on the o^3 v^3 ring contraction at o=20, v=200)
+    if (!force_tm && !force_tn && tm == 4 && tn == 4 && wide && p.M >= 2048) { tm = 16; tn = 8; }
     const int BM = tm == 16 ? 256 : tm == 8 ? 128 : 32 * tm, BN = tn == 16 ? 256 : tn == 8 ? 128 : 32 * tn;
     a.mtiles = (p.M + BM - 1) / BM;
     a.ntiles = (p.N + BN - 1) / BN;
@@ -350,7 +373,10 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     // tile code (tm,tn) -> wave grid x per-wave MFMA grid.  (4,4) is the 8-wave 128x128 tile: two waves per SIMD share
     // the matrix pipe, so one wave's gather/LDS phases are covered by the other's MFMAs.
 #define AFESP_CFG(TM_, TN_, WM_, WN_, PM_, PN_) \
-    if (tm == TM_ && tn == TN_) launch_cfg<WM_, WN_, PM_, PN_>(a, grid, stream);
+    if (tm == TM_ && tn == TN_) {                                                           \
+        if (wide && TM_ >= 2 && TN_ >= 2) launch_cfg<WM_, WN_, PM_, PN_, (TM_ >= 2 && TN_ >= 2) ? 2 : 1>(a, grid, stream); \
+        else launch_cfg<WM_, WN_, PM_, PN_, 1>(a, grid, stream);                            \
+    }
     AFESP_CFG(1, 1, 2, 2, 1, 1) AFESP_CFG(1, 2, 2, 2, 1, 2) AFESP_CFG(1, 4, 2, 2, 1, 4)
     AFESP_CFG(2, 1, 2, 2, 2, 1) AFESP_CFG(2, 2, 2, 2, 2, 2) AFESP_CFG(2, 4, 2, 2, 2, 4)
     AFESP_CFG(4, 1, 2, 2, 4, 1) AFESP_CFG(4, 2, 2, 2, 4, 2) AFESP_CFG(4, 4, 2, 4, 4, 2)

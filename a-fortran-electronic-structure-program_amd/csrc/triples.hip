@@ -230,6 +230,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             gp.alpha = 1.0; gp.beta = 0.0;
             gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
             gp.a_kcontig = gp.b_kcontig = true;
+            gp.wide = (Kc % 2 == 0) && (V % 2 == 0);   // then every row/column offset above is even
             AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
         }
         hipLaunchKernelGGL(triples_orbit_kernel, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,

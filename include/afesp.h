@@ -96,6 +96,8 @@ int afesp_contract(afesp_ctx* ctx, double alpha, const double* A, const char* la
 int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double scale, uint64_t seed, int diis_n_errmat);
 /* Kernel-only timing helpers: average HIP-event milliseconds per launch over `reps` launches on the context stream. */
 int afesp_time_pp_ladder(afesp_ctx* ctx, int reps, double* ms_per_launch);
+/* y = a x + b y on n doubles (8 B per lane, 24 n bytes of HBM traffic per launch): PMC calibration / achievable-bandwidth probe. */
+int afesp_bench_stream(afesp_ctx* ctx, int64_t n, int reps, double* ms_per_launch);
 /* Same for an arbitrary labelled contraction on hashed device operands (dense column-major extents). */
 int afesp_bench_contract(afesp_ctx* ctx, const char* la, const int64_t* dimsA, const char* lb, const int64_t* dimsB,
                          const char* lc, const int64_t* dimsC, int reps, double* ms_per_launch);
