@@ -23,7 +23,7 @@ EXPORTS = [
     "afesp_ccsd_init", "afesp_ccsd_iterate", "afesp_ccsd_energy", "afesp_ccsd_diis", "afesp_ccsd_solve",
     "afesp_ccsd_get_amplitudes", "afesp_ccsd_set_amplitudes", "afesp_ccsd_get_tensor", "afesp_ccsd_update_intermediates",
     "afesp_ccsd_update_amplitudes", "afesp_ccsd_t_ntriples", "afesp_ccsd_t", "afesp_gemm", "afesp_permute4",
-    "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder", "afesp_bench_contract", "afesp_set_tuning", "afesp_bench_stream",
+    "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder", "afesp_bench_contract", "afesp_set_tuning", "afesp_bench_stream", "afesp_profile",
 ]
 
 
@@ -74,6 +74,7 @@ def load_library():
                                        C.POINTER(i64), C.c_int, C.POINTER(dbl)]
     L.afesp_set_tuning.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.afesp_bench_stream.argtypes = [C.c_void_p, i64, C.c_int, C.POINTER(dbl)]
+    L.afesp_profile.argtypes = [C.c_void_p, C.c_int, _dp]
     _lib = L
     return L
 
@@ -223,6 +224,12 @@ class Engine:
         self._chk(self.L.afesp_bench_contract(self.h, la.encode(), (i64 * len(dA))(*dA), lb.encode(), (i64 * len(dB))(*dB),
                                               lc.encode(), (i64 * len(dC))(*dC), reps, C.byref(ms)))
         return ms.value
+
+    def profile(self, enable):
+        out = np.zeros(6)
+        self._chk(self.L.afesp_profile(self.h, 1 if enable else 0, out))
+        return dict(gemm_ms=out[0], gemm_launches=int(out[1]), gemm_flop=out[2], orbit_ms=out[3], orbit_launches=int(out[4]),
+                    orbit_bytes=out[5])
 
     def bench_stream(self, n, reps=5):
         ms = dbl()

@@ -55,6 +55,10 @@ struct Context {
     std::map<std::string, Plan> plans;
     std::map<std::string, std::pair<void*, size_t>> cache;   // named scratch buffers kept across calls (not zeroed)
     std::string last_error;
+    // optional HIP-event timing of the (T) launches (bench.py roofline): enabled by afesp_profile
+    bool prof = false;
+    double prof_gemm_ms = 0.0, prof_gemm_flop = 0.0, prof_orbit_ms = 0.0, prof_orbit_bytes = 0.0;
+    int64_t prof_gemm_launches = 0, prof_orbit_launches = 0;
 
     double* alloc(int64_t n);             // zero-initialised doubles
     int64_t* alloc_i64(int64_t n);

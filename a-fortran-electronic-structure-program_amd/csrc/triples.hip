@@ -216,8 +216,17 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     double* partial = cx.scratch("t_partial", 4 * std::max<int64_t>((int64_t)p->norb * p->nb, 512));
     // one stream, no host round trip until the four sums are read back: chunk c+1's GEMMs overwrite the X pool only
     // after chunk c's orbit kernel has consumed it (stream order)
+    std::vector<hipEvent_t> evs;
+    auto stamp = [&]() {
+        if (!cx.prof) return;
+        hipEvent_t e;
+        AFESP_HIP(hipEventCreate(&e));
+        AFESP_HIP(hipEventRecord(e, cx.stream));
+        evs.push_back(e);
+    };
     for (const TriplesPlan::Chunk& ch : p->chunks) {
         const int64_t* tabs = p->tables + ch.tab_off;
+        stamp();
         for (const TriplesPlan::Group& g : ch.groups) {
             GettProblem gp;
             gp.A = vt.d + Kc * v2 * g.r;   // vt(:,:,:,r)
@@ -232,10 +241,20 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             gp.a_kcontig = gp.b_kcontig = true;
             gp.wide = (Kc % 2 == 0) && (V % 2 == 0);   // then every row/column offset above is even
             AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+            if (cx.prof) {
+                cx.prof_gemm_launches += 1;
+                cx.prof_gemm_flop += 2.0 * (double)gp.M * (double)gp.N * (double)gp.K;
+            }
         }
+        stamp();
         hipLaunchKernelGGL(triples_orbit_kernel, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,
                            p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
         AFESP_HIP(hipGetLastError());
+        stamp();
+        if (cx.prof) {
+            cx.prof_orbit_launches += 1;
+            cx.prof_orbit_bytes += 8.0 * 6.0 * (double)v3 * ch.nt;
+        }
         hipLaunchKernelGGL(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, p->norb * ch.nt);
         AFESP_HIP(hipGetLastError());
     }
@@ -246,6 +265,14 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         AFESP_HIP(hipGetLastError());
     }
     double* h = host_scalars(cx, 4);
+    for (size_t q = 0; q + 2 < evs.size(); q += 3) {
+        float a = 0.f, b = 0.f;
+        AFESP_HIP(hipEventElapsedTime(&a, evs[q], evs[q + 1]));
+        AFESP_HIP(hipEventElapsedTime(&b, evs[q + 1], evs[q + 2]));
+        cx.prof_gemm_ms += a;
+        cx.prof_orbit_ms += b;
+    }
+    for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     out_host[0] = h[0];            // E[T]
     out_host[1] = h[0] + h[1];     // E(T)            ccsd.f90:2220
     out_host[2] = h[2];            // D[T]

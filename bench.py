@@ -189,12 +189,14 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    eng.profile(True)                                   # HIP-event stamps around the (T) launches from here on
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    prof = eng.profile(False)
     tt = torch.tensor([elapsed, t_iter, t_trip], dtype=torch.float64, device=f"cuda:{local}")
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -203,20 +205,31 @@ def main():
     flop_step = flops_iter(o, v) + flops_t_sym(o, v)
 
     if rank == 0:
-        # dominant contraction of the iteration (pp-ladder, ccsd.f90:1669), timed with HIP events on the engine's stream
-        ms_lad = eng.time_pp_ladder(20 if o * v < 2000 else 5)
-        lad_flop = 2 * o**2 * v**4
-        lad_bytes = 8 * (v**4 + 2 * o**2 * v**2)
-        ai = lad_flop / lad_bytes
-        if ai > MFMA_F64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
-            roof = {"bound": "mfma", "achieved": lad_flop / (ms_lad * 1e-3) / 1e12, "peak": MFMA_F64_PEAK_TFLOPS,
-                    "unit": "TFLOP/s"}
-        else:
-            roof = {"bound": "hbm", "achieved": lad_bytes / (ms_lad * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+        # Dominant kernel: the (T) GEMM (gett_kernel, X = tt^T vt over kappa = d + l, K = v+o), timed over the timed region
+        # with HIP events on the engine's stream (csrc/triples.hip).  Algorithmic flop per launch = 2 M N K of that launch.
+        nl = max(prof["gemm_launches"], 1)
+        ms_launch = prof["gemm_ms"] / nl
+        roof = {"bound": "mfma", "achieved": prof["gemm_flop"] / max(prof["gemm_ms"], 1e-9) / 1e9,
+                "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
         roof["traffic"] = None
-        roof["kernel"] = "gett_kernel (pp-ladder 0.5*c_oovv(ij,ef)*v_vvvv(ef,ab))"
-        roof["ms_per_launch"] = ms_lad
+        roof["kernel"] = "gett_kernel, (T) launches: X(a,b,c|ijk) = sum_kappa tt(kappa;a,ij) vt(kappa;b,c,k), K = v+o"
+        roof["launches"] = prof["gemm_launches"]
+        roof["ms_per_launch"] = ms_launch
+        roof["flop_per_launch"] = prof["gemm_flop"] / nl
+        roof["share_of_step_time"] = prof["gemm_ms"] * 1e-3 / elapsed
+        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tfile):
+            tr = json.load(open(tfile)).get(args.workload + "_t_gemm")
+            if tr:
+                roof["traffic"] = tr["hbm_bytes_per_launch"]
+                roof["traffic_source"] = tr["command"]
+        second = {"kernel": "triples_orbit_kernel", "bound": "hbm",
+                  "achieved": prof["orbit_bytes"] / max(prof["orbit_ms"], 1e-9) / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "ms_per_launch": prof["orbit_ms"] / max(prof["orbit_launches"], 1),
+                  "share_of_step_time": prof["orbit_ms"] * 1e-3 / elapsed}
+        second["frac"] = second["achieved"] / second["peak"]
+        ms_lad = eng.time_pp_ladder(20 if o * v < 2000 else 5)
         line = {
             "metric": "CCSD iter wall-time (s) + (T) wall-time (s); fp64 TFLOP/s vs MFMA peak",
             "value": flop_step / sec_per_step / 1e12, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
@@ -229,6 +242,9 @@ def main():
             "flop_per_step": flop_step, "fraction_of_mfma_peak": flop_step / sec_per_step / 1e12 / (MFMA_F64_PEAK_TFLOPS * world),
             "e_t": [float(x) for x in last],
             "roofline": roof,
+            "roofline_second_kernel": second,
+            "pp_ladder": {"ms_per_launch": ms_lad, "tflops": 2 * o**2 * v**4 / (ms_lad * 1e-3) / 1e12,
+                          "algorithmic_gbs": 8 * (v**4 + 2 * o**2 * v**2) / (ms_lad * 1e-3) / 1e9},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(o, v, args.scale, seed, eng)
