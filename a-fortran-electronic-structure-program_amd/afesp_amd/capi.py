@@ -23,7 +23,7 @@ EXPORTS = [
     "afesp_ccsd_init", "afesp_ccsd_iterate", "afesp_ccsd_energy", "afesp_ccsd_diis", "afesp_ccsd_solve",
     "afesp_ccsd_get_amplitudes", "afesp_ccsd_set_amplitudes", "afesp_ccsd_get_tensor", "afesp_ccsd_update_intermediates",
     "afesp_ccsd_update_amplitudes", "afesp_ccsd_t_ntriples", "afesp_ccsd_t", "afesp_gemm", "afesp_permute4",
-    "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder", "afesp_bench_contract", "afesp_set_tuning", "afesp_bench_stream", "afesp_profile",
+    "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder", "afesp_bench_contract", "afesp_set_tuning", "afesp_bench_stream", "afesp_profile", "afesp_ccsd_cr_intermediates", "afesp_ccsd_t_cr",
 ]
 
 
@@ -64,6 +64,8 @@ def load_library():
     L.afesp_ccsd_t_ntriples.argtypes = [i64]
     L.afesp_ccsd_t_ntriples.restype = i64
     L.afesp_ccsd_t.argtypes = [C.c_void_p, i64, i64, _dp]
+    L.afesp_ccsd_t_cr.argtypes = [C.c_void_p, i64, i64, _dp]
+    L.afesp_ccsd_cr_intermediates.argtypes = [C.c_void_p]
     L.afesp_gemm.argtypes = [C.c_void_p, C.c_char, C.c_char, i64, i64, i64, dbl, _dp, _dp, dbl, _dp]
     L.afesp_permute4.argtypes = [C.c_void_p, C.POINTER(i64), C.c_char_p, _dp, _dp, C.c_int, dbl]
     L.afesp_contract.argtypes = [C.c_void_p, dbl, _dp, C.c_char_p, C.POINTER(i64), _dp, C.c_char_p, C.POINTER(i64), dbl,
@@ -196,6 +198,17 @@ class Engine:
         if t_end is None:
             t_end = self.ntriples()
         self._chk(self.L.afesp_ccsd_t(self.h, t_begin, t_end, out))
+        return out
+
+    # ---- completely renormalised variants (src/ccsd.f90:2338-2551, :2186-2194)
+    def build_cr_intermediates(self):
+        self._chk(self.L.afesp_ccsd_cr_intermediates(self.h))
+
+    def do_ccsd_t_spatial_cr(self, t_begin=0, t_end=None):
+        out = np.zeros(6)
+        if t_end is None:
+            t_end = self.ntriples()
+        self._chk(self.L.afesp_ccsd_t_cr(self.h, t_begin, t_end, out))
         return out
 
     # ---- src/linalg.fpp operator layer

@@ -304,6 +304,23 @@ int afesp_ccsd_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[4])
     });
 }
 
+int afesp_ccsd_cr_intermediates(afesp_ctx* ctx)
+{
+    return guarded(ctx, [&] {
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        ccsd_cr_intermediates(ctx->cx, ctx->cc);
+        ctx->cx.sync();
+    });
+}
+
+int afesp_ccsd_t_cr(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[6])
+{
+    return guarded(ctx, [&] {
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        ccsd_triples(ctx->cx, ctx->cc, t_begin, t_end, out, true);
+    });
+}
+
 // ---------------------------------------------------------------- operator layer on host arrays
 int afesp_contract(afesp_ctx* ctx, double alpha, const double* A, const char* la, const int64_t* dimsA, const double* B,
                    const char* lb, const int64_t* dimsB, double beta, double* C, const char* lc, const int64_t* dimsC,

@@ -22,6 +22,8 @@ struct CCState {
     std::vector<double> B;      // host copy of the error overlap matrix (nerr x nerr, full)
     double energy = 0.0, energy_old = 0.0, rms = 0.0;
     void* tplan = nullptr;      // cached (T) launch plan (triples.hip)
+    Tensor I_vovv_pp, I_ooov_pp;   // completely renormalised moments (ccsd.f90:2338-2551), built on request
+    bool have_cr = false;
 };
 void triples_plan_free(CCState& s);
 
@@ -38,6 +40,9 @@ void ccsd_free(Context& cx, CCState& s);
 // (T): out[0]=E[T] out[1]=E(T) out[2]=D[T] out[3]=D(T) contributions of the unordered triples with
 // flat index in [t_begin, t_end) of the i<=j<=k enumeration; D base term (ccsd.f90:2243) added iff t_begin==0.
 int64_t triples_count(int o);
-void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host);
+// cr = true: also out[4] = sum t_bar.M3, out[5] = out[4] + sum z_bar.M3 (needs ccsd_cr_intermediates)
+void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host, bool cr = false);
+// build_cr_ccsd_t_intermediates (ccsd.f90:2338-2551) on the converged amplitudes
+void ccsd_cr_intermediates(Context& cx, CCState& s);
 
 }  // namespace afesp

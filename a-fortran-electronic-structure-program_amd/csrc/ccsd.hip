@@ -6,6 +6,7 @@
 // is a single gather-GEMM on the resident tensors: no reshape temporaries, and the integrals are never
 // antisymmetrised in place (the reference mutates and restores v_oovv/v_vvov/v_oovo every iteration,
 // :1089,:1101-1126; here the three "2x - x^T" companions are built once at init).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -72,7 +73,7 @@ void ccsd_free(Context& cx, CCState& s)
     double* bufs[] = {s.e, s.v_oovv.d, s.v_ovov.d, s.v_vvov.d, s.v_oovo.d, s.v_oooo.d, s.v_vvvv.d, s.w_oovv.d, s.w_vvov.d,
                       s.w_oovo.d, s.D1.d, s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.I_vo.d, s.I_vv.d, s.I_oo_p.d, s.I_oo.d, s.c.d,
                       s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_vovv_p.d, s.I_ooov_p.d, s.amp_s, s.hist_t,
-                      s.hist_e, s.coef};
+                      s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d};
     for (double* b : bufs) cx.release(b);
     cx.drop_scratch();
     triples_plan_free(s);
@@ -164,6 +165,71 @@ int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol)
     s.energy = h[0];
     s.rms = h[1];                   // un-rooted, ccsd.f90:1806
     return (std::sqrt(h[1]) < t_tol && std::fabs(s.energy - s.energy_old) < e_tol) ? 1 : 0;   // ccsd.f90:1805
+}
+
+// build_cr_ccsd_t_intermediates, src/ccsd.f90:2338-2551.  Data flow as in the reference: t1/t2 are the converged amplitudes,
+// I_vo and asym_t2 are what the last update_restricted_intermediates left behind (:2374-2378).  The three terms of
+// I_ooov_pp that the reference sums over `e = 1, nocc` although e is a virtual index (:2535) are summed over the first
+// min(o,v) virtuals here too -- the bundled CR goldens contain that bound.
+void ccsd_cr_intermediates(Context& cx, CCState& s)
+{
+    if (!s.ready) throw Error(1, "ccsd_cr_intermediates: no CCSD state");
+    const int64_t O = s.o, V = s.v;
+    auto C = [&](double al, const Tensor& A, const char* la, const Tensor& B, const char* lb, double be, const Tensor& Cc,
+                 const char* lc) { contract(cx, al, A, la, B, lb, be, Cc, lc); };
+    if (!s.have_cr) {
+        s.I_vovv_pp = cx.tensor({V, O, V, V});
+        s.I_ooov_pp = cx.tensor({O, O, O, V});
+        s.have_cr = true;
+    }
+    Tensor xvp = view(cx.scratch("cr_xvp", V * V * V * O), {V, V, V, O}), xv = view(cx.scratch("cr_xv", V * V * V * O), {V, V, V, O});
+    Tensor xovov_p = view(cx.scratch("cr_a", O * V * O * V), {O, V, O, V}), xvoov_p = view(cx.scratch("cr_b", O * V * O * V), {V, O, O, V});
+    Tensor xovov_pp = view(cx.scratch("cr_c", O * V * O * V), {O, V, O, V}), xvoov_pp = view(cx.scratch("cr_d", O * V * O * V), {V, O, O, V});
+    Tensor xovoo = view(cx.scratch("cr_e", O * V * O * O), {O, V, O, O});
+    // x_vvvo_p(b,c,a,i) = <cb|ia> - 1/2 t(m,a) <mi|bc>  (:2429);   x_vvvo = x_vvvo_p - 1/2 t(m,a) <mi|bc>  (:2465)
+    permute_add(cx, 1.0, s.v_vvov, "cbia", 0.0, xvp, "bcai");
+    C(-0.5, s.t1, "ma", s.v_oovv, "mibc", 1.0, xvp, "bcai");
+    k_copy(cx, xv.d, xvp.d, xv.size());
+    C(-0.5, s.t1, "ma", s.v_oovv, "mibc", 1.0, xv, "bcai");
+    // x_ovov_p / x_ovov_pp (j,b,i,a)  (:2441, :2489)
+    k_copy(cx, xovov_p.d, s.v_ovov.d, xovov_p.size());
+    C(-0.5, s.v_oovo, "mibj", s.t1, "ma", 1.0, xovov_p, "jbia");
+    C(1.0, s.t1, "je", xvp, "beai", 1.0, xovov_p, "jbia");
+    k_copy(cx, xovov_pp.d, s.v_ovov.d, xovov_pp.size());
+    C(-1.0, s.v_oovo, "mibj", s.t1, "ma", 1.0, xovov_pp, "jbia");
+    C(0.5, s.t1, "je", xv, "beai", 1.0, xovov_pp, "jbia");
+    // x_voov_p / x_voov_pp (b,j,i,a)  (:2453, :2501)
+    permute_add(cx, 1.0, s.v_oovv, "ijba", 0.0, xvoov_p, "bjia");
+    C(-0.5, s.v_oovo, "imbj", s.t1, "ma", 1.0, xvoov_p, "bjia");
+    C(1.0, xvp, "ebai", s.t1, "je", 1.0, xvoov_p, "bjia");
+    permute_add(cx, 1.0, s.v_oovv, "ijba", 0.0, xvoov_pp, "bjia");
+    C(-1.0, s.v_oovo, "imbj", s.t1, "ma", 1.0, xvoov_pp, "bjia");
+    C(0.5, xv, "ebai", s.t1, "je", 1.0, xvoov_pp, "bjia");
+    // x_ovoo(k,a,i,j) = <ji|ak> + t(k,e) <ij|ea>  (:2477)
+    permute_add(cx, 1.0, s.v_oovo, "jiak", 0.0, xovoo, "kaij");
+    C(1.0, s.t1, "ke", s.v_oovv, "ijea", 1.0, xovoo, "kaij");
+    // I_vovv_pp(c,i,a,b)  (:2513-2520)
+    permute_add(cx, 1.0, s.v_vvov, "baic", 0.0, s.I_vovv_pp, "ciab");
+    C(1.0, s.v_vvvv, "ecba", s.t1, "ie", 1.0, s.I_vovv_pp, "ciab");
+    C(-1.0, xovov_p, "icma", s.t1, "mb", 1.0, s.I_vovv_pp, "ciab");
+    C(-1.0, s.t1, "ma", xvoov_p, "cimb", 1.0, s.I_vovv_pp, "ciab");
+    C(-1.0, s.I_vo, "cm", s.t2, "miab", 1.0, s.I_vovv_pp, "ciab");
+    C(1.0, s.t2, "mnba", xovoo, "icmn", 1.0, s.I_vovv_pp, "ciab");
+    C(1.0, xv, "ceam", s.asym, "imbe", 1.0, s.I_vovv_pp, "ciab");
+    C(-1.0, xv, "ecam", s.t2, "mieb", 1.0, s.I_vovv_pp, "ciab");
+    C(-1.0, s.t2, "miae", xv, "ecbm", 1.0, s.I_vovv_pp, "ciab");
+    // I_ooov_pp(j,k,i,a)  (:2532-2539)
+    permute_add(cx, 1.0, s.v_oovo, "kjai", 0.0, s.I_ooov_pp, "jkia");
+    C(-1.0, s.v_oooo, "mikj", s.t1, "ma", 1.0, s.I_ooov_pp, "jkia");
+    C(1.0, xovov_pp, "jeia", s.t1, "ke", 1.0, s.I_ooov_pp, "jkia");
+    C(1.0, s.t1, "je", xvoov_pp, "ekia", 1.0, s.I_ooov_pp, "jkia");
+    C(1.0, s.t2, "kjef", xv, "efai", 1.0, s.I_ooov_pp, "jkia");
+    const int64_t eb = std::min(O, V);
+    auto clip = [](Tensor t, int axis, int64_t n) { t.dim[axis] = n; return t; };
+    Tensor xo_e = clip(xovoo, 1, eb), as_e = clip(s.asym, 2, eb), t2_e2 = clip(s.t2, 2, eb), t2_e3 = clip(s.t2, 3, eb);
+    C(1.0, xo_e, "jeim", as_e, "mkea", 1.0, s.I_ooov_pp, "jkia");
+    C(-1.0, xo_e, "jemi", t2_e2, "mkea", 1.0, s.I_ooov_pp, "jkia");
+    C(-1.0, t2_e3, "mjae", xo_e, "kemi", 1.0, s.I_ooov_pp, "jkia");
 }
 
 // Symmetric solve of the (n+1)x(n+1) DIIS system on the host (the reference calls LAPACK dsysv, linalg.fpp:38-56;

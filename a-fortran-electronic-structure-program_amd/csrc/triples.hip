@@ -73,6 +73,7 @@ struct TriplesPlan {
     int o = 0, v = 0;
     int64_t t_begin = -1, t_end = -1, nb = 0;
     int norb = 0;
+    bool cr = false;
     struct Group { int r; int64_t start, N; };
     struct Chunk { int nt; int64_t meta_off, tab_off, ntab; std::vector<Group> groups; };
     std::vector<Chunk> chunks;
@@ -82,19 +83,19 @@ struct TriplesPlan {
     int* orbits = nullptr;
 };
 
-static TriplesPlan* plan_for(Context& cx, CCState& s, int64_t t_begin, int64_t t_end)
+static TriplesPlan* plan_for(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, bool cr)
 {
     TriplesPlan* p = (TriplesPlan*)s.tplan;
-    if (p && p->o == s.o && p->v == s.v && p->t_begin == t_begin && p->t_end == t_end) return p;
+    if (p && p->o == s.o && p->v == s.v && p->t_begin == t_begin && p->t_end == t_end && p->cr == cr) return p;
     delete p;
     p = new TriplesPlan();
     s.tplan = p;
     const int o = s.o, v = s.v;
     const int64_t O = o, V = v, v2 = V * V, v3 = v2 * V, Kc = V + O;
-    p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end;
+    p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = cr;
     // chunk size: 6 X blocks of v^3 doubles per triple (W never leaves LDS); a few dozen ordered triples per k-group keep
     // the GEMM column count in the thousands, more buys nothing
-    const int64_t per = 6 * v3 * (int64_t)sizeof(double);
+    const int64_t per = (cr ? 12 : 6) * v3 * (int64_t)sizeof(double);   // CR mode keeps a second pool for the M3 blocks
     int64_t nb = std::max<int64_t>(1, ((int64_t)24 << 30) / per);
     nb = std::min<int64_t>(nb, 4096);
     nb = std::min<int64_t>(nb, std::max<int64_t>(1, t_end - t_begin));
@@ -184,14 +185,15 @@ void triples_plan_free(CCState& s)
     s.tplan = nullptr;
 }
 
-void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host)
+void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host, bool cr)
 {
+    if (cr && !s.have_cr) throw Error(1, "ccsd_triples: completely renormalised mode needs ccsd_cr_intermediates first");
     if (!s.ready) throw Error(1, "ccsd_triples: no converged CCSD state in this context");
     const int o = s.o, v = s.v;
     const int64_t O = o, V = v, v2 = V * V, v3 = V * V * V, Kc = V + O;
     t_begin = std::max<int64_t>(0, t_begin);
     t_end = std::min<int64_t>(triples_count(o), t_end);
-    TriplesPlan* p = plan_for(cx, s, t_begin, t_end);
+    TriplesPlan* p = plan_for(cx, s, t_begin, t_end, cr);
     // concatenated operands, summed index kappa = [d ; l] first (the reference also moves the summed index first, :2056-2066)
     //   vt(kappa,b,c,k): kappa<v: <cb|kd> = v_vvov(c,b,k,d);  kappa=v+l: t2(l,k,b,c)
     //   tt(kappa,a,j,i): kappa<v: t2(i,j,a,d);                kappa=v+l: -<ij|al> = -v_oovo(i,j,a,l)
@@ -210,10 +212,25 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     Tensor ts = view(cx.scratch("t_ts", v2 * O * O), {V, V, O, O});    // ts(x,y,p,q)  = t2(p,q,x,y)
     permute_add(cx, 1.0, s.v_oovv, "pqxy", 0.0, vs, "xypq");
     permute_add(cx, 1.0, s.t2, "pqxy", 0.0, ts, "xypq");
-    k_fill(cx, cx.scal, 4, 0.0);
+    // completely renormalised mode: the same GEMMs with I_vovv_pp / -I_ooov_pp in place of <cb|kd> / -<ij|al>
+    //   vt2(kappa,b,c,k): kappa<v: I_vovv_pp(d,k,b,c);  kappa=v+l: t2(l,k,b,c)
+    //   tt2(kappa,a,j,i): kappa<v: t2(i,j,a,d);         kappa=v+l: -I_ooov_pp(j,i,l,a)      (ccsd.f90:2188-2193)
+    Tensor vt2, tt2;
+    double* Mpool = nullptr;
+    if (cr) {
+        vt2 = view(cx.scratch("t_vt2", Kc * v2 * O), {Kc, V, V, O});
+        tt2 = view(cx.scratch("t_tt2", Kc * V * O * O), {Kc, V, O, O});
+        permute_add(cx, 1.0, s.I_vovv_pp, "dkbc", 0.0, sub(vt2, 0, V), "dbck");
+        permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vt2, V, O), "lbck");
+        permute_add(cx, 1.0, s.t2, "ijad", 0.0, sub(tt2, 0, V), "daji");
+        permute_add(cx, -1.0, s.I_ooov_pp, "jila", 0.0, sub(tt2, V, O), "laji");
+        Mpool = cx.scratch("t_mpool", 6 * p->nb * v3);
+    }
+    const int nq = cr ? 6 : 4;
+    k_fill(cx, cx.scal, 6, 0.0);
     TriplesIn in{s.e, s.t1.d, vs.d, ts.d, s.t2.d, o, v};
     double* Xpool = cx.scratch("t_xpool", 6 * p->nb * v3);
-    double* partial = cx.scratch("t_partial", 4 * std::max<int64_t>((int64_t)p->norb * p->nb, 512));
+    double* partial = cx.scratch("t_partial", 6 * std::max<int64_t>((int64_t)p->norb * p->nb, 512));
     // one stream, no host round trip until the four sums are read back: chunk c+1's GEMMs overwrite the X pool only
     // after chunk c's orbit kernel has consumed it (stream order)
     std::vector<hipEvent_t> evs;
@@ -241,21 +258,32 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             gp.a_kcontig = gp.b_kcontig = true;
             gp.wide = (Kc % 2 == 0) && (V % 2 == 0);   // then every row/column offset above is even
             AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+            if (cr) {
+                GettProblem gm = gp;
+                gm.A = vt2.d + Kc * v2 * g.r;
+                gm.B = tt2.d;
+                gm.C = Mpool;
+                AFESP_HIP(gett_launch(gm, cx.ws, cx.stream));
+            }
             if (cx.prof) {
                 cx.prof_gemm_launches += 1;
                 cx.prof_gemm_flop += 2.0 * (double)gp.M * (double)gp.N * (double)gp.K;
             }
         }
         stamp();
-        hipLaunchKernelGGL(triples_orbit_kernel, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,
-                           p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
+        if (cr)
+            hipLaunchKernelGGL(triples_orbit_kernel<true>, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
+                               p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
+        else
+            hipLaunchKernelGGL(triples_orbit_kernel<false>, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
+                               p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
         AFESP_HIP(hipGetLastError());
         stamp();
         if (cx.prof) {
             cx.prof_orbit_launches += 1;
             cx.prof_orbit_bytes += 8.0 * 6.0 * (double)v3 * ch.nt;
         }
-        hipLaunchKernelGGL(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, p->norb * ch.nt);
+        hipLaunchKernelGGL(triples_sum_kernel, dim3(nq), dim3(256), 0, cx.stream, cx.scal, partial, p->norb * ch.nt);
         AFESP_HIP(hipGetLastError());
     }
     if (t_begin == 0) {
@@ -264,7 +292,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         hipLaunchKernelGGL(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, 256);
         AFESP_HIP(hipGetLastError());
     }
-    double* h = host_scalars(cx, 4);
+    double* h = host_scalars(cx, 6);
     for (size_t q = 0; q + 2 < evs.size(); q += 3) {
         float a = 0.f, b = 0.f;
         AFESP_HIP(hipEventElapsedTime(&a, evs[q], evs[q + 1]));
@@ -277,6 +305,10 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     out_host[1] = h[0] + h[1];     // E(T)            ccsd.f90:2220
     out_host[2] = h[2];            // D[T]
     out_host[3] = h[2] + h[3];     // D(T)            ccsd.f90:2232
+    if (cr) {
+        out_host[4] = h[4];            // sum t_bar.M3     ccsd.f90:2223-2224
+        out_host[5] = h[4] + h[5];     // + sum z_bar.M3   ccsd.f90:2225
+    }
 }
 
 }  // namespace afesp

@@ -42,7 +42,12 @@ __device__ __forceinline__ int cidx(int p0, int p1, int p2) { return ((p0 ^ p1 ^
 // Every X element is read from HBM exactly once (coalesced along its own leading index) and W never leaves LDS.
 // Thread t owns elements el = t + 256 r (r = 0..11): cube q = r/2 is a compile-time constant after unrolling, so
 // every permuted index below resolves to a fixed register.
+// CR = true additionally assembles the completely-renormalised moment M3 (ccsd.f90:2186-2194) from a second pool of
+// blocks (same offsets) and accumulates sum t_bar.M3, sum z_bar.M3 (ccsd.f90:2222-2226); M3 is only needed at (a,b,c)
+// itself, so it stays in registers.
+template <bool CR>
 __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restrict__ partial, const double* __restrict__ Xpool,
+                                                            const double* __restrict__ Mpool,
                                                             const TripleMeta* __restrict__ meta,
                                                             const int* __restrict__ orbits, TriplesIn in, int nblk_total)
 {
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
     __shared__ double wl[6 * CUBE];            // W on the six cubes of the orbit
     __shared__ int srcq[6][6];                 // srcq[s][q]: which cube of the orbit is sigma_s applied to cube q
     __shared__ int dup[6];                     // 1 if cube q repeats an earlier cube (degenerate orbit)
-    __shared__ double red[16];
+    __shared__ double red[24];
     const TripleMeta m = meta[blockIdx.y];
     const int o = in.o, v = in.v, t = threadIdx.x;
     const int packed = orbits[blockIdx.x];
@@ -94,6 +99,35 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
             wreg[r] += stage[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])];
         }
     }
+    double mreg[CR ? 12 : 1];
+    if (CR) {
+#pragma unroll
+        for (int r = 0; r < 12; ++r) mreg[CR ? r : 0] = 0.0;
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            const double* X = Mpool + m.xoff[s];
+            double xin[12];
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                const int q = r >> 1, l2 = l2h[r & 1];
+                const int g0 = tile[sig(q, 0)] * TT + l0, g1 = tile[sig(q, 1)] * TT + l1, g2 = tile[sig(q, 2)] * TT + l2;
+                const bool ok = g0 < v && g1 < v && g2 < v;
+                const double x = X[ok ? g0 + (int64_t)v * g1 + vv * g2 : 0];
+                xin[r] = ok ? x : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 12; ++r) stage[(r >> 1) * CUBE + cidx(l0, l1, l2h[r & 1])] = xin[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                const int q = r >> 1;
+                const int l[3] = {l0, l1, l2h[r & 1]};
+                mreg[CR ? r : 0] += stage[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])];
+            }
+        }
+        __syncthreads();   // every reader of `stage` is done before the patches overwrite it
+    }
 #pragma unroll
     for (int r = 0; r < 12; ++r) wl[(r >> 1) * CUBE + cidx(l0, l1, l2h[r & 1])] = wreg[r];
     __syncthreads();
@@ -118,7 +152,10 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
     }
     __syncthreads();
     const double eo = in.e[m.i] + in.e[m.j] + in.e[m.k];
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr int NQ = CR ? 6 : 4;
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
     // q stays a run-time (wave-uniform) loop counter here: fully unrolled, the scheduler hoists every LDS read of all
     // twelve elements and spills; the permutation of cube q then only enters through scalar address arithmetic.
 #pragma unroll 1
@@ -151,6 +188,14 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
             acc[1] += zbar * w;
             acc[2] += tbar * y;
             acc[3] += zbar * y;
+            if (CR) {
+                // mreg is indexed by r = 2q + h: select with a short compare chain (q is a run-time loop counter)
+                double mm = 0.0;
+#pragma unroll
+                for (int r = 0; r < 12; ++r) mm = (r == 2 * q + h) ? mreg[CR ? r : 0] : mm;
+                acc[NQ - 2] += tbar * mm;
+                acc[NQ - 1] += zbar * mm;
+            }
 #undef WAT
 #undef T1R
 #undef VP
@@ -159,14 +204,14 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
     }
     const int lane = t & 63, wv = t >> 6;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         double sdl = acc[q];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sdl += __shfl_down(sdl, off, 64);
         if (lane == 0) red[q * 4 + wv] = sdl;
     }
     __syncthreads();
-    if (t < 4) {
+    if (t < NQ) {
         const int blk = blockIdx.y * gridDim.x + blockIdx.x;
         partial[(int64_t)t * nblk_total + blk] = m.mult * (red[t * 4] + red[t * 4 + 1] + red[t * 4 + 2] + red[t * 4 + 3]);
     }

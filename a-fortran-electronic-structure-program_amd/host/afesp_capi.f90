@@ -6,7 +6,7 @@ module afesp_capi
    private
    public :: afesp_ctx_create, afesp_ctx_destroy, afesp_last_error, afesp_ao2mo_mp2, afesp_ccsd_init, afesp_ccsd_energy, &
              afesp_ccsd_iterate, afesp_ccsd_diis, afesp_ccsd_get_amplitudes, afesp_ccsd_t, afesp_ccsd_t_ntriples, &
-             afesp_neri, afesp_error_text
+             afesp_neri, afesp_error_text, afesp_ccsd_cr_intermediates, afesp_ccsd_t_cr
 
    interface
       function afesp_ctx_create(device, ctx) bind(C, name='afesp_ctx_create') result(rc)
@@ -92,6 +92,20 @@ module afesp_capi
          type(c_ptr), value :: ctx
          integer(c_int64_t), value :: t_begin, t_end
          real(c_double), intent(out) :: out(4)
+         integer(c_int) :: rc
+      end function
+      !> replaces build_cr_ccsd_t_intermediates (reference src/ccsd.f90:381)
+      function afesp_ccsd_cr_intermediates(ctx) bind(C, name='afesp_ccsd_cr_intermediates') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int) :: rc
+      end function
+      !> (T) with the completely renormalised moment sums: out = E[T], E(T), D[T], D(T), sum t_bar.M3, sum (t_bar+z_bar).M3
+      function afesp_ccsd_t_cr(ctx, t_begin, t_end, out) bind(C, name='afesp_ccsd_t_cr') result(rc)
+         import :: c_int, c_int64_t, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int64_t), value :: t_begin, t_end
+         real(c_double), intent(out) :: out(6)
          integer(c_int) :: rc
       end function
    end interface

@@ -36,7 +36,7 @@ module host_config
       integer :: scf_diis_n_errmat = 6, ccsd_diis_n_errmat = 8, scf_maxiter = 50, ccsd_maxiter = 50
       logical :: write_fcidump = .false., scf_read_guess = .false., scf_write_guess = .false.
       integer :: level = LEVEL_CCSD_T
-      logical :: paren = .false., renorm = .false.
+      logical :: paren = .false., renorm = .false., comp_renorm = .false.
    end type
 contains
    !> &elsinput namelist; keys that are absent keep the defaults above (the reference leaves them undefined).
@@ -71,8 +71,8 @@ contains
       case ('CCSD[T]_spatial');  cfg%level = LEVEL_CCSD_T
       case ('RCCSD(T)_spatial'); cfg%level = LEVEL_CCSD_T; cfg%paren = .true.; cfg%renorm = .true.
       case ('RCCSD[T]_spatial'); cfg%level = LEVEL_CCSD_T; cfg%renorm = .true.
-      case ('CRCCSD(T)_spatial', 'CRCCSD[T]_spatial')
-         call fail('system::read_system_in', 'completely renormalised CCSD(T) is not offloaded yet (use RCCSD(T)_spatial)')
+      case ('CRCCSD(T)_spatial'); cfg%level = LEVEL_CCSD_T; cfg%paren = .true.; cfg%comp_renorm = .true.
+      case ('CRCCSD[T]_spatial'); cfg%level = LEVEL_CCSD_T; cfg%comp_renorm = .true.
       case ('UHF', 'MP2_spinorb', 'CCSD_spinorb', 'CCSD(T)_spinorb')
          call fail('system::read_system_in', 'spin-orbital calculation types are not part of the MI355X engine')
       case default
@@ -374,8 +374,8 @@ program els_amd
    type(molecule) :: mol
    type(c_ptr) :: ctx
    real(dp), allocatable :: coeff(:, :), levels(:), t1(:, :)
-   real(dp) :: e_hf, e_mp2, e_ccsd, energy, eold, rms, tq(4), t0, t1s, tstart, t1diag, e_highest
-   real(dp) :: e_bt, e_pt, e_rbt, e_rpt
+   real(dp) :: e_hf, e_mp2, e_ccsd, energy, eold, rms, tq(6), t0, t1s, tstart, t1diag, e_highest
+   real(dp) :: e_bt, e_pt, e_rbt, e_rpt, e_crbt, e_crpt
    integer(c_int) :: rc, conv
    integer :: iter, device
    logical :: scf_ok, cc_ok, compat
@@ -401,7 +401,7 @@ program els_amd
    t1s = seconds()
    write (out, '(1X, A, 1X, F16.8, A)') 'Time taken for restricted Hartree-Fock:', t1s - t0, 's'
    e_highest = 0.0_dp; e_mp2 = 0.0_dp; e_ccsd = 0.0_dp; t1diag = 0.0_dp; tq = 0.0_dp; cc_ok = .false.
-   e_bt = 0.0_dp; e_pt = 0.0_dp; e_rbt = 0.0_dp; e_rpt = 0.0_dp
+   e_bt = 0.0_dp; e_pt = 0.0_dp; e_rbt = 0.0_dp; e_rpt = 0.0_dp; e_crbt = 0.0_dp; e_crpt = 0.0_dp
 
    if (cfg%level >= LEVEL_MP2 .and. scf_ok) then
       device = 0
@@ -467,6 +467,10 @@ program els_amd
             write (out, '(1X, A, 1X, F8.5)') 'T1 diagnostic:', t1diag
             if (t1diag > 0.02_dp) write (out, '(1X, A)') 'Significant multireference character detected, CCSD result might be unreliable!'
             e_ccsd = energy; e_highest = e_ccsd
+            if (cfg%comp_renorm) then          ! reference src/ccsd.f90:377-382
+               rc = afesp_ccsd_cr_intermediates(ctx)
+               if (rc /= 0) call fail('ccsd::build_cr_ccsd_t_intermediates', afesp_error_text(ctx))
+            end if
          end if
          write (out, '(1X, A, 1X, F16.8, A)') 'Time taken for restricted CCSD:', seconds() - t0, 's'
 
@@ -474,24 +478,34 @@ program els_amd
             ! ---------------- (T) (reference do_ccsd_t_spatial): whole (i<=j<=k) range on this GPU
             t0 = seconds()
             write (out, '(1X, 10("-"))'); write (out, '(1X, A)') 'CCSD(T)'; write (out, '(1X, 10("-"))')
-            rc = afesp_ccsd_t(ctx, 0_c_int64_t, afesp_ccsd_t_ntriples(int(mol%nocc, c_int64_t)), tq)
+            if (cfg%comp_renorm) then
+               rc = afesp_ccsd_t_cr(ctx, 0_c_int64_t, afesp_ccsd_t_ntriples(int(mol%nocc, c_int64_t)), tq)
+            else
+               rc = afesp_ccsd_t(ctx, 0_c_int64_t, afesp_ccsd_t_ntriples(int(mol%nocc, c_int64_t)), tq(1:4))
+            end if
             if (rc /= 0) call fail('ccsd::do_ccsd_t_spatial', afesp_error_text(ctx))
             ! The reference's plain CCSD(T)_spatial never fills z3_bar (src/ccsd.f90:2211-2215) and therefore prints
             ! E[T] on its "CCSD(T)" line.  AFESP_T_COMPAT=1 reproduces that printout; the default prints the (T) value
             ! the reference itself produces in its R/CR modes.
             call get_environment_variable('AFESP_T_COMPAT', envval)
-            compat = (trim(envval) == '1') .and. .not. cfg%renorm
+            compat = (trim(envval) == '1') .and. .not. (cfg%renorm .or. cfg%comp_renorm)
             e_bt = e_ccsd + tq(1)
             e_pt = e_ccsd + merge(tq(1), tq(2), compat)
             e_highest = e_bt
             if (cfg%paren) e_highest = e_pt
             calcname = merge('CCSD(T)', 'CCSD[T]', cfg%paren)
-            if (cfg%renorm) then
+            if (cfg%renorm .or. cfg%comp_renorm) then
                e_rbt = e_ccsd + tq(1)/tq(3)
                e_rpt = e_ccsd + tq(2)/tq(4)
                e_highest = merge(e_rpt, e_rbt, cfg%paren)
-               calcname = 'renormalised '//trim(calcname)
             end if
+            if (cfg%comp_renorm) then          ! reference src/ccsd.f90:2267-2274
+               e_crbt = e_ccsd + tq(5)/tq(3)
+               e_crpt = e_ccsd + tq(6)/tq(4)
+               e_highest = merge(e_crpt, e_crbt, cfg%paren)
+            end if
+            if (cfg%renorm) calcname = 'renormalised '//trim(calcname)
+            if (cfg%comp_renorm) calcname = 'completely renormalised '//trim(calcname)
             write (out, '(1X, A, 1X, F15.9)') 'Restricted '//trim(calcname)//' correlation energy (Hartree):', e_highest
             write (out, '(1X, A, 1X, F16.8, A)') 'Time taken for restricted '//trim(calcname)//':', seconds() - t0, 's'
          end if
@@ -520,12 +534,20 @@ program els_amd
          write (out, '(1X, A, 1X, F15.10)') 'CCSD(T) correlation energy:    ', e_pt
          write (out, '(1X, A, 1X, F15.10)') 'CCSD(T) energy:                ', e_pt + e_hf + mol%e_nuc
       end if
-      if (cfg%renorm) then
+      if (cfg%renorm .or. cfg%comp_renorm) then
          write (out, '(1X, A, 1X, F15.10)') 'R-CCSD[T] correlation energy:  ', e_rbt
          write (out, '(1X, A, 1X, F15.10)') 'R-CCSD[T] energy:              ', e_rbt + e_hf + mol%e_nuc
          if (cfg%paren) then
             write (out, '(1X, A, 1X, F15.10)') 'R-CCSD(T) correlation energy:  ', e_rpt
             write (out, '(1X, A, 1X, F15.10)') 'R-CCSD(T) energy:              ', e_rpt + e_hf + mol%e_nuc
+         end if
+         if (cfg%comp_renorm) then
+            write (out, '(1X, A, 1X, F15.10)') 'CR-CCSD[T] correlation energy: ', e_crbt
+            write (out, '(1X, A, 1X, F15.10)') 'CR-CCSD[T] energy:             ', e_crbt + e_hf + mol%e_nuc
+            if (cfg%paren) then
+               write (out, '(1X, A, 1X, F15.10)') 'CR-CCSD(T) correlation energy: ', e_crpt
+               write (out, '(1X, A, 1X, F15.10)') 'CR-CCSD(T) energy:             ', e_crpt + e_hf + mol%e_nuc
+            end if
          end if
       end if
    end if
@@ -533,7 +555,7 @@ program els_amd
       write (out, '(1X, 47("-"))')
       write (out, '(1X, A, 1X, F15.10)') 'T1 diagnostic:                 ', t1diag
    end if
-   if (cfg%renorm) then
+   if (cfg%renorm .or. cfg%comp_renorm) then
       write (out, '(1X, A, 1X, F15.10)') 'D[T]:                          ', tq(3)
       if (cfg%paren) write (out, '(1X, A, 1X, F15.10)') 'D(T):                          ', tq(4)
    end if

@@ -78,6 +78,14 @@ int afesp_ccsd_update_amplitudes(afesp_ctx* ctx);
 int64_t afesp_ccsd_t_ntriples(int64_t nocc);
 int afesp_ccsd_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[4]);
 
+/* Completely renormalised CCSD[T]/(T).  afesp_ccsd_cr_intermediates replaces
+ * build_cr_ccsd_t_intermediates (src/ccsd.f90:381, :2338-2551) and must be called on the converged amplitudes, before any
+ * further afesp_ccsd_iterate.  afesp_ccsd_t_cr = afesp_ccsd_t plus the generalised-moment sums:
+ *   out[4] = sum t_bar.M3 (src/ccsd.f90:2223-2224)   out[5] = out[4] + sum z_bar.M3 (:2225)
+ * so that E_CR[T] = out[4]/out[2] and E_CR(T) = out[5]/out[3] (src/ccsd.f90:2268-2272).  Same sharding contract. */
+int afesp_ccsd_cr_intermediates(afesp_ctx* ctx);
+int afesp_ccsd_t_cr(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[6]);
+
 /* Operator layer (src/linalg.fpp), exported for parity tests against the oracle.
  * afesp_gemm    = dgemm_wrapper (src/linalg.fpp:58-89): C(m x n) = alpha op(A) op(B) + beta C, host arrays.
  * afesp_permute4 = omp_reshape (src/linalg.fpp:99-156): out(perm) = beta*out + in; has_beta=0 zeroes `out` first. */

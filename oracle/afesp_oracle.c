@@ -19,6 +19,7 @@
  *   DIIS ........................... ccsd.f90:577-676, linalg.fpp:38-56
  *   (T): W, t3, z3, x_bar, sums .... ccsd.f90:2152-2237, :2295-2318
  *   R-CCSD denominators ............ ccsd.f90:2181-2185, :2228-2247
+ *   CR-CCSD(T) intermediates, M3 ... ccsd.f90:2338-2551, :2186-2194, :2222-2226
  *
  * Parity pin: tests/test_oracle_golden.py runs this restatement on the reference's
  * bundled N2 and F2 cc-pVDZ inputs and checks it against the reference's own bundled
@@ -124,6 +125,7 @@ typedef struct {
     /* intermediates */
     double *I_vo, *I_vv, *I_oo_p, *I_oo, *c, *asym, *x_voov, *I_oooo, *I_ovov, *I_voov, *I_vovv_p, *I_ooov_p;
     double *r1, *r2;
+    double *I_vovv_pp, *I_ooov_pp;               /* completely renormalised (T) moments, ccsd.f90:2338-2551 */
     double energy, energy_old, rms;
     /* DIIS (ccsd.f90:38-67) */
     int nerr, nact, it;
@@ -175,6 +177,7 @@ orc_cc *orc_cc_create(i64 o, i64 v, const double *eri_mo, const double *e, int d
     s->I_oooo = dalloc(o * o * o * o); s->I_ovov = dalloc(o2v2); s->I_voov = dalloc(o2v2);
     s->I_vovv_p = dalloc(o * v * v * v); s->I_ooov_p = dalloc(o * o * o * v);
     s->r1 = dalloc(o * v); s->r2 = dalloc(o2v2);
+    s->I_vovv_pp = dalloc(o * v * v * v); s->I_ooov_pp = dalloc(o * o * o * v);
 #define PHYS(p, q, r, t) eri_mo[orc_eri_index((p), (r), (q), (t))]
     for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) for (i64 j = 0; j < o; ++j) for (i64 i = 0; i < o; ++i) {
         OOVV(i, j, a, b) = PHYS(i, j, a + o, b + o);
@@ -209,7 +212,7 @@ void orc_cc_destroy(orc_cc *s)
     if (!s) return;
     double *p[] = {s->e, s->v_oovv, s->v_ovov, s->v_vvov, s->v_oovo, s->v_oooo, s->v_vvvv, s->D1, s->D2, s->t1, s->t2,
                    s->t2_old, s->I_vo, s->I_vv, s->I_oo_p, s->I_oo, s->c, s->asym, s->x_voov, s->I_oooo, s->I_ovov,
-                   s->I_voov, s->I_vovv_p, s->I_ooov_p, s->r1, s->r2, s->d_t1, s->d_e1, s->d_t2, s->d_e2, s->t1_s, s->t2_s};
+                   s->I_voov, s->I_vovv_p, s->I_ooov_p, s->r1, s->r2, s->I_vovv_pp, s->I_ooov_pp, s->d_t1, s->d_e1, s->d_t2, s->d_e2, s->t1_s, s->t2_s};
     for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); ++i) free(p[i]);
     free(s);
 }
@@ -495,15 +498,99 @@ double orc_cc_t1_diagnostic(const orc_cc *s, i64 nel)
     return sqrt(ddot(s->o * s->v, s->t1, s->t1)) / sqrt((double)nel);
 }
 
+/* ccsd.f90:2338-2551 build_cr_ccsd_t_intermediates.  Called after convergence: t1,t2 are the converged amplitudes while
+ * I_vo and asym_t2 are whatever the LAST update_restricted_intermediates left (i.e. built from the previous iterate) --
+ * exactly the reference's data flow (:2374-2378).  The inner `e` loop of I_ooov_pp runs over 1..nocc although e is a
+ * virtual index (:2535); that bound is reproduced because the bundled goldens contain it. */
+void orc_cc_cr_intermediates(orc_cc *s)
+{
+    const i64 o = O, v = V;
+    double *xvp = dalloc(v * v * v * o), *xv = dalloc(v * v * v * o), *xovov_p = dalloc(o * v * o * v), *xvoov_p = dalloc(o * v * o * v);
+    double *xovoo = dalloc(o * v * o * o), *xovov_pp = dalloc(o * v * o * v), *xvoov_pp = dalloc(o * v * o * v);
+#define XVP(b, c, a, i) xvp[(b) + v * ((c) + v * ((a) + v * (i)))]
+#define XV(b, c, a, i) xv[(b) + v * ((c) + v * ((a) + v * (i)))]
+#define XOVOVP(j, b, i, a) xovov_p[(j) + o * ((b) + v * ((i) + o * (a)))]
+#define XVOOVP(b, j, i, a) xvoov_p[(b) + v * ((j) + o * ((i) + o * (a)))]
+#define XOVOO(k, a, i, j) xovoo[(k) + o * ((a) + v * ((i) + o * (j)))]
+#define XOVOVPP(j, b, i, a) xovov_pp[(j) + o * ((b) + v * ((i) + o * (a)))]
+#define XVOOVPP(b, j, i, a) xvoov_pp[(b) + v * ((j) + o * ((i) + o * (a)))]
+#define IVOVVPP(c, i, a, b) s->I_vovv_pp[(c) + v * ((i) + o * ((a) + v * (b)))]
+#define IOOOVPP(j, k, i, a) s->I_ooov_pp[(j) + o * ((k) + o * ((i) + o * (a)))]
+    for (i64 i = 0; i < o; ++i) for (i64 a = 0; a < v; ++a) for (i64 c = 0; c < v; ++c) for (i64 b = 0; b < v; ++b) {
+        double x = 0.0;
+        for (i64 m = 0; m < o; ++m) x += T1(m, a) * OOVV(m, i, b, c);
+        XVP(b, c, a, i) = VVOV(c, b, i, a) - 0.5 * x;            /* :2429 */
+        XV(b, c, a, i) = VVOV(c, b, i, a) - x;                    /* :2465 */
+    }
+    for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i) for (i64 b = 0; b < v; ++b) for (i64 j = 0; j < o; ++j) {
+        double m1 = 0.0, m2 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0, e4 = 0.0;
+        for (i64 m = 0; m < o; ++m) { m1 += OOVO(m, i, b, j) * T1(m, a); m2 += OOVO(i, m, b, j) * T1(m, a); }
+        for (i64 e = 0; e < v; ++e) {
+            e1 += T1(j, e) * XVP(b, e, a, i); e2 += XVP(e, b, a, i) * T1(j, e);
+            e3 += T1(j, e) * XV(b, e, a, i);  e4 += XV(e, b, a, i) * T1(j, e);
+        }
+        XOVOVP(j, b, i, a) = OVOV(j, b, i, a) - 0.5 * m1 + e1;    /* :2441 */
+        XVOOVP(b, j, i, a) = OOVV(i, j, b, a) - 0.5 * m2 + e2;    /* :2453 */
+        XOVOVPP(j, b, i, a) = OVOV(j, b, i, a) - m1 + 0.5 * e3;   /* :2489 */
+        XVOOVPP(b, j, i, a) = OOVV(i, j, b, a) - m2 + 0.5 * e4;   /* :2501 */
+    }
+    for (i64 j = 0; j < o; ++j) for (i64 i = 0; i < o; ++i) for (i64 a = 0; a < v; ++a) for (i64 k = 0; k < o; ++k) {
+        double x = OOVO(j, i, a, k);
+        for (i64 e = 0; e < v; ++e) x += T1(k, e) * OOVV(i, j, e, a);
+        XOVOO(k, a, i, j) = x;                                     /* :2477 */
+    }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i) for (i64 c = 0; c < v; ++c) {
+        double x = VVOV(b, a, i, c);                                /* :2513-2520 */
+        for (i64 e = 0; e < v; ++e) x += VVVV(e, c, b, a) * T1(i, e);
+        for (i64 m = 0; m < o; ++m) x -= XOVOVP(i, c, m, a) * T1(m, b) + T1(m, a) * XVOOVP(c, i, m, b) + IVO(c, m) * T2(m, i, a, b);
+        for (i64 n = 0; n < o; ++n) for (i64 m = 0; m < o; ++m) x += T2(m, n, b, a) * XOVOO(i, c, m, n);
+        for (i64 m = 0; m < o; ++m) for (i64 e = 0; e < v; ++e)
+            x += XV(c, e, a, m) * AS(i, m, b, e) - XV(e, c, a, m) * T2(m, i, e, b) - T2(m, i, a, e) * XV(e, c, b, m);
+        IVOVVPP(c, i, a, b) = x;
+    }
+    const i64 ebound = o < v ? o : v;   /* reference loop bound `do e = 1, nocc` on a virtual index (:2535) */
+    for (i64 a = 0; a < v; ++a) for (i64 i = 0; i < o; ++i) for (i64 k = 0; k < o; ++k) for (i64 j = 0; j < o; ++j) {
+        double x = OOVO(k, j, a, i);                                /* :2532-2539 */
+        for (i64 m = 0; m < o; ++m) x -= OOOO(m, i, k, j) * T1(m, a);
+        for (i64 e = 0; e < v; ++e) x += XOVOVPP(j, e, i, a) * T1(k, e) + T1(j, e) * XVOOVPP(e, k, i, a);
+        for (i64 f = 0; f < v; ++f) for (i64 e = 0; e < v; ++e) x += T2(k, j, e, f) * XV(e, f, a, i);
+        for (i64 e = 0; e < ebound; ++e) for (i64 m = 0; m < o; ++m)
+            x += XOVOO(j, e, i, m) * AS(m, k, e, a) - XOVOO(j, e, m, i) * T2(m, k, e, a) - T2(m, j, a, e) * XOVOO(k, e, m, i);
+        IOOOVPP(j, k, i, a) = x;
+    }
+    free(xvp); free(xv); free(xovov_p); free(xvoov_p); free(xovoo); free(xovov_pp); free(xvoov_pp);
+}
+double *orc_cc_cr_field(orc_cc *s, int which) { return which == 0 ? s->I_vovv_pp : s->I_ooov_pp; }
+
 /* ---------------------------------------------------------------- (T) */
 /* ccsd.f90:2152-2237 as coded: all o^3 (i,j,k), W from the six permuted particle/hole terms (:2168-2173),
  * t3 = W/D (:2175), z3 (:2178-2179), y (:2183-2184), x_bar = 4/3 x(abc) - 2 x(acb) + 2/3 x(cab) (:2314-2318).
  * out[0]=E[T] (:2218-2219)  out[1]=E(T) with z_bar (:2220, the R/CR-mode value = the correct (T))
  * out[2]=D[T] out[3]=D(T) (:2228-2247, include the 1+2 t1^2+asym.c base term)
  * Triples (i,j,k) with flat index i*o*o+j*o+k in [t_begin,t_end) only (sharding / bounded timing). */
+static void orc_ccsd_t_impl(i64 o, i64 v, const double *e, const double *t1, const double *t2, const double *v_vvov,
+                            const double *v_oovo, const double *v_oovv, const double *Ivovv_pp, const double *Iooov_pp,
+                            i64 t_begin, i64 t_end, double *out);
 void orc_ccsd_t(i64 o, i64 v, const double *e, const double *t1, const double *t2, const double *v_vvov,
                 const double *v_oovo, const double *v_oovv, i64 t_begin, i64 t_end, double *out)
 {
+    double tmp[6];
+    orc_ccsd_t_impl(o, v, e, t1, t2, v_vvov, v_oovo, v_oovv, NULL, NULL, t_begin, t_end, tmp);
+    memcpy(out, tmp, 4 * sizeof(double));
+}
+/* out[4] = sum t_bar.M3 (E_CR[T] numerator), out[5] = that + sum z_bar.M3 (E_CR(T) numerator): ccsd.f90:2186-2194, :2222-2226 */
+void orc_ccsd_t_cr(i64 o, i64 v, const double *e, const double *t1, const double *t2, const double *v_vvov,
+                   const double *v_oovo, const double *v_oovv, const double *Ivovv_pp, const double *Iooov_pp, i64 t_begin,
+                   i64 t_end, double *out)
+{
+    orc_ccsd_t_impl(o, v, e, t1, t2, v_vvov, v_oovo, v_oovv, Ivovv_pp, Iooov_pp, t_begin, t_end, out);
+}
+static void orc_ccsd_t_impl(i64 o, i64 v, const double *e, const double *t1, const double *t2, const double *v_vvov,
+                            const double *v_oovo, const double *v_oovv, const double *Ivovv_pp, const double *Iooov_pp,
+                            i64 t_begin, i64 t_end, double *out)
+{
+    double eCR = 0.0, eCRT = 0.0;
     const i64 v3 = v * v * v;
     double eT = 0.0, eTT = 0.0, dT = 0.0, dTT = 0.0;
 #define t1_(i, a) t1[(i) + o * (a)]
@@ -512,8 +599,9 @@ void orc_ccsd_t(i64 o, i64 v, const double *e, const double *t1, const double *t
 #define oovo_(i, j, a, k) v_oovo[(i) + o * ((j) + o * ((a) + v * (k)))]
 #define oovv_(i, j, a, b) v_oovv[(i) + o * ((j) + o * ((a) + v * (b)))]
 /* X^{ijk}(a,b,c) = sum_d t2(i,j,a,d) <cb|kd> - sum_l t2(l,i,b,a) <kj|cl>   (:2168, operands per :2056-2066) */
-#pragma omp parallel reduction(+ : eT, eTT, dT, dTT)
+#pragma omp parallel reduction(+ : eT, eTT, dT, dTT, eCR, eCRT)
     {
+        double *M3 = (double *)malloc(sizeof(double) * v3);
         double *W = (double *)malloc(sizeof(double) * v3), *T3 = (double *)malloc(sizeof(double) * v3);
         double *Z = (double *)malloc(sizeof(double) * v3), *Y = (double *)malloc(sizeof(double) * v3);
         /* per-thread contiguous copies so the inner dot products run over unit stride */
@@ -552,18 +640,32 @@ void orc_ccsd_t(i64 o, i64 v, const double *e, const double *t1, const double *t
                 Z[x] = (t1_(i, a) * oovv_(j, k, b, c) + t1_(j, b) * oovv_(i, k, a, c) + t1_(k, c) * oovv_(i, j, a, b)) / D;
                 Y[x] = t1_(i, a) * t1_(j, b) * t1_(k, c) + t1_(i, a) * t2_(j, k, b, c) + t1_(j, b) * t2_(i, k, a, c)
                      + t1_(k, c) * t2_(i, j, a, b);
+                M3[x] = 0.0;
+                if (Ivovv_pp) {   /* ccsd.f90:2188-2193 */
+#define ipp_(d, q, y, z) Ivovv_pp[(d) + v * ((q) + o * ((y) + v * (z)))]
+#define iooov_(p, q, l, y) Iooov_pp[(p) + o * ((q) + o * ((l) + o * (y)))]
+                    double m3 = 0.0;
+                    for (i64 d = 0; d < v; ++d)
+                        m3 += t2_(i, j, a, d) * ipp_(d, k, b, c) + t2_(j, i, b, d) * ipp_(d, k, a, c) + t2_(k, j, c, d) * ipp_(d, i, b, a)
+                            + t2_(i, k, a, d) * ipp_(d, j, c, b) + t2_(j, k, b, d) * ipp_(d, i, c, a) + t2_(k, i, c, d) * ipp_(d, j, a, b);
+                    for (i64 l = 0; l < o; ++l)
+                        m3 -= t2_(l, i, b, a) * iooov_(j, k, l, c) + t2_(l, j, a, b) * iooov_(i, k, l, c) + t2_(l, k, b, c) * iooov_(j, i, l, a)
+                            + t2_(l, i, c, a) * iooov_(k, j, l, b) + t2_(l, j, c, b) * iooov_(k, i, l, a) + t2_(l, k, a, c) * iooov_(i, j, l, b);
+                    M3[x] = m3;
+                }
             }
             /* x_bar(a,b,c) = 4/3 x(a,b,c) - 2 x(a,c,b) + 2/3 x(c,a,b)  (:2314-2318) */
-            double s_tw = 0.0, s_zw = 0.0, s_ty = 0.0, s_zy = 0.0;
+            double s_tw = 0.0, s_zw = 0.0, s_ty = 0.0, s_zy = 0.0, s_tm = 0.0, s_zm = 0.0;
             for (i64 c = 0; c < v; ++c) for (i64 b = 0; b < v; ++b) for (i64 a = 0; a < v; ++a) {
                 const i64 x = a + v * (b + v * c), xacb = a + v * (c + v * b), xcab = c + v * (a + v * b);
                 const double tb = 4.0 * T3[x] / 3.0 - 2.0 * T3[xacb] + 2.0 * T3[xcab] / 3.0;
                 const double zb = 4.0 * Z[x] / 3.0 - 2.0 * Z[xacb] + 2.0 * Z[xcab] / 3.0;
                 s_tw += tb * W[x]; s_zw += zb * W[x]; s_ty += tb * Y[x]; s_zy += zb * Y[x];
+                s_tm += tb * M3[x]; s_zm += zb * M3[x];
             }
-            eT += s_tw; eTT += s_tw + s_zw; dT += s_ty; dTT += s_ty + s_zy;
+            eT += s_tw; eTT += s_tw + s_zw; dT += s_ty; dTT += s_ty + s_zy; eCR += s_tm; eCRT += s_tm + s_zm;
         }
-        free(W); free(T3); free(Z); free(Y); free(ta); free(va);
+        free(W); free(T3); free(Z); free(Y); free(ta); free(va); free(M3);
     }
     /* :2243: 1 + 2 sum t1^2 + sum asym_t2 * c_oovv (added once, only by the caller holding t_begin == 0) */
     if (t_begin == 0) {
@@ -573,7 +675,7 @@ void orc_ccsd_t(i64 o, i64 v, const double *e, const double *t1, const double *t
             base += (2.0 * t2_(i, j, a, b) - t2_(j, i, a, b)) * (t2_(i, j, a, b) + t1_(i, a) * t1_(j, b));
         dT += base; dTT += base;
     }
-    out[0] = eT; out[1] = eTT; out[2] = dT; out[3] = dTT;
+    out[0] = eT; out[1] = eTT; out[2] = dT; out[3] = dTT; out[4] = eCR; out[5] = eCRT;
 }
 
 /* ---------------------------------------------------------------- operator layer (linalg.fpp) */

@@ -57,6 +57,12 @@ def lib():
     L.orc_cc_t1_diagnostic.restype = dbl
     L.orc_ccsd_t.argtypes = [i64, i64, dp, dp, dp, dp, dp, dp, i64, i64, dp]
     L.orc_ccsd_t.restype = None
+    L.orc_ccsd_t_cr.argtypes = [i64, i64, dp, dp, dp, dp, dp, dp, dp, dp, i64, i64, dp]
+    L.orc_ccsd_t_cr.restype = None
+    L.orc_cc_cr_intermediates.argtypes = [C.c_void_p]
+    L.orc_cc_cr_intermediates.restype = None
+    L.orc_cc_cr_field.argtypes = [C.c_void_p, C.c_int]
+    L.orc_cc_cr_field.restype = C.POINTER(dbl)
     L.orc_gemm.argtypes = [C.c_int, C.c_int, i64, i64, i64, dbl, dp, dp, dbl, dp]
     L.orc_gemm.restype = None
     L.orc_permute4.argtypes = [C.POINTER(i64), C.c_char_p, dp, dp, C.c_int, dbl]
@@ -130,6 +136,32 @@ class OracleCC:
         self.L.orc_ccsd_t(o, v, np.ascontiguousarray(e), f(self.t1), f(self.t2), f(self.field("v_vvov")),
                           f(self.field("v_oovo")), f(self.field("v_oovv")), t_begin, t_end, out)
         return out
+
+
+def _cr_methods():
+    def cr_intermediates(self):
+        self.L.orc_cc_cr_intermediates(self.h)
+        o, v = self.o, self.v
+        return (self._view(self.L.orc_cc_cr_field(self.h, 0), (v, o, v, v)),
+                self._view(self.L.orc_cc_cr_field(self.h, 1), (o, o, o, v)))
+
+    def triples_cr(self, e, t_begin=0, t_end=None):
+        """-> out[6]: E[T], E(T), D[T], D(T), sum t_bar.M3, sum (t_bar+z_bar).M3 (call cr_intermediates first)"""
+        o, v = self.o, self.v
+        out = np.zeros(6)
+        if t_end is None:
+            t_end = o ** 3
+        f = lambda a: np.ascontiguousarray(a.ravel(order="F"))
+        ipp = self._view(self.L.orc_cc_cr_field(self.h, 0), (v, o, v, v))
+        ioo = self._view(self.L.orc_cc_cr_field(self.h, 1), (o, o, o, v))
+        self.L.orc_ccsd_t_cr(o, v, np.ascontiguousarray(e), f(self.t1), f(self.t2), f(self.field("v_vvov")),
+                             f(self.field("v_oovo")), f(self.field("v_oovv")), f(ipp), f(ioo), t_begin, t_end, out)
+        return out
+    OracleCC.cr_intermediates = cr_intermediates
+    OracleCC.triples_cr = triples_cr
+
+
+_cr_methods()
 
 
 def ao2mo(n, Cmat, eri_packed):

@@ -63,6 +63,31 @@ def test_molecule_full_path_matches_reference(eng, name):
     assert np.max(np.abs(parts - out)) < 1e-12
 
 
+@pytest.mark.parametrize("name", ["n2-cc-pvdz", "f2-cc-pvdz"])
+def test_completely_renormalised_triples_match_bundled_outputs(eng, name):
+    """CR-CCSD[T]/(T) (src/ccsd.f90:2338-2551): the numbers of the reference's bundled CRCCSD(T)_spatial runs."""
+    si, ints, res, gold = molecules.load(name)
+    n, o = ints.nbasis, ints.nel // 2
+    v = n - o
+    e_mp2, eri_mo = eng.do_mp2_spatial(n, o, res.canon_coeff, res.canon_levels, ints.eri)
+    eng.ccsd_init(o, v, res.canon_levels, None, si.ccsd_diis_n_errmat)
+    nit, en, rm = eng.do_ccsd_spatial(si.ccsd_maxiter, si.ccsd_e_tol, si.ccsd_t_tol)
+    eng.build_cr_intermediates()
+    out = eng.do_ccsd_t_spatial_cr()
+    cc = orc.OracleCC(o, v, eri_mo, res.canon_levels, si.ccsd_diis_n_errmat)
+    cc.solve(si.ccsd_maxiter, si.ccsd_e_tol, si.ccsd_t_tol)
+    cc.cr_intermediates()
+    ref = cc.triples_cr(res.canon_levels)
+    assert np.max(np.abs(out - ref)) < 1e-9
+    ec = en[nit]
+    assert abs(ec + out[4] / out[2] - gold["cr_ccsd_bt_corr"]) < 1e-8
+    assert abs(ec + out[5] / out[3] - gold["cr_ccsd_pt_corr"]) < 1e-8
+    assert abs(ec + out[1] / out[3] - gold["r_ccsd_pt_corr"]) < 1e-8
+    nt = eng.ntriples()
+    parts = sum(eng.do_ccsd_t_spatial_cr(b, min(b + 17, nt)) for b in range(0, nt, 17))
+    assert np.max(np.abs(parts - out)) < 1e-12
+
+
 def test_one_iteration_term_by_term(eng):
     """Every intermediate and both residuals after one update from non-trivial amplitudes (t1 != 0)."""
     o, v = 4, 9

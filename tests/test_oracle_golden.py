@@ -37,6 +37,13 @@ def test_oracle_reproduces_bundled_els_out(name):
     assert abs(ec + t[1] / t[3] - gold["r_ccsd_pt_corr"]) < 1e-9
     assert abs(t[2] - gold["d_bt"]) < 1e-9 and abs(t[3] - gold["d_pt"]) < 1e-9
     assert abs(cc.L.orc_cc_t1_diagnostic(cc.h, ints.nel) - gold["t1_diag"]) < 1e-9
+    # completely renormalised variants (ccsd.f90:2338-2551, :2186-2194): the calc_type of the bundled runs
+    cc.cr_intermediates()
+    tc = cc.triples_cr(res.canon_levels)
+    assert np.allclose(tc[:4], t, atol=1e-12)
+    assert abs(ec + tc[4] / tc[2] - gold["cr_ccsd_bt_corr"]) < 1e-9
+    assert abs(ec + tc[5] / tc[3] - gold["cr_ccsd_pt_corr"]) < 1e-9
+    assert abs(res.e_hf + ints.e_nuc + ec + tc[5] / tc[3] - gold["total"]) < 2e-9
 
 
 def test_oracle_h2o_matches_survey_recorded_reference_run():
