@@ -46,6 +46,18 @@ def test_host_rccsd_t_matches_reference_output(tmp_path, name):
         assert abs(got["total"] - (gold["rhf_total"] + gold["r_ccsd_pt_corr"])) < 2e-8
 
 
+@pytest.mark.parametrize("name", ["n2-cc-pvdz", "f2-cc-pvdz"])
+def test_host_runs_the_bundled_input_unchanged(tmp_path, name):
+    """The bundled els.in (calc_type = CRCCSD(T)_spatial) as shipped: the whole final energy table of the reference's
+    own els.out is reproduced (10 decimals printed)."""
+    res, got = run_host(tmp_path, name, "CRCCSD(T)_spatial")
+    assert res.returncode == 0, res.stderr
+    gold = inputs.parse_els_out(os.path.join(molecules.GOLDEN, name, "els.out"))
+    for key in ("rhf_total", "mp2_corr", "ccsd_corr", "ccsd_bt_corr", "ccsd_pt_corr", "r_ccsd_bt_corr", "r_ccsd_pt_corr",
+                "cr_ccsd_bt_corr", "cr_ccsd_pt_corr", "t1_diag", "d_bt", "d_pt", "e_nuc", "total"):
+        assert abs(got[key] - gold[key]) < 1e-8, (key, got[key], gold[key])
+
+
 def test_host_plain_ccsd_t_compat_printout(tmp_path):
     """Plain CCSD(T)_spatial: default prints the correct (T); AFESP_T_COMPAT=1 reproduces the reference's printout,
     whose CCSD(T) line equals CCSD[T] (src/ccsd.f90:2211-2215)."""
