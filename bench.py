@@ -129,14 +129,120 @@ def cpu_baseline(o, v, scale, seed, eng, budget_s=25.0):
             "sample": sample, "gflops": (flops_iter(o, v) + flops_t_ref(o, v)) / (t_iter + t_t) / 1e9}
 
 
+DEFAULT_SCALE = {"cfg5": 0.005}     # magnitude of the hashed integrals: keeps the first iterates of every workload finite
+
+
+def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch, with_roofline=True):
+    """Run `warmup` untimed + `steps` timed steps of one workload; returns the result dictionary (rank 0) or None."""
+    from afesp_amd.capi import Engine
+    from afesp_amd.dist import shard_range
+    o, v = WORKLOADS[workload]
+    scale = args.scale if args.scale is not None else DEFAULT_SCALE.get(workload, 0.02)
+    seed = 12345
+    eng = Engine(local)
+    eng.synthetic_init(o, v, scale, seed, 8)
+    eng.ccsd_energy()                                   # the "MP1" line: primes t2_old
+    nt = eng.ntriples()
+    lo, hi = shard_range(nt, rank, world)               # contiguous shard of the i<=j<=k list
+    red = torch.zeros(4, dtype=torch.float64, device=cdev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    acc = {"iter": 0.0, "trip": 0.0, "last": None}
+
+    def step(timed):
+        t0 = time.perf_counter()
+        eng.ccsd_iterate()
+        eng.ccsd_diis()
+        t1 = time.perf_counter()
+        part = eng.do_ccsd_t_spatial(lo, hi)
+        red.copy_(torch.from_numpy(part))
+        if dist is not None:
+            dist.all_reduce(red)                        # the only collective of the path: 4 doubles over xGMI
+        acc["last"] = red.cpu().numpy()
+        t2 = time.perf_counter()
+        if timed:
+            acc["iter"] += t1 - t0
+            acc["trip"] += t2 - t1
+
+    for _ in range(warmup):
+        step(False)
+    eng.profile(True)                                   # HIP-event stamps around the (T) launches from here on
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile(False)
+    tt = torch.tensor([elapsed, acc["iter"], acc["trip"]], dtype=torch.float64, device=cdev)
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed, t_iter, t_trip = [float(x) for x in tt.cpu()]
+    sec_per_step = elapsed / steps
+    flop_step = flops_iter(o, v) + flops_t_sym(o, v)
+    res = None
+    if rank == 0:
+        res = {
+            "value": flop_step / sec_per_step / 1e12, "ms_per_step": sec_per_step * 1e3,
+            "config": {"workload": f"{workload}: nocc={o} nvirt={v}, synthetic hashed ERIs scale {scale}; "
+                                   "step = 1 CCSD iteration (replicated) + full (T) over i<=j<=k sharded across ranks",
+                       "nocc": o, "nvirt": v, "triples": int(nt), "parallelism": f"(T) ijk-shard x{world}, CCSD replicas"},
+            "ccsd_iter_s": t_iter / steps, "t_s": t_trip / steps, "flop_per_step": flop_step,
+            "fraction_of_mfma_peak": flop_step / sec_per_step / 1e12 / (MFMA_F64_PEAK_TFLOPS * world),
+            "e_t": [float(x) for x in acc["last"]],
+        }
+        if with_roofline:
+            # Dominant kernel: the (T) GEMM (gett_kernel, X = tt^T vt over kappa = d + l, K = v+o), timed over the timed
+            # region with HIP events on the engine's stream (csrc/triples.hip).  Algorithmic flop per launch = 2 M N K.
+            nl = max(prof["gemm_launches"], 1)
+            roof = {"bound": "mfma", "achieved": prof["gemm_flop"] / max(prof["gemm_ms"], 1e-9) / 1e9,
+                    "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s"}
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof["traffic"] = None
+            roof["kernel"] = "gett_kernel, (T) launches: X(a,b,c|ijk) = sum_kappa tt(kappa;a,ij) vt(kappa;b,c,k), K = v+o"
+            roof["launches"] = prof["gemm_launches"]
+            roof["ms_per_launch"] = prof["gemm_ms"] / nl
+            roof["flop_per_launch"] = prof["gemm_flop"] / nl
+            roof["share_of_step_time"] = prof["gemm_ms"] * 1e-3 / elapsed
+            tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tfile):
+                tr = json.load(open(tfile)).get(workload + "_t_gemm")
+                if tr:
+                    roof["traffic"] = tr["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = tr["command"]
+            second = {"kernel": "triples_orbit_kernel", "bound": "hbm",
+                      "achieved": prof["orbit_bytes"] / max(prof["orbit_ms"], 1e-9) / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "ms_per_launch": prof["orbit_ms"] / max(prof["orbit_launches"], 1),
+                      "share_of_step_time": prof["orbit_ms"] * 1e-3 / elapsed}
+            second["frac"] = second["achieved"] / second["peak"]
+            ms_lad = eng.time_pp_ladder(20 if o * v < 2000 else 5)
+            res["roofline"] = roof
+            res["roofline_second_kernel"] = second
+            res["pp_ladder"] = {"ms_per_launch": ms_lad, "tflops": 2 * o**2 * v**4 / (ms_lad * 1e-3) / 1e12,
+                                "algorithmic_gbs": 8 * (v**4 + 2 * o**2 * v**2) / (ms_lad * 1e-3) / 1e9}
+        if args.cpu_baseline and with_roofline:
+            res["cpu_baseline"] = cpu_baseline(o, v, scale, seed, eng)
+    barrier()
+    eng.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="h2o_tz", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scale", type=float, default=0.02)
+    ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
+    ap.add_argument("--no-extra", dest="extra", action="store_false",
+                    help="skip the additional config-5 (o=20, v=200) measurement appended at N=1")
+    ap.add_argument("--scale", type=float, default=None)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo only to rehearse the multi-rank path on a one-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,110 +253,32 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "gloo":
+            local = 0                                   # rehearsal: every rank shares the one visible GPU
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(local)
+    cdev = "cpu" if (world > 1 and args.backend == "gloo") else f"cuda:{local}"   # where the collectives run
 
-    from afesp_amd.capi import Engine
-    from afesp_amd.dist import shard_range
-    o, v = WORKLOADS[args.workload]
-    seed = 12345
-    eng = Engine(local)
-    eng.synthetic_init(o, v, args.scale, seed, 8)
-    eng.ccsd_energy()                                   # the "MP1" line: primes t2_old
-    nt = eng.ntriples()
-    lo, hi = shard_range(nt, rank, world)                   # contiguous shard of the i<=j<=k list
-    red = torch.zeros(4, dtype=torch.float64, device=f"cuda:{local}")
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    t_iter = t_trip = 0.0
-    last = None
-
-    def step(timed):
-        nonlocal t_iter, t_trip, last
-        t0 = time.perf_counter()
-        eng.ccsd_iterate()
-        eng.ccsd_diis()
-        t1 = time.perf_counter()
-        part = eng.do_ccsd_t_spatial(lo, hi)
-        red.copy_(torch.from_numpy(part))
-        if dist is not None:
-            dist.all_reduce(red)                       # the only collective of the path: 4 doubles over xGMI
-        last = red.cpu().numpy()
-        t2 = time.perf_counter()
-        if timed:
-            t_iter += t1 - t0
-            t_trip += t2 - t1
-
-    for _ in range(args.warmup):
-        step(False)
-    eng.profile(True)                                   # HIP-event stamps around the (T) launches from here on
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile(False)
-    tt = torch.tensor([elapsed, t_iter, t_trip], dtype=torch.float64, device=f"cuda:{local}")
-    if dist is not None:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed, t_iter, t_trip = [float(x) for x in tt.cpu()]
-    sec_per_step = elapsed / args.steps
-    flop_step = flops_iter(o, v) + flops_t_sym(o, v)
-
+    res = measure(args, args.workload, args.steps, args.warmup, rank, world, local, dist, cdev, torch)
+    extra = None
+    if world == 1 and args.extra and args.workload != "cfg5":
+        # the only configuration where the fp64 MFMA roofline is meaningful: config 5, one step
+        extra = measure(args, "cfg5", 1, 1, rank, world, local, dist, cdev, torch, with_roofline=True)
     if rank == 0:
-        # Dominant kernel: the (T) GEMM (gett_kernel, X = tt^T vt over kappa = d + l, K = v+o), timed over the timed region
-        # with HIP events on the engine's stream (csrc/triples.hip).  Algorithmic flop per launch = 2 M N K of that launch.
-        nl = max(prof["gemm_launches"], 1)
-        ms_launch = prof["gemm_ms"] / nl
-        roof = {"bound": "mfma", "achieved": prof["gemm_flop"] / max(prof["gemm_ms"], 1e-9) / 1e9,
-                "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s"}
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None
-        roof["kernel"] = "gett_kernel, (T) launches: X(a,b,c|ijk) = sum_kappa tt(kappa;a,ij) vt(kappa;b,c,k), K = v+o"
-        roof["launches"] = prof["gemm_launches"]
-        roof["ms_per_launch"] = ms_launch
-        roof["flop_per_launch"] = prof["gemm_flop"] / nl
-        roof["share_of_step_time"] = prof["gemm_ms"] * 1e-3 / elapsed
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tfile):
-            tr = json.load(open(tfile)).get(args.workload + "_t_gemm")
-            if tr:
-                roof["traffic"] = tr["hbm_bytes_per_launch"]
-                roof["traffic_source"] = tr["command"]
-        second = {"kernel": "triples_orbit_kernel", "bound": "hbm",
-                  "achieved": prof["orbit_bytes"] / max(prof["orbit_ms"], 1e-9) / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "ms_per_launch": prof["orbit_ms"] / max(prof["orbit_launches"], 1),
-                  "share_of_step_time": prof["orbit_ms"] * 1e-3 / elapsed}
-        second["frac"] = second["achieved"] / second["peak"]
-        ms_lad = eng.time_pp_ladder(20 if o * v < 2000 else 5)
-        line = {
-            "metric": "CCSD iter wall-time (s) + (T) wall-time (s); fp64 TFLOP/s vs MFMA peak",
-            "value": flop_step / sec_per_step / 1e12, "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: nocc={o} nvirt={v}, synthetic hashed ERIs scale {args.scale}; "
-                                   "step = 1 CCSD iteration (replicated) + full (T) over i<=j<=k sharded across ranks",
-                       "nocc": o, "nvirt": v, "triples": int(nt), "parallelism": f"(T) ijk-shard x{world}, CCSD replicas"},
-            "ccsd_iter_s": t_iter / args.steps, "t_s": t_trip / args.steps,
-            "flop_per_step": flop_step, "fraction_of_mfma_peak": flop_step / sec_per_step / 1e12 / (MFMA_F64_PEAK_TFLOPS * world),
-            "e_t": [float(x) for x in last],
-            "roofline": roof,
-            "roofline_second_kernel": second,
-            "pp_ladder": {"ms_per_launch": ms_lad, "tflops": 2 * o**2 * v**4 / (ms_lad * 1e-3) / 1e12,
-                          "algorithmic_gbs": 8 * (v**4 + 2 * o**2 * v**2) / (ms_lad * 1e-3) / 1e9},
-        }
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(o, v, args.scale, seed, eng)
+        line = {"metric": "CCSD iter wall-time (s) + (T) wall-time (s); fp64 TFLOP/s vs MFMA peak",
+                "value": res.pop("value"), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic"}
+        line.update(res)
+        if extra is not None:
+            extra.pop("cpu_baseline", None)
+            line["config5_same_run"] = dict(extra, unit="TFLOP/s", steps=1, warmup=1)
         print(json.dumps(line))
-    barrier()
-    eng.close()
     if dist is not None:
         dist.destroy_process_group()
 
