@@ -91,7 +91,8 @@ void k_div(Context& cx, double* out, const double* num, const double* den, int64
 void k_antisym_pair(Context& cx, double* out, const double* in, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
                     int which);   // which=0: 2x - x(swap idx 0,1)   which=1: 2x - x(swap idx 2,3)
 void k_asym_c(Context& cx, double* asym, double* c, const double* t1, const double* t2, int o, int v);
-void k_t2_update(Context& cx, double* t2, const double* r2, const double* v_oovv, const double* D2, int o, int v);
+void k_t2_update(Context& cx, double* t2, const double* r2, const double* v_oovv, const double* D2, const double* pp, int o, int v);
+void k_r2_full(Context& cx, double* out, const double* r2, const double* pp, int o, int v);
 void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v);
 // out[0] = sum (2 v(ijab) - v(ijba)) (t2 + t1 t1), out[1] = sum (t2 - t2_old)^2 ; then t2_old = t2
 void k_cc_energy(Context& cx, double* out2, const double* v_oovv, const double* t1, const double* t2, double* t2_old,

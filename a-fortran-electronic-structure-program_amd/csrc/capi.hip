@@ -286,7 +286,13 @@ int afesp_ccsd_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t
             if (!strcmp(e.n, name)) {
                 if (e.t->size() > capacity) throw Error(1, std::string("afesp_ccsd_get_tensor: buffer too small for ") + name);
                 AFESP_HIP(hipSetDevice(ctx->cx.device));
-                AFESP_HIP(hipMemcpyAsync(out, e.t->d, sizeof(double) * e.t->size(), hipMemcpyDeviceToHost, ctx->cx.stream));
+                const double* src = e.t->d;
+                if (!strcmp(name, "r2")) {   // the reference's tmp_t2 before P(ia/jb) includes 1/2 pp; it is kept packed here
+                    double* full = ctx->cx.scratch("r2_full", e.t->size());
+                    k_r2_full(ctx->cx, full, s.r2.d, s.pp, s.o, s.v);
+                    src = full;
+                }
+                AFESP_HIP(hipMemcpyAsync(out, src, sizeof(double) * e.t->size(), hipMemcpyDeviceToHost, ctx->cx.stream));
                 ctx->cx.sync();
                 return;
             }
@@ -496,9 +502,9 @@ int afesp_time_pp_ladder(afesp_ctx* ctx, int reps, double* ms_per_launch)
         hipEvent_t a, b;
         AFESP_HIP(hipEventCreate(&a));
         AFESP_HIP(hipEventCreate(&b));
-        contract(cx, 0.5, s.c, "ijef", s.v_vvvv, "efab", 0.0, s.r2, "ijab");   // warm (plan + caches)
+        ccsd_pp_ladder(cx, s);   // warm
         AFESP_HIP(hipEventRecord(a, cx.stream));
-        for (int r = 0; r < reps; ++r) contract(cx, 0.5, s.c, "ijef", s.v_vvvv, "efab", 0.0, s.r2, "ijab");
+        for (int r = 0; r < reps; ++r) ccsd_pp_ladder(cx, s);
         AFESP_HIP(hipEventRecord(b, cx.stream));
         AFESP_HIP(hipEventSynchronize(b));
         float ms = 0.f;

@@ -11,6 +11,8 @@ struct CCState {
     // integral slices (ccsd.f90:507-512) and their immutable "2x - x^T" companions
     Tensor v_oovv, v_ovov, v_vvov, v_oovo, v_oooo, v_vvvv, w_oovv, w_vvov, w_oovo;
     Tensor D1, D2, t1, t2, t2_old, r1, r2;
+    double* pp = nullptr;          // packed particle-particle ladder PP(i,j,p), p over a <= b
+    int64_t* pp_tab = nullptr;     // offset tables of the pp-ladder GEMM: [Am | k | Bk | n]
     Tensor I_vo, I_vv, I_oo_p, I_oo, c, asym, x_voov, I_oooo, I_ovov, I_voov, I_vovv_p, I_ooov_p;
     // DIIS ring (ccsd.f90:38-67): vectors are [t1 ; t2] concatenated, length nvec
     int nerr = 0, nact = 0, it = 0;
@@ -32,6 +34,7 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
 void ccsd_diis_save(Context& cx, CCState& s);
 void ccsd_intermediates(Context& cx, CCState& s);
 void ccsd_amplitudes(Context& cx, CCState& s);
+void ccsd_pp_ladder(Context& cx, CCState& s);
 // updates s.energy / s.energy_old / s.rms (un-rooted, as ccsd.f90:1806); returns 1 if converged
 int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol);
 void ccsd_diis_update(Context& cx, CCState& s);

@@ -50,6 +50,22 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     s.c = cx.tensor({O, O, V, V}); s.asym = cx.tensor({O, O, V, V}); s.x_voov = cx.tensor({V, O, O, V});
     s.I_oooo = cx.tensor({O, O, O, O}); s.I_ovov = cx.tensor({O, V, O, V}); s.I_voov = cx.tensor({V, O, O, V});
     s.I_vovv_p = cx.tensor({V, O, V, V}); s.I_ooov_p = cx.tensor({O, O, O, V});
+    // pp-ladder (ccsd.f90:1669) over the symmetry-unique column pairs a <= b: rows p of <ef|ab> viewed as [ef x ab]
+    {
+        const int64_t np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
+        std::vector<int64_t> tab;
+        tab.reserve((size_t)(np + 2 * K2 + N2));
+        for (int64_t b = 0; b < V; ++b)
+            for (int64_t a = 0; a <= b; ++a) tab.push_back((a + V * b) * K2);     // offAm[p]: column (a,b) of v_vvvv
+        for (int64_t k = 0; k < K2; ++k) tab.push_back(k);                        // offAk[(e,f)]
+        for (int64_t k = 0; k < K2; ++k) tab.push_back(N2 * k);                   // offBk[(e,f)] in c(i,j,e,f)
+        for (int64_t x = 0; x < N2; ++x) tab.push_back(x);                        // offBn = offCn[(i,j)]
+        for (int64_t pz = 0; pz < np; ++pz) tab.push_back(N2 * pz);               // offCm[p] in PP(i,j,p)
+        s.pp_tab = cx.alloc_i64((int64_t)tab.size());
+        AFESP_HIP(hipMemcpyAsync(s.pp_tab, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
+        cx.sync();
+        s.pp = cx.alloc(N2 * np);
+    }
     // ccsd.f90:520-521: t1 = 0, t2 = v_oovv / D
     k_div(cx, s.t2.d, s.v_oovv.d, s.D2.d, o2v2);
     // ccsd.f90:577-615
@@ -73,7 +89,7 @@ void ccsd_free(Context& cx, CCState& s)
     double* bufs[] = {s.e, s.v_oovv.d, s.v_ovov.d, s.v_vvov.d, s.v_oovo.d, s.v_oooo.d, s.v_vvvv.d, s.w_oovv.d, s.w_vvov.d,
                       s.w_oovo.d, s.D1.d, s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.I_vo.d, s.I_vv.d, s.I_oo_p.d, s.I_oo.d, s.c.d,
                       s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_vovv_p.d, s.I_ooov_p.d, s.amp_s, s.hist_t,
-                      s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d};
+                      s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d, s.pp, (double*)s.pp_tab};
     for (double* b : bufs) cx.release(b);
     cx.drop_scratch();
     triples_plan_free(s);
@@ -130,6 +146,24 @@ void ccsd_intermediates(Context& cx, CCState& s)
     C(1.0, s.t1, "je", s.x_voov, "ekia", 1.0, s.I_ooov_p, "jkia");
 }
 
+// Particle-particle ladder (src/ccsd.f90:1669), the O(o^2 v^4) term.  pp(ijab) = sum_ef c(ij,ef) <ef|ab> obeys
+// pp(ijab) = pp(jiba), so only the v(v+1)/2 column pairs a <= b are contracted (half the flops of the reference's dgemm);
+// the packed result PP(ij,p) enters the amplitude update directly (t2_update_kernel) instead of being accumulated into r2.
+void ccsd_pp_ladder(Context& cx, CCState& s)
+{
+    const int64_t O = s.o, V = s.v, np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
+    GettProblem gp;
+    gp.A = s.v_vvvv.d; gp.B = s.c.d; gp.C = s.pp;
+    gp.offAm = s.pp_tab; gp.offAk = s.pp_tab + np; gp.offBk = s.pp_tab + np + K2; gp.offBn = s.pp_tab + np + 2 * K2;
+    gp.offCm = s.pp_tab + np + 2 * K2 + N2; gp.offCn = gp.offBn;
+    gp.M = (int)np; gp.N = (int)N2; gp.K = (int)K2;
+    gp.alpha = 1.0; gp.beta = 0.0;
+    gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
+    gp.a_kcontig = true; gp.b_kcontig = false;
+    gp.wide = (O % 2 == 0) && (V % 2 == 0) && (np % 2 == 0);
+    AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+}
+
 void ccsd_amplitudes(Context& cx, CCState& s)
 {
     auto C = [&](double al, const Tensor& A, const char* la, const Tensor& B, const char* lb, double be, const Tensor& Cc,
@@ -145,7 +179,7 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     // ---- T2, Eq. 44                                                    ccsd.f90:1637-1716
     C(1.0, s.t2, "ijae", s.I_vv, "eb", 0.0, s.r2, "ijab");                 // :1647
     C(-1.0, s.t2, "miba", s.I_oo, "jm", 1.0, s.r2, "ijab");                // :1654-1664
-    C(0.5, s.c, "ijef", s.v_vvvv, "efab", 1.0, s.r2, "ijab");              // :1669  particle-particle ladder
+    ccsd_pp_ladder(cx, s);                                                 // :1669  particle-particle ladder
     C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");              // :1673  hole-hole ladder
     C(-1.0, s.t2, "mjae", s.I_ovov, "iemb", 1.0, s.r2, "ijab");            // :1680-1695 ring terms
     C(-1.0, s.I_ovov, "iema", s.t2, "mjeb", 1.0, s.r2, "ijab");
@@ -154,7 +188,7 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     C(-1.0, s.t1, "ma", s.I_ooov_p, "ijmb", 1.0, s.r2, "ijab");            // :1705-1715
     // P(ia/jb), + v_oovv, Jacobi divide                                  ccsd.f90:1720-1728
     k_div(cx, s.t1.d, s.r1.d, s.D1.d, s.t1.size());
-    k_t2_update(cx, s.t2.d, s.r2.d, s.v_oovv.d, s.D2.d, s.o, s.v);
+    k_t2_update(cx, s.t2.d, s.r2.d, s.v_oovv.d, s.D2.d, s.pp, s.o, s.v);
 }
 
 int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol)

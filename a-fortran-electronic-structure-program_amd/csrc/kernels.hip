@@ -73,8 +73,10 @@ __global__ void asym_c_kernel(double* asym, double* c, const double* t1, const d
     }
 }
 
-// t2 = (r2(ijab) + r2(jiba) + v_oovv) / D2   (ccsd.f90:1720-1728)
-__global__ void t2_update_kernel(double* t2, const double* r2, const double* voovv, const double* D2, int o, int v)
+// t2 = (r2(ijab) + r2(jiba) + v_oovv) / D2   (ccsd.f90:1720-1728).  The particle-particle ladder pp(ijab) =
+// sum_ef c(ij,ef) <ef|ab> satisfies pp(ijab) = pp(jiba), so it is computed for a <= b only and stored packed as
+// PP(i,j,p), p = b(b+1)/2 + a; its contribution to r2(ijab) + r2(jiba) is 2 * 1/2 * pp = PP (ccsd.f90:1669).
+__global__ void t2_update_kernel(double* t2, const double* r2, const double* voovv, const double* D2, const double* pp, int o, int v)
 {
     const int64_t n = (int64_t)o * o * v * v;
     GRID_STRIDE(x, n)
@@ -85,7 +87,9 @@ __global__ void t2_update_kernel(double* t2, const double* r2, const double* voo
         r /= o;
         int a = (int)(r % v), b = (int)(r / v);
         int64_t y = j + (int64_t)o * (i + (int64_t)o * (b + (int64_t)v * a));
-        t2[x] = (r2[x] + r2[y] + voovv[x]) / D2[x];
+        const int64_t lad = (a <= b) ? i + (int64_t)o * (j + (int64_t)o * ((int64_t)b * (b + 1) / 2 + a))
+                                     : j + (int64_t)o * (i + (int64_t)o * ((int64_t)a * (a + 1) / 2 + b));
+        t2[x] = (r2[x] + r2[y] + pp[lad] + voovv[x]) / D2[x];
     }
 }
 
@@ -261,9 +265,29 @@ void k_asym_c(Context& cx, double* asym, double* c, const double* t1, const doub
 {
     LAUNCH(asym_c_kernel, dim3(grid_for((int64_t)o * o * v * v)), asym, c, t1, t2, o, v);
 }
-void k_t2_update(Context& cx, double* t2, const double* r2, const double* v_oovv, const double* D2, int o, int v)
+void k_t2_update(Context& cx, double* t2, const double* r2, const double* v_oovv, const double* D2, const double* pp, int o, int v)
 {
-    LAUNCH(t2_update_kernel, dim3(grid_for((int64_t)o * o * v * v)), t2, r2, v_oovv, D2, o, v);
+    LAUNCH(t2_update_kernel, dim3(grid_for((int64_t)o * o * v * v)), t2, r2, v_oovv, D2, pp, o, v);
+}
+// r2_full(ijab) = r2(ijab) + 1/2 pp(ijab): the residual as the reference holds it before P(ia/jb) (tests / get_tensor)
+__global__ void r2_full_kernel(double* out, const double* r2, const double* pp, int o, int v)
+{
+    const int64_t n = (int64_t)o * o * v * v;
+    GRID_STRIDE(x, n)
+    {
+        int i = (int)(x % o);
+        int64_t r = x / o;
+        int j = (int)(r % o);
+        r /= o;
+        int a = (int)(r % v), b = (int)(r / v);
+        const int64_t lad = (a <= b) ? i + (int64_t)o * (j + (int64_t)o * ((int64_t)b * (b + 1) / 2 + a))
+                                     : j + (int64_t)o * (i + (int64_t)o * ((int64_t)a * (a + 1) / 2 + b));
+        out[x] = r2[x] + 0.5 * pp[lad];
+    }
+}
+void k_r2_full(Context& cx, double* out, const double* r2, const double* pp, int o, int v)
+{
+    LAUNCH(r2_full_kernel, dim3(grid_for((int64_t)o * o * v * v)), out, r2, pp, o, v);
 }
 void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v)
 {

@@ -32,8 +32,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def flops_iter(o, v):
-    """sum over every contraction site of one CCSD iteration."""
-    return (2 * o**2 * v**4 + 14 * o**3 * v**3 + 2 * o**4 * v**2 + 2 * o**4 * v + 18 * o**2 * v**3 + 2 * o * v**3
+    """sum over every contraction site of one CCSD iteration -- with the pp-ladder counted as it is
+    executed here (only the v(v+1)/2 symmetry-unique column pairs: o^2 v^2 v(v+1) instead of 2 o^2 v^4), the same
+    "count the algorithm that is timed" rule as for (T)."""
+    return (o**2 * v**2 * v * (v + 1) + 14 * o**3 * v**3 + 2 * o**4 * v**2 + 2 * o**4 * v + 18 * o**2 * v**3 + 2 * o * v**3
             + 14 * o**3 * v**2)
 
 
@@ -222,8 +224,9 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             ms_lad = eng.time_pp_ladder(20 if o * v < 2000 else 5)
             res["roofline"] = roof
             res["roofline_second_kernel"] = second
-            res["pp_ladder"] = {"ms_per_launch": ms_lad, "tflops": 2 * o**2 * v**4 / (ms_lad * 1e-3) / 1e12,
-                                "algorithmic_gbs": 8 * (v**4 + 2 * o**2 * v**2) / (ms_lad * 1e-3) / 1e9}
+            res["pp_ladder"] = {"ms_per_launch": ms_lad, "tflops_executed": o**2 * v**3 * (v + 1) / (ms_lad * 1e-3) / 1e12,
+                                "tflops_reference_equivalent": 2 * o**2 * v**4 / (ms_lad * 1e-3) / 1e12,
+                                "algorithmic_gbs": 8 * (v**3 * (v + 1) / 2 + 2 * o**2 * v**2) / (ms_lad * 1e-3) / 1e9}
         if args.cpu_baseline and with_roofline:
             res["cpu_baseline"] = cpu_baseline(o, v, scale, seed, eng)
     barrier()

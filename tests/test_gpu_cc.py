@@ -128,6 +128,34 @@ def test_h2o_tz_shape_synthetic(eng):
     assert np.max(np.abs(out - ref)) < 1e-9
 
 
+@pytest.mark.parametrize("o,v", [(1, 3), (2, 2), (3, 8), (6, 4), (4, 16), (8, 8), (2, 17), (5, 9)])
+def test_ragged_and_degenerate_extents(eng, o, v):
+    """Edge shapes: o > v, single occupied, v below / not a multiple of the 8-wide cube and 16-deep K tiles, even and odd
+    extents (16-byte and 8-byte staging paths).  Three iterations with DIIS, then (T) and CR-(T), against the oracle."""
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05, seed=o * 100 + v)
+    cc = orc.OracleCC(o, v, eri, e, 3)
+    eng.ccsd_init(o, v, e, eri, 3)
+    L = cc.L
+    eng.ccsd_energy(1e-12, 1e-12)
+    L.orc_cc_energy(cc.h, 1e-12, 1e-12)
+    for it in range(3):
+        ge, gr, _ = eng.ccsd_iterate(1e-12, 1e-12)
+        eng.ccsd_diis()
+        L.orc_cc_diis_save(cc.h); L.orc_cc_intermediates(cc.h); L.orc_cc_amplitudes(cc.h); L.orc_cc_energy(cc.h, 1e-12, 1e-12)
+        assert abs(ge - cc.energy) < 1e-11 and abs(gr - L.orc_cc_get_rms(cc.h)) < 1e-11, (it, ge, cc.energy)
+        L.orc_cc_diis_update(cc.h)
+    t1, t2 = eng.amplitudes()
+    assert np.max(np.abs(t1 - cc.t1)) < 1e-11 and np.max(np.abs(t2 - cc.t2)) < 1e-11
+    out = eng.do_ccsd_t_spatial()
+    ref = cc.triples(e)
+    assert np.max(np.abs(out - ref)) < 1e-10, (out, ref)
+    eng.build_cr_intermediates()
+    ipp, ioo = cc.cr_intermediates()
+    outc = eng.do_ccsd_t_spatial_cr()
+    refc = cc.triples_cr(e)
+    assert np.max(np.abs(outc - refc)) < 1e-10, (outc, refc)
+
+
 def test_ccsd_without_diis_and_nonconvergence_is_silent(eng):
     o, v = 3, 6
     n, e, eri = molecules.synthetic_system(o, v, scale=0.05)
