@@ -341,15 +341,34 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     int tm = force_tm ? force_tm : pick_t(p.M), tn = force_tn ? force_tn : pick_t(p.N);
     // tall problems with 16-byte staging: the 256x128 tile (8 waves, 4x4 MFMA grid per wave) halves the staging
     // instructions per MFMA once more (62 TF against 55 TF for 128x128 on the o^3 v^3 ring contraction at o=20, v=200)
-    if (!force_tm && !force_tn && tm == 4 && tn == 4 && wide && p.M >= 2048) { tm = 16; tn = 8; }
+    const int ksteps = (p.K + BK - 1) / BK;
+    int wq_split = 0;
+    if (!force_tm && !force_tn && tm == 4 && tn == 4 && wide && p.M >= 2048) {
+        // Wave quantisation: 256 CUs take one workgroup each, so a grid of 316 tiles runs as 256 + 60.  Score the two tile
+        // shapes with 1..4 K slices by (relative tile speed) x (fill of the last round) and keep the best.
+        auto score = [&](int bm, int bn, int s, double rate) {
+            const int64_t work = (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nbatch * s;
+            const int64_t rounds = (work + 255) / 256;
+            const double waste = (double)((p.M + bm - 1) / bm * bm) * ((p.N + bn - 1) / bn * bn) / ((double)p.M * p.N);
+            return rate * (double)work / (double)(rounds * 256) / waste * (s > 1 ? 0.96 : 1.0);
+        };
+        double best = 0.0;
+        for (int big = 0; big < 2; ++big)
+            for (int s = 1; s <= 4; ++s) {
+                if (s > 1 && (force_split > 0 || ksteps / s < 32)) continue;
+                const double sc = score(big ? 256 : 128, 128, s, big ? 1.0 : 0.89);
+                if (sc > best * 1.02) { best = sc; tm = big ? 16 : 4; tn = big ? 8 : 4; wq_split = s; }
+            }
+    }
     const int BM = tm == 16 ? 256 : tm == 8 ? 128 : 32 * tm, BN = tn == 16 ? 256 : tn == 8 ? 128 : 32 * tn;
     a.mtiles = (p.M + BM - 1) / BM;
     a.ntiles = (p.N + BN - 1) / BN;
     const int64_t tiles = (int64_t)a.mtiles * a.ntiles * p.nbatch;
-    const int ksteps = (p.K + BK - 1) / BK;
     int split = 1;
     if (force_split > 0) {
         split = force_split;
+    } else if (wq_split > 1) {
+        split = wq_split;
     } else if (tiles < 192 && ksteps >= 8) {
         // too few tiles to fill 256 CUs: slice K, at least 4 K steps per slice, aim for ~2 blocks per CU
         split = (int)((512 + tiles - 1) / tiles);
