@@ -43,6 +43,8 @@ struct Plan {
     int64_t *offAm, *offAk, *offBk, *offBn, *offCm, *offCn;
     int M, N, K;
     bool swapped, a_kc, b_kc, wide;
+    int repack = 0;                 // 1/2: caller's first/second operand is re-laid-out into scratch before the product
+    int64_t repack_stride[6] = {0, 0, 0, 0, 0, 0};
 };
 
 struct Context {
@@ -50,6 +52,7 @@ struct Context {
     hipStream_t stream = nullptr;
     std::vector<void*> owned;             // everything freed at destroy
     GettWorkspace ws{nullptr, 0};
+    bool in_repack = false;               // set while contract() runs on a re-laid-out operand
     double* scal = nullptr;               // small device scratch for reductions (64 doubles)
     double* scal_host = nullptr;          // pinned mirror
     std::map<std::string, Plan> plans;

@@ -205,11 +205,56 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
         char afast = min_stride_label(A, la), bfast = min_stride_label(B, lb);
         sort_by(N, 2);
         sort_by(M, has(M, afast) ? 0 : 2);
-        if (has(K, afast)) sort_by(K, 0);
+        // both operands want their own fastest label first in K: the larger one is the one that streams from HBM
+        if (has(K, afast) && has(K, bfast)) sort_by(K, B.size() > 4 * A.size() ? 1 : 0);
+        else if (has(K, afast)) sort_by(K, 0);
         else if (has(K, bfast)) sort_by(K, 1);
         else sort_by(K, 0);
         Plan p;
         p.swapped = swapped;
+        // An operand whose unit-stride label leads neither its free nor its contracted enumeration is read 8 bytes per
+        // 64-byte line on every K step.  When the product is large enough to pay for it, re-lay it out once into scratch
+        // (free labels in C order first, then K) and plan again on the copy.
+        {
+            auto lead = [](const std::vector<Lab>& g) {
+                for (auto& l : g)
+                    if (l.dim > 1) return l.c;
+                return (char)0;
+            };
+            const bool a_ok = lead(K) == afast || lead(M) == afast || A.size() <= 4096;
+            const bool b_ok = lead(K) == bfast || lead(N) == bfast || B.size() <= 4096;
+            int64_t Md = 1, Nd = 1;
+            for (auto& l : M) Md *= l.dim;
+            for (auto& l : N) Nd *= l.dim;
+            const int64_t limit = (int64_t)1 << 28;
+            int which = 0;   // 1 = A, 2 = B (kernel roles)
+            if (nbatch == 1 && !bA0 && !bB0 && !cx.in_repack) {
+                if (!b_ok && Md >= 512 && B.size() <= limit) which = 2;
+                else if (!a_ok && Nd >= 512 && A.size() <= limit) which = 1;
+            }
+            if (which) {
+                const Tensor& T = which == 1 ? A : B;
+                const char* lt = which == 1 ? la : lb;
+                std::vector<Lab> F = which == 1 ? M : N;
+                sort_by(F, 2);
+                int64_t run = 1;
+                auto place = [&](const std::vector<Lab>& g) {
+                    for (auto& l : g) {
+                        p.repack_stride[std::strchr(lt, l.c) - lt] = run;
+                        run *= l.dim;
+                    }
+                };
+                place(F);
+                place(K);
+                (void)T;
+                p.repack = (which == 1) != swapped ? 1 : 2;
+                p.offAm = p.offAk = p.offBk = p.offBn = p.offCm = p.offCn = nullptr;
+                p.M = p.N = p.K = 0;
+                p.a_kc = p.b_kc = p.wide = false;
+                it = cx.plans.emplace(key, p).first;
+            }
+        }
+        if (it == cx.plans.end()) {
         p.a_kc = !K.empty() && K[0].c == afast && K[0].sa == 1;
         p.b_kc = !K.empty() && K[0].c == bfast && K[0].sb == 1;
         auto tAm = table(M, 0), tAk = table(K, 0), tBk = table(K, 1), tBn = table(N, 1), tCm = table(M, 2), tCn = table(N, 2);
@@ -232,8 +277,27 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
         p.offAm = upload(cx, tAm); p.offAk = upload(cx, tAk); p.offBk = upload(cx, tBk);
         p.offBn = upload(cx, tBn); p.offCm = upload(cx, tCm); p.offCn = upload(cx, tCn);
         it = cx.plans.emplace(key, p).first;
+        }
     }
     const Plan& p = it->second;
+    if (p.repack) {
+        const Tensor& src = p.repack == 1 ? A0 : B0;
+        Tensor packed = src;
+        for (int i = 0; i < src.rank; ++i) packed.stride[i] = p.repack_stride[i];
+        packed.d = cx.scratch("repack:" + key, src.size());
+        const char* ls = p.repack == 1 ? la0 : lb0;
+        permute_add(cx, 1.0, src, ls, 0.0, packed, ls);
+        cx.in_repack = true;
+        try {
+            contract(cx, alpha, p.repack == 1 ? packed : A0, la0, p.repack == 2 ? packed : B0, lb0, beta, C, lc, nbatch, bA0, bB0,
+                     bC, force_split, force_tm, force_tn);
+        } catch (...) {
+            cx.in_repack = false;
+            throw;
+        }
+        cx.in_repack = false;
+        return;
+    }
     GettProblem g;
     g.A = p.swapped ? B0.d : A0.d;
     g.B = p.swapped ? A0.d : B0.d;
