@@ -453,7 +453,7 @@ int afesp_profile(afesp_ctx* ctx, int enable, double out[6])
 
 int afesp_set_tuning(int group_m, int force_tm, int force_tn, int force_split)
 {
-    g_allow_wide = !(group_m & 0x10000); group_m &= 0xffff;
+    g_allow_wide = !(group_m & 0x10000); g_dbg = (group_m >> 17) & 7; group_m &= 0xffff;
     g_group_m = group_m; g_force_tm = force_tm; g_force_tn = force_tn; g_force_split = force_split;
     return 0;
 }

@@ -67,6 +67,15 @@ struct Stager {
             rowoff[r] = offMN[mn < MN ? mn : MN - W];   // (W = 2: MN is even, so MN - 2 is the last group)
         }
     }
+    // row (or column) offsets of another tile, same operand
+    __device__ __forceinline__ void rows(const int64_t* offMN, int mn0, int MN, int t)
+    {
+#pragma unroll
+        for (int r = 0; r < NROW; ++r) {
+            int mn = mn0 + T::mn_of(t, r);
+            rowoff[r] = offMN[mn < MN ? mn : MN - W];
+        }
+    }
     // offsets of the K step starting at k0 (clamped: always a valid table entry)
     __device__ __forceinline__ void fetch_ko(int k0, int t)
     {
@@ -113,6 +122,7 @@ struct GettKernelArgs {
     double* ws;   // partial sums [z][split][M][N] when ksplit > 1
     int mtiles, ntiles;
     int gm;       // m-tiles per group (tile walk order)
+    int dbg;      // measurement only: bit 0 skips the epilogue stores
 };
 
 // XCD-aware bijective remap (cdna_hip_programming.md T1): blocks b, b+8, b+16... share an XCD (and its L2);
@@ -136,23 +146,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
     const GettProblem& p = a.p;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave % WM, wn = wave / WM;
-    // Grouped order: a group is `gm` m-tiles x all n-tiles walked m-fastest, so that the ~32 workgroups co-resident on
-    // one XCD form a near-square patch of C and both operand panels are re-used out of that XCD's L2.
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int width = a.gm * a.ntiles, grp = tile / width, first = grp * a.gm;
-    const int gsz = min(a.mtiles - first, a.gm), rem = tile - grp * width;
-    const int m0 = (first + rem % gsz) * BM, n0 = (rem / gsz) * BN;
     const int z = blockIdx.z, split = blockIdx.y;
     const int kbeg = split * a.kchunk;
     const int kend = min(p.K, kbeg + a.kchunk);
-
     const double* Ab = p.A + (p.batchA ? p.batchA[z] : 0);
     const double* Bb = p.B + (p.batchB ? p.batchB[z] : 0);
 
-    Stager<BM, AKC, NT, W> stA;
-    Stager<BN, BKC, NT, W> stB;
-    stA.init(Ab, p.offAm, p.offAk, m0, p.M, p.K, t);
-    stB.init(Bb, p.offBn, p.offBk, n0, p.N, p.K, t);
+    // Persistent workgroups: block b owns tiles b, b + gridDim.x, ... and runs their K steps as ONE stream -- the
+    // gathers of the next tile's first steps are issued under the MFMAs of this tile's last steps and the C stores of
+    // a finished tile drain under the next tile's MFMAs.  (Measured at M=40000, N=8192, K=224 with one tile per
+    // workgroup: 57 us of MFMA per tile, 7 us of exposed first-load latency and 4 us of store drain.)
+    // Tile order: a group is `gm` m-tiles x all n-tiles walked m-fastest, so that the ~32 workgroups co-resident on one
+    // XCD form a near-square patch of C and both operand panels are re-used out of that XCD's L2; within a round of
+    // gridDim.x tiles the XCD remap gives each XCD consecutive ids.
+    const int ntiles_all = a.mtiles * a.ntiles;
+    const int ntl = (ntiles_all - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto origin = [&](int j, int& m0, int& n0) {
+        const int r0 = j * (int)gridDim.x;
+        const int tile = r0 + xcd_remap(blockIdx.x, min((int)gridDim.x, ntiles_all - r0));
+        const int width = a.gm * a.ntiles, grp = tile / width, first = grp * a.gm;
+        const int gsz = min(a.mtiles - first, a.gm), rem = tile - grp * width;
+        m0 = (first + rem % gsz) * BM;
+        n0 = (rem / gsz) * BN;
+    };
 
     v4d acc[TM][TN];
 #pragma unroll
@@ -160,26 +176,109 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    // Register ring of depth 2: while the MFMAs of step kt run, the data of steps kt+1 (set P) and kt+2 (set Q) and the
-    // offsets of step kt+3 are in flight; set P is written to LDS after the MFMAs.  Two K steps (~8k cycles of MFMA at
+    // epilogue: lane l, register r of accumulator (i,j) is C[m0 + wm*16*TM + 16i + (l>>4) + 4r][n0 + ... + (l&15)]
+    auto store_tile = [&](int m0, int n0) {
+        if (a.dbg & 1) return;
+        const int nl = n0 + wn * 16 * TN + (lane & 15);
+        const int ml = m0 + wm * 16 * TM + (lane >> 4);
+        if (a.ksplit == 1) {
+            double* Cb = p.C + (p.batchC ? p.batchC[z] : 0);
+            int64_t cn[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int n = nl + 16 * j;
+                cn[j] = p.offCn[n < p.N ? n : p.N - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int m = ml + 16 * i + 4 * r;
+                    if (m >= p.M) continue;
+                    int64_t cm = p.offCm[m];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        int n = nl + 16 * j;
+                        if (n >= p.N) continue;
+                        double* dst = Cb + cm + cn[j];
+                        double val = p.alpha * acc[i][j][r];
+                        if (p.beta != 0.0) val += p.beta * *dst;
+                        *dst = val;
+                    }
+                }
+        } else {
+            double* slab = a.ws + ((int64_t)z * a.ksplit + split) * (int64_t)p.M * p.N;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int m = ml + 16 * i + 4 * r;
+                    if (m >= p.M) continue;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        int n = nl + 16 * j;
+                        if (n < p.N) slab[(int64_t)m * p.N + n] = acc[i][j][r];
+                    }
+                }
+        }
+    };
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk <= 0) {   // empty contraction: C = beta*C
+        for (int j = 0; j < ntl; ++j) {
+            int m0, n0;
+            origin(j, m0, n0);
+            store_tile(m0, n0);
+        }
+        return;
+    }
+    const bool ragged = ((kend - kbeg) % BK) != 0;   // the last step of every tile is partial
+    const int G = ntl * nk;                          // K steps in this workgroup's stream
+
+    // Gather cursors.  Data fetches run two stream steps ahead of the MFMAs, their K offsets three steps ahead; when the
+    // data cursor leaves a tile the row/column offsets of the next tile are reloaded in place (they are dead until the
+    // next fetch, three MFMA groups later).
+    Stager<BM, AKC, NT, W> stA;
+    Stager<BN, BKC, NT, W> stB;
+    int fkt = 0, ftile = 0, kok = 0;
+    {
+        int m0, n0;
+        origin(0, m0, n0);
+        stA.init(Ab, p.offAm, p.offAk, m0, p.M, p.K, t);
+        stB.init(Bb, p.offBn, p.offBk, n0, p.N, p.K, t);
+    }
+    auto advance_fetch = [&]() {
+        if (++fkt == nk) {
+            fkt = 0;
+            if (++ftile < ntl) {
+                int m0, n0;
+                origin(ftile, m0, n0);
+                stA.rows(p.offAm, m0, p.M, t);
+                stB.rows(p.offBn, n0, p.N, t);
+            }
+        }
+    };
+    auto next_ko = [&]() {
+        stA.fetch_ko(kbeg + kok * BK, t);
+        stB.fetch_ko(kbeg + kok * BK, t);
+        kok = (kok + 1 == nk) ? 0 : kok + 1;
+    };
+
+    // Register ring of depth 2: while the MFMAs of step g run, the data of steps g+1 (set P) and g+2 (set Q) and the
+    // offsets of step g+3 are in flight; set P is written to LDS after the MFMAs.  Two K steps (~8k cycles of MFMA at
     // TM=TN=4) cover the loaded HBM latency with a single wave per SIMD.
     double ra0[TA::PER][W], rb0[TB::PER][W], ra1[TA::PER][W], rb1[TB::PER][W];
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    const bool ragged = ((kend - kbeg) % BK) != 0;   // the last step is partial
-    if (nk > 0) {
-        stA.fetch_ko(kbeg, t);
-        stB.fetch_ko(kbeg, t);
-        stA.fetch(ra0);
-        stB.fetch(rb0);
-        stA.fetch_ko(kbeg + BK, t);
-        stB.fetch_ko(kbeg + BK, t);
-        stA.stash(lds, ra0, t, kbeg, kend, ragged && nk == 1);
-        stB.stash(lds + TA::SIZE, rb0, t, kbeg, kend, ragged && nk == 1);
-        stA.fetch(ra1);                       // step 1 (clamped if it does not exist)
-        stB.fetch(rb1);
-        stA.fetch_ko(kbeg + 2 * BK, t);
-        stB.fetch_ko(kbeg + 2 * BK, t);
-    }
+    next_ko();
+    stA.fetch(ra0);
+    stB.fetch(rb0);
+    advance_fetch();
+    next_ko();
+    stA.stash(lds, ra0, t, kbeg, kend, ragged && nk == 1);
+    stB.stash(lds + TA::SIZE, rb0, t, kbeg, kend, ragged && nk == 1);
+    stA.fetch(ra1);                       // step 1 (stale but valid addresses if it does not exist)
+    stB.fetch(rb1);
+    advance_fetch();
+    next_ko();
     __syncthreads();
 
     const int fa = wm * 16 * TM + (lane & 15), fb = wn * 16 * TN + (lane & 15), fk = lane >> 4;
@@ -200,91 +299,58 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
             for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
-    if (nk > 0) frag(af0, bf0, lds, lds + TA::SIZE, 0);
-    // One K step.  On entry set 0 holds sub-step 0 of LDS buffer `cur`.  Register set (pa,pb) holds the gathered data of
-    // step kt+1 and is written to the other LDS buffer; set (qa,qb) receives step kt+2.  The single barrier sits between
-    // sub-steps 2 and 3: every read of buffer `cur` has been issued before it and every write of buffer cur^1 is
+    frag(af0, bf0, lds, lds + TA::SIZE, 0);
+    // One stream step.  On entry set 0 holds sub-step 0 of LDS buffer `cur`.  Register set (pa,pb) holds the gathered
+    // data of step g+1 and is written to the other LDS buffer; set (qa,qb) receives step g+2.  The single barrier sits
+    // between sub-steps 2 and 3: every read of buffer `cur` has been issued before it and every write of buffer cur^1 is
     // complete, so after it the next step's first fragments can be read while sub-step 3 still multiplies.
+    int kt = 0, ctile = 0;
 #define AFESP_GETT_STEP(qa, qb, pa, pb)                                                         \
     {                                                                                           \
-        const int cur = kt & 1;                                                                 \
+        const int cur = g & 1;                                                                  \
         const double* cA = lds + cur * STAGE;                                                   \
         const double* cB = cA + TA::SIZE;                                                       \
-        const bool ld = kt + 2 < nk, st = kt + 1 < nk;                                          \
-        const bool tail = ragged && (kt + 2 == nk);                                             \
+        const bool ld = g + 2 < G, st = g + 1 < G;                                              \
+        const int ktn = (kt + 1 == nk) ? 0 : kt + 1;                                            \
+        const bool tail = ragged && (ktn == nk - 1);                                            \
         frag(af1, bf1, cA, cB, 1);                                                              \
         if (ld) stA.fetch(qa);                                                                  \
         mfma(af0, bf0);                                                                         \
         frag(af0, bf0, cA, cB, 2);                                                              \
-        if (ld) stB.fetch(qb);                                                                  \
+        if (ld) {                                                                               \
+            stB.fetch(qb);                                                                      \
+            advance_fetch();                                                                    \
+        }                                                                                       \
         mfma(af1, bf1);                                                                         \
         frag(af1, bf1, cA, cB, 3);                                                              \
-        if (ld) {                                                                               \
-            stA.fetch_ko(kbeg + (kt + 3) * BK, t);                                              \
-            stB.fetch_ko(kbeg + (kt + 3) * BK, t);                                              \
-        }                                                                                       \
+        if (ld) next_ko();                                                                      \
         if (st) {                                                                               \
-            stA.stash(lds + (cur ^ 1) * STAGE, pa, t, kbeg + (kt + 1) * BK, kend, tail);        \
-            stB.stash(lds + (cur ^ 1) * STAGE + TA::SIZE, pb, t, kbeg + (kt + 1) * BK, kend, tail); \
+            stA.stash(lds + (cur ^ 1) * STAGE, pa, t, kbeg + ktn * BK, kend, tail);             \
+            stB.stash(lds + (cur ^ 1) * STAGE + TA::SIZE, pb, t, kbeg + ktn * BK, kend, tail);  \
         }                                                                                       \
         mfma(af0, bf0);                                                                         \
         __syncthreads();                                                                        \
         if (st) frag(af0, bf0, lds + (cur ^ 1) * STAGE, lds + (cur ^ 1) * STAGE + TA::SIZE, 0); \
         mfma(af1, bf1);                                                                         \
+        if (ktn == 0) {                                                                         \
+            int m0, n0;                                                                         \
+            origin(ctile, m0, n0);                                                              \
+            store_tile(m0, n0);                                                                 \
+            ++ctile;                                                                            \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                      \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0}; \
+        }                                                                                       \
+        kt = ktn;                                                                               \
     }
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
+    int g = 0;
+    for (; g + 1 < G; g += 2) {
         AFESP_GETT_STEP(ra0, rb0, ra1, rb1)
-        ++kt;
+        ++g;
         AFESP_GETT_STEP(ra1, rb1, ra0, rb0)
-        --kt;
+        --g;
     }
-    if (kt < nk) AFESP_GETT_STEP(ra0, rb0, ra1, rb1)
+    if (g < G) AFESP_GETT_STEP(ra0, rb0, ra1, rb1)
 #undef AFESP_GETT_STEP
-
-    // epilogue: lane l, register r of accumulator (i,j) is C[m0 + wm*16*TM + 16i + (l>>4) + 4r][n0 + ... + (l&15)]
-    const int nl = n0 + wn * 16 * TN + (lane & 15);
-    const int ml = m0 + wm * 16 * TM + (lane >> 4);
-    if (a.ksplit == 1) {
-        double* Cb = p.C + (p.batchC ? p.batchC[z] : 0);
-        int64_t cn[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int n = nl + 16 * j;
-            cn[j] = p.offCn[n < p.N ? n : p.N - 1];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int m = ml + 16 * i + 4 * r;
-                if (m >= p.M) continue;
-                int64_t cm = p.offCm[m];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    int n = nl + 16 * j;
-                    if (n >= p.N) continue;
-                    double* dst = Cb + cm + cn[j];
-                    double val = p.alpha * acc[i][j][r];
-                    if (p.beta != 0.0) val += p.beta * *dst;
-                    *dst = val;
-                }
-            }
-    } else {
-        double* slab = a.ws + ((int64_t)z * a.ksplit + split) * (int64_t)p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int m = ml + 16 * i + 4 * r;
-                if (m >= p.M) continue;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    int n = nl + 16 * j;
-                    if (n < p.N) slab[(int64_t)m * p.N + n] = acc[i][j][r];
-                }
-            }
-    }
 }
 
 // Deterministic split-K combine: fixed summation order over the split index.
@@ -306,15 +372,39 @@ __global__ __launch_bounds__(256) void gett_reduce_kernel(GettKernelArgs a)
     }
 }
 
+int g_dbg = 0;
+
+// Resident workgroups the device holds for one kernel instantiation (CUs x occupancy), found once per instantiation.
+template <typename Kern>
+static int resident_blocks(Kern kern, int threads)
+{
+    int dev = 0, cus = 256, occ = 1;
+    if (hipGetDevice(&dev) != hipSuccess) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, 0) != hipSuccess || occ <= 0) occ = 1;
+    return cus * occ;
+}
+
+template <int WM, int WN, int TM, int TN, bool AK, bool BK_, int W>
+static void launch_one(const GettKernelArgs& a, dim3 grid, hipStream_t st)
+{
+    static const int cap = resident_blocks(gett_kernel<WM, WN, TM, TN, AK, BK_, W>, 64 * WM * WN);
+    // persistent grid: no more workgroups than the device holds at once, the rest of the tiles are walked in-kernel
+    int per = cap / (int)(grid.y * grid.z);
+    if (per < 1) per = 1;
+    if (g_dbg & 2) per = 1 << 30;   // measurement only: one tile per workgroup
+    if ((int)grid.x > per) grid.x = (unsigned)per;
+    hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, AK, BK_, W>), grid, dim3(64 * WM * WN), 0, st, a);
+}
+
 template <int WM, int WN, int TM, int TN, int W>
 static void launch_cfg(const GettKernelArgs& a, dim3 grid, hipStream_t st)
 {
     const bool ak = a.p.a_kcontig, bk = a.p.b_kcontig;
-    const dim3 blk(64 * WM * WN);
-    if (ak && bk) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, true, true, W>), grid, blk, 0, st, a);
-    else if (ak) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, true, false, W>), grid, blk, 0, st, a);
-    else if (bk) hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, false, true, W>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, false, false, W>), grid, blk, 0, st, a);
+    if (ak && bk) launch_one<WM, WN, TM, TN, true, true, W>(a, grid, st);
+    else if (ak) launch_one<WM, WN, TM, TN, true, false, W>(a, grid, st);
+    else if (bk) launch_one<WM, WN, TM, TN, false, true, W>(a, grid, st);
+    else launch_one<WM, WN, TM, TN, false, false, W>(a, grid, st);
 }
 
 int g_group_m = 0;   // >0 overrides the tile-walk group size (tuning knob, see afesp_set_tuning)
@@ -386,6 +476,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     a.ksplit = (ksteps + steps_per - 1) / steps_per;
     if (a.ksplit < 1) a.ksplit = 1;
     a.ws = ws.ptr;
+    a.dbg = g_dbg;
     a.gm = g_group_m > 0 ? g_group_m : (a.ntiles >= 8 ? 4 : a.ntiles >= 4 ? 8 : a.ntiles >= 2 ? 16 : 32);
     if (a.gm > a.mtiles) a.gm = a.mtiles;
     dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)a.ksplit, (unsigned)p.nbatch);
