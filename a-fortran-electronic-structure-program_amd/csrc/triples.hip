@@ -91,11 +91,12 @@ static TriplesPlan* plan_for(Context& cx, CCState& s, int64_t t_begin, int64_t t
     p = new TriplesPlan();
     s.tplan = p;
     const int o = s.o, v = s.v;
-    const int64_t O = o, V = v, v2 = V * V, v3 = v2 * V, Kc = (V + O + 15) / 16 * 16;   // padded, see ccsd_triples
+    const int64_t O = o, V = v, Kc = (V + O + 15) / 16 * 16;   // padded, see ccsd_triples
     p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = cr;
     // chunk size: 6 X blocks of v^3 doubles per triple (W never leaves LDS); a few dozen ordered triples per k-group keep
     // the GEMM column count in the thousands, more buys nothing
-    const int64_t per = (cr ? 12 : 6) * v3 * (int64_t)sizeof(double);   // CR mode keeps a second pool for the M3 blocks
+    const int64_t nt8 = (V + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;   // a block is stored cube by cube, edges padded to 8
+    const int64_t per = (cr ? 12 : 6) * vp3 * (int64_t)sizeof(double);   // CR mode keeps a second pool for the M3 blocks
     int64_t nb = std::max<int64_t>(1, ((int64_t)24 << 30) / per);
     nb = std::min<int64_t>(nb, 4096);
     nb = std::min<int64_t>(nb, std::max<int64_t>(1, t_end - t_begin));
@@ -108,7 +109,8 @@ static TriplesPlan* plan_for(Context& cx, CCState& s, int64_t t_begin, int64_t t
         for (int64_t b = 0; b < V; ++b) tab.push_back(Kc * (b + V * c));      // rows (b,c) of vt(:,b,c,k)
     p->off_Cm = (int64_t)tab.size();
     for (int64_t c = 0; c < V; ++c)
-        for (int64_t b = 0; b < V; ++b) tab.push_back(V * b + v2 * c);        // rows (b,c) of X(a,b,c)
+        for (int64_t b = 0; b < V; ++b)                                       // rows (b,c) of X(a,b,c), cube-blocked
+            tab.push_back(CUBE * nt8 * (b / TT) + TT * (b % TT) + CUBE * nt8 * nt8 * (c / TT) + TT * TT * (c % TT));
     std::vector<TripleMeta> metas;
     struct Ord { int p, q, r; int64_t buf; };
     std::vector<Ord> ords;
@@ -127,7 +129,7 @@ static TriplesPlan* plan_for(Context& cx, CCState& s, int64_t t_begin, int64_t t
                 if (od.r == r)
                     for (int64_t a = 0; a < V; ++a) {
                         hBn.push_back(Kc * (a + V * (od.q + O * od.p)));   // tt(:, a, q, p)
-                        hCn.push_back(a + v3 * od.buf);
+                        hCn.push_back(CUBE * (a / TT) + a % TT + vp3 * od.buf);
                     }
             const int64_t N = (int64_t)hBn.size() - start;
             if (N > 0) ch.groups.push_back({r, start, N});
@@ -155,7 +157,7 @@ static TriplesPlan* plan_for(Context& cx, CCState& s, int64_t t_begin, int64_t t
                         if (P[r][0] == P[q][0] && P[r][1] == P[q][1] && P[r][2] == P[q][2]) { found = r; break; }
                     if (found >= 0) { m.xoff[q] = m.xoff[found]; continue; }
                     const int64_t buf = (int64_t)ords.size();
-                    m.xoff[q] = buf * v3;
+                    m.xoff[q] = buf * vp3;
                     ords.push_back({P[q][0], P[q][1], P[q][2], buf});
                 }
                 cur.push_back(m);
@@ -163,7 +165,6 @@ static TriplesPlan* plan_for(Context& cx, CCState& s, int64_t t_begin, int64_t t
             }
     flush();
     // orbits of 8x8x8 cubes under index permutation: tile triples A <= B <= C
-    const int nt8 = (v + TT - 1) / TT;
     std::vector<int> orb;
     for (int A = 0; A < nt8; ++A)
         for (int B = A; B < nt8; ++B)
@@ -191,6 +192,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     if (!s.ready) throw Error(1, "ccsd_triples: no converged CCSD state in this context");
     const int o = s.o, v = s.v;
     const int64_t O = o, V = v, v2 = V * V, v3 = V * V * V;
+    const int64_t nt8 = (V + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;   // stored size of one X block (cube-blocked)
     // the summed extent v+o is padded with zero rows to whole K steps of the GEMM: a ragged last step costs ~8 % of a
     // 14-step tile (measured: K=220 49 TF, K=224 54 TF at M=v^2=40000)
     const int64_t Kc = (V + O + 15) / 16 * 16;
@@ -235,12 +237,12 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vt2, V, O), "lbck");
         permute_add(cx, 1.0, s.t2, "ijad", 0.0, sub(tt2, 0, V), "daji");
         permute_add(cx, -1.0, s.I_ooov_pp, "jila", 0.0, sub(tt2, V, O), "laji");
-        Mpool = cx.scratch("t_mpool", 6 * p->nb * v3);
+        Mpool = cx.scratch("t_mpool", 6 * p->nb * vp3);
     }
     const int nq = cr ? 6 : 4;
     k_fill(cx, cx.scal, 6, 0.0);
     TriplesIn in{s.e, s.t1.d, vs.d, ts.d, s.t2.d, o, v};
-    double* Xpool = cx.scratch("t_xpool", 6 * p->nb * v3);
+    double* Xpool = cx.scratch("t_xpool", 6 * p->nb * vp3);
     double* partial = cx.scratch("t_partial", 6 * std::max<int64_t>((int64_t)p->norb * p->nb, 512));
     // one stream, no host round trip until the four sums are read back: chunk c+1's GEMMs overwrite the X pool only
     // after chunk c's orbit kernel has consumed it (stream order)

@@ -39,7 +39,7 @@ __device__ __forceinline__ int cidx(int p0, int p1, int p2) { return ((p0 ^ p1 ^
 // under the six permutations -- the smallest set closed under every index permutation the formulas use:
 //   W(a,b,c) = sum_s X_s(sigma_s(a,b,c))                                              ccsd.f90:2168-2173
 //   t_bar    = [4W(abc) + W(bca) + W(cab) - 2W(acb) - 2W(bac) - 2W(cba)] / 3D         symmetrised :2314-2318
-// Every X element is read from HBM exactly once (coalesced along its own leading index) and W never leaves LDS.
+// Every X element is read from HBM exactly once (whole 4 KiB cubes, 16 bytes per lane) and W never leaves LDS.
 // Thread t owns elements el = t + 256 r (r = 0..11): cube q = r/2 is a compile-time constant after unrolling, so
 // every permuted index below resolves to a fixed register.
 // CR = true additionally assembles the completely-renormalised moment M3 (ccsd.f90:2186-2194) from a second pool of
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
                                                             const TripleMeta* __restrict__ meta,
                                                             const int* __restrict__ orbits, TriplesIn in, int nblk_total)
 {
-    __shared__ double stage[6 * CUBE + 512];   // X cubes of one term; later the V / T2 patches and t1 rows
+    __shared__ __attribute__((aligned(16))) double stage[6 * CUBE + 512];   // X cubes of one term; later the V / T2 patches and t1 rows
     __shared__ double wl[6 * CUBE];            // W on the six cubes of the orbit
     __shared__ int srcq[6][6];                 // srcq[s][q]: which cube of the orbit is sigma_s applied to cube q
     __shared__ int dup[6];                     // 1 if cube q repeats an earlier cube (degenerate orbit)
@@ -73,60 +73,55 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
     const int64_t vv = (int64_t)v * v;
     // local coordinates of this thread's two elements per cube (half = 0, 1)
     const int l0 = t & 7, l1 = (t >> 3) & 7, l2h[2] = {t >> 6, (t >> 6) + 4};
+    // The X blocks are stored cube by cube (triples.hip: element (a,b,c) of a block sits at
+    // 512*(a/8 + nt8*(b/8) + nt8^2*(c/8)) + a%8 + 8*(b%8) + 64*(c%8)), so one cube is 4 KiB of contiguous HBM: thread t
+    // fetches elements 2t, 2t+1 of each of the six cubes with one 16-byte load and parks them in the swizzled image.
+    const int nt8 = (v + TT - 1) / TT;
+    const int p0 = (2 * t) & 7, p1 = (t >> 2) & 7, p2 = t >> 5;
+    const int sbase = (((p0 ^ p1 ^ p2) & 7) & ~1) | (p1 << 3) | (p2 << 6);
+    const bool flip = ((p1 ^ p2) & 1) != 0;   // the XOR swizzle swaps the two elements of the pair
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+    auto load_term = [&](const double* X, v2d_t (&xin)[6]) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int T0 = tile[sig(q, 0)], T1 = tile[sig(q, 1)], T2 = tile[sig(q, 2)];
+            const v2d_t x = *reinterpret_cast<const v2d_t*>(X + (int64_t)CUBE * (T0 + (int64_t)nt8 * (T1 + (int64_t)nt8 * T2)) + 2 * t);
+            const int g0 = T0 * TT + p0;
+            const bool rows = (T1 * TT + p1 < v) && (T2 * TT + p2 < v);   // the padding of a block is never written
+            xin[q][0] = (rows && g0 < v) ? x[0] : 0.0;
+            xin[q][1] = (rows && g0 + 1 < v) ? x[1] : 0.0;
+        }
+    };
+    auto park_term = [&](const v2d_t (&xin)[6]) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            *reinterpret_cast<v2d_t*>(&stage[q * CUBE + sbase]) = flip ? (v2d_t){xin[q][1], xin[q][0]} : xin[q];
+    };
     double wreg[12];
+    double mreg[CR ? 12 : 1];
 #pragma unroll
     for (int r = 0; r < 12; ++r) wreg[r] = 0.0;
 #pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const double* X = Xpool + m.xoff[s];
-        double xin[12];
+    for (int r = 0; r < (CR ? 12 : 1); ++r) mreg[r] = 0.0;
+    // term s+1 is in flight while term s is permuted out of LDS
+    constexpr int NTERM = CR ? 12 : 6;
+    v2d_t xin[6];
+    load_term(Xpool + m.xoff[0], xin);
 #pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            const int q = r >> 1, l2 = l2h[r & 1];
-            const int g0 = tile[sig(q, 0)] * TT + l0, g1 = tile[sig(q, 1)] * TT + l1, g2 = tile[sig(q, 2)] * TT + l2;
-            const bool ok = g0 < v && g1 < v && g2 < v;
-            const double x = X[ok ? g0 + (int64_t)v * g1 + vv * g2 : 0];
-            xin[r] = ok ? x : 0.0;
-        }
+    for (int s2 = 0; s2 < NTERM; ++s2) {
+        const int s = s2 % 6;
         __syncthreads();   // the previous term's readers are done with `stage` (also publishes srcq on the first pass)
-#pragma unroll
-        for (int r = 0; r < 12; ++r) stage[(r >> 1) * CUBE + cidx(l0, l1, l2h[r & 1])] = xin[r];
+        park_term(xin);
+        if (s2 + 1 < NTERM) load_term((s2 + 1 < 6 ? Xpool : Mpool) + m.xoff[(s2 + 1) % 6], xin);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 12; ++r) {
             const int q = r >> 1;
             const int l[3] = {l0, l1, l2h[r & 1]};
-            wreg[r] += stage[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])];
+            const double x = stage[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])];
+            if (s2 < 6) wreg[r] += x;
+            else mreg[CR ? r : 0] += x;
         }
-    }
-    double mreg[CR ? 12 : 1];
-    if (CR) {
-#pragma unroll
-        for (int r = 0; r < 12; ++r) mreg[CR ? r : 0] = 0.0;
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-            const double* X = Mpool + m.xoff[s];
-            double xin[12];
-#pragma unroll
-            for (int r = 0; r < 12; ++r) {
-                const int q = r >> 1, l2 = l2h[r & 1];
-                const int g0 = tile[sig(q, 0)] * TT + l0, g1 = tile[sig(q, 1)] * TT + l1, g2 = tile[sig(q, 2)] * TT + l2;
-                const bool ok = g0 < v && g1 < v && g2 < v;
-                const double x = X[ok ? g0 + (int64_t)v * g1 + vv * g2 : 0];
-                xin[r] = ok ? x : 0.0;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 12; ++r) stage[(r >> 1) * CUBE + cidx(l0, l1, l2h[r & 1])] = xin[r];
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 12; ++r) {
-                const int q = r >> 1;
-                const int l[3] = {l0, l1, l2h[r & 1]};
-                mreg[CR ? r : 0] += stage[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])];
-            }
-        }
-        __syncthreads();   // every reader of `stage` is done before the patches overwrite it
     }
 #pragma unroll
     for (int r = 0; r < 12; ++r) wl[(r >> 1) * CUBE + cidx(l0, l1, l2h[r & 1])] = wreg[r];
