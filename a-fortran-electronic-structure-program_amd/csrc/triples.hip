@@ -93,11 +93,15 @@ static TriplesPlan* plan_for(Context& cx, CCState& s, int64_t t_begin, int64_t t
     const int o = s.o, v = s.v;
     const int64_t O = o, V = v, Kc = (V + O + 15) / 16 * 16;   // padded, see ccsd_triples
     p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = cr;
-    // chunk size: 6 X blocks of v^3 doubles per triple (W never leaves LDS); a few dozen ordered triples per k-group keep
-    // the GEMM column count in the thousands, more buys nothing
+    // chunk size: 6 X blocks of (padded) v^3 doubles per triple; W never leaves LDS
     const int64_t nt8 = (V + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;   // a block is stored cube by cube, edges padded to 8
     const int64_t per = (cr ? 12 : 6) * vp3 * (int64_t)sizeof(double);   // CR mode keeps a second pool for the M3 blocks
-    int64_t nb = std::max<int64_t>(1, ((int64_t)24 << 30) / per);
+    // pool budget: a quarter of the device memory, at most 64 GiB (MI355X: 288 GB -> 64 GiB, ~165 triples per chunk at
+    // v = 200): the more triples share an integral slab, the wider each GEMM and the smaller its ragged last round
+    size_t mem_free = 0, mem_total = 0;
+    AFESP_HIP(hipMemGetInfo(&mem_free, &mem_total));
+    const int64_t budget = std::min<int64_t>((int64_t)64 << 30, (int64_t)(mem_total / 4));
+    int64_t nb = std::max<int64_t>(1, budget / per);
     nb = std::min<int64_t>(nb, 4096);
     nb = std::min<int64_t>(nb, std::max<int64_t>(1, t_end - t_begin));
     p->nb = nb;
