@@ -20,8 +20,8 @@ def lib():
     if _LIB is not None:
         return _LIB
     so = os.path.join(ROOT, "oracle", "liborc.so")
-    src = os.path.join(ROOT, "oracle", "afesp_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("afesp_oracle.c", "afesp_oracle_so.c")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liborc.so"])
     L = C.CDLL(so)
     L.orc_neri.restype = i64
@@ -69,6 +69,29 @@ def lib():
     L.orc_permute4.restype = None
     L.orc_linsolve.argtypes = [C.c_int, dp, dp]
     L.orc_linsolve.restype = C.c_int
+    # spin-orbital path (afesp_oracle_so.c)
+    L.orc_so_create.restype = C.c_void_p
+    L.orc_so_create.argtypes = [i64, i64, dp, dp, C.c_int]
+    L.orc_so_destroy.argtypes = [C.c_void_p]
+    for f in ("orc_so_iterate", "orc_so_diis_save"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = None
+    L.orc_so_diis_update.argtypes = [C.c_void_p]
+    L.orc_so_diis_update.restype = C.c_int
+    L.orc_so_energy.argtypes = [C.c_void_p, dbl, dbl]
+    L.orc_so_energy.restype = C.c_int
+    L.orc_so_solve.argtypes = [C.c_void_p, C.c_int, dbl, dbl, dp, dp]
+    L.orc_so_solve.restype = C.c_int
+    for f in ("orc_so_get_energy", "orc_so_get_rms", "orc_so_triples"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = dbl
+    for f in ("orc_so_t1", "orc_so_t2"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = C.POINTER(dbl)
+    L.orc_so_set_foo_as_published.argtypes = [C.c_void_p, C.c_int]
+    L.orc_so_set_foo_as_published.restype = None
+    L.orc_so_field.argtypes = [C.c_void_p, C.c_int]
+    L.orc_so_field.restype = C.POINTER(dbl)
     _LIB = L
     return L
 
@@ -174,3 +197,63 @@ def ao2mo(n, Cmat, eri_packed):
 
 def mp2_energy(n, o, eri_mo, e):
     return lib().orc_mp2_energy(n, o, np.ascontiguousarray(eri_mo), np.ascontiguousarray(e))
+
+
+SO_FIELDS = {"F_vv": 0, "F_oo": 1, "F_ov": 2, "W_oooo": 3, "W_vvvv": 4, "W_ovvo": 5, "tau": 6, "tau_tilde": 7, "oovv": 8,
+             "vvvv": 9}
+
+
+class OracleSO:
+    """Spin-orbital CCSD / CCSD(T) restatement (oracle/afesp_oracle_so.c).  o, v are spin-orbital counts."""
+
+    def __init__(self, n, nel, eri_mo, e, diis_nerr=8, foo_as_published=False):
+        self.L = lib()
+        self.n, self.o, self.v = int(n), int(nel), int(2 * n - nel)
+        self.h = self.L.orc_so_create(n, nel, np.ascontiguousarray(eri_mo), np.ascontiguousarray(e), diis_nerr)
+        self.L.orc_so_set_foo_as_published(self.h, 1 if foo_as_published else 0)
+
+    def close(self):
+        if self.h:
+            self.L.orc_so_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _view(self, ptr, shape):
+        return np.ctypeslib.as_array(ptr, shape=(int(np.prod(shape)),)).reshape(shape, order="F")
+
+    def field(self, name):
+        o, v = self.o, self.v
+        shape = {"F_vv": (v, v), "F_oo": (o, o), "F_ov": (o, v), "W_oooo": (o, o, o, o), "W_vvvv": (v, v, v, v),
+                 "W_ovvo": (o, v, v, o), "tau": (o, o, v, v), "tau_tilde": (o, o, v, v), "oovv": (o, o, v, v),
+                 "vvvv": (v, v, v, v)}[name]
+        return self._view(self.L.orc_so_field(self.h, SO_FIELDS[name]), shape)
+
+    @property
+    def t1(self):
+        return self._view(self.L.orc_so_t1(self.h), (self.o, self.v))
+
+    @property
+    def t2(self):
+        return self._view(self.L.orc_so_t2(self.h), (self.o, self.o, self.v, self.v))
+
+    def iterate(self):
+        self.L.orc_so_iterate(self.h)
+
+    def energy_step(self, e_tol, t_tol):
+        conv = self.L.orc_so_energy(self.h, e_tol, t_tol)
+        return self.L.orc_so_get_energy(self.h), self.L.orc_so_get_rms(self.h), bool(conv)
+
+    def solve(self, maxiter, e_tol, t_tol):
+        en = np.zeros(maxiter + 1)
+        rm = np.zeros(maxiter + 1)
+        nit = self.L.orc_so_solve(self.h, maxiter, e_tol, t_tol, en, rm)
+        return nit, en, rm
+
+    @property
+    def energy(self):
+        return self.L.orc_so_get_energy(self.h)
+
+    def triples(self):
+        return self.L.orc_so_triples(self.h)
