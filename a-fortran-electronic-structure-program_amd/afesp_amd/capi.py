@@ -24,6 +24,8 @@ EXPORTS = [
     "afesp_ccsd_get_amplitudes", "afesp_ccsd_set_amplitudes", "afesp_ccsd_get_tensor", "afesp_ccsd_update_intermediates",
     "afesp_ccsd_update_amplitudes", "afesp_ccsd_t_ntriples", "afesp_ccsd_t", "afesp_gemm", "afesp_permute4",
     "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder", "afesp_bench_contract", "afesp_set_tuning", "afesp_bench_stream", "afesp_profile", "afesp_ccsd_cr_intermediates", "afesp_ccsd_t_cr",
+    "afesp_ccsd_so_init", "afesp_ccsd_so_energy", "afesp_ccsd_so_iterate", "afesp_ccsd_so_diis", "afesp_ccsd_so_get_amplitudes",
+    "afesp_ccsd_so_set_amplitudes", "afesp_ccsd_so_get_tensor", "afesp_ccsd_so_t_ntriples", "afesp_ccsd_so_t",
 ]
 
 
@@ -77,6 +79,16 @@ def load_library():
     L.afesp_set_tuning.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.afesp_bench_stream.argtypes = [C.c_void_p, i64, C.c_int, C.POINTER(dbl)]
     L.afesp_profile.argtypes = [C.c_void_p, C.c_int, _dp]
+    L.afesp_ccsd_so_init.argtypes = [C.c_void_p, i64, i64, _opt, _dp, C.c_int, C.c_int]
+    L.afesp_ccsd_so_iterate.argtypes = [C.c_void_p, dbl, dbl, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_int)]
+    L.afesp_ccsd_so_energy.argtypes = [C.c_void_p, dbl, dbl, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_int)]
+    L.afesp_ccsd_so_diis.argtypes = [C.c_void_p]
+    L.afesp_ccsd_so_get_amplitudes.argtypes = [C.c_void_p, _dp, _dp]
+    L.afesp_ccsd_so_set_amplitudes.argtypes = [C.c_void_p, _dp, _dp]
+    L.afesp_ccsd_so_get_tensor.argtypes = [C.c_void_p, C.c_char_p, _dp, i64]
+    L.afesp_ccsd_so_t_ntriples.argtypes = [i64]
+    L.afesp_ccsd_so_t_ntriples.restype = i64
+    L.afesp_ccsd_so_t.argtypes = [C.c_void_p, i64, i64, C.POINTER(dbl)]
     _lib = L
     return L
 
@@ -199,6 +211,72 @@ class Engine:
             t_end = self.ntriples()
         self._chk(self.L.afesp_ccsd_t(self.h, t_begin, t_end, out))
         return out
+
+    # ---- spin-orbital path: do_ccsd_spinorb (src/ccsd.f90:71-277), do_ccsd_t_spinorb (:1812-1922)
+    SO_SHAPES = {"F_vv": "vv", "F_oo": "oo", "F_ov": "ov", "W_oooo": "oooo", "W_vvvv": "vvvv", "W_ovvo": "ovvo", "tau": "oovv",
+                 "tau_tilde": "oovv", "oovv": "oovv", "vvvv": "vvvv", "t1": "ov", "t2": "oovv"}
+
+    def init_cc_spinorb(self, nbasis, nel, canon_levels, eri_mo=None, diis_nerr=8, foo_as_published=False):
+        self.so_o, self.so_v = int(nel), int(2 * nbasis - nel)
+        eri = None
+        if eri_mo is not None:
+            eri_mo = np.ascontiguousarray(eri_mo, dtype=np.float64)
+            eri = eri_mo.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.afesp_ccsd_so_init(self.h, nbasis, nel, eri, np.ascontiguousarray(canon_levels, dtype=np.float64),
+                                            diis_nerr, 1 if foo_as_published else 0))
+
+    def _so_step(self, fn, e_tol, t_tol):
+        e, r, c = dbl(), dbl(), C.c_int()
+        self._chk(fn(self.h, e_tol, t_tol, C.byref(e), C.byref(r), C.byref(c)))
+        return e.value, r.value, bool(c.value)
+
+    def so_energy(self, e_tol=1e-6, t_tol=1e-7):
+        return self._so_step(self.L.afesp_ccsd_so_energy, e_tol, t_tol)
+
+    def so_iterate(self, e_tol=1e-6, t_tol=1e-7):
+        return self._so_step(self.L.afesp_ccsd_so_iterate, e_tol, t_tol)
+
+    def so_diis(self):
+        self._chk(self.L.afesp_ccsd_so_diis(self.h))
+
+    def do_ccsd_spinorb(self, maxiter=50, e_tol=1e-6, t_tol=1e-7):
+        """The driver loop of src/ccsd.f90:215-275 -> (iterations or -1, energies incl. the MP1 line, un-rooted rms)."""
+        en, rm = [], []
+        e, r, _ = self.so_energy(e_tol, t_tol)
+        en.append(e); rm.append(r)
+        for it in range(1, maxiter + 1):
+            e, r, conv = self.so_iterate(e_tol, t_tol)
+            en.append(e); rm.append(r)
+            if conv:
+                return it, np.array(en), np.array(rm)
+            self.so_diis()
+        return -1, np.array(en), np.array(rm)
+
+    def so_amplitudes(self):
+        o, v = self.so_o, self.so_v
+        t1 = np.zeros(o * v)
+        t2 = np.zeros(o * o * v * v)
+        self._chk(self.L.afesp_ccsd_so_get_amplitudes(self.h, t1, t2))
+        return t1.reshape((o, v), order="F"), t2.reshape((o, o, v, v), order="F")
+
+    def so_set_amplitudes(self, t1, t2):
+        self._chk(self.L.afesp_ccsd_so_set_amplitudes(self.h, _f(t1), _f(t2)))
+
+    def so_tensor(self, name):
+        dims = tuple(self.so_o if ch == "o" else self.so_v for ch in self.SO_SHAPES[name])
+        buf = np.zeros(int(np.prod(dims)))
+        self._chk(self.L.afesp_ccsd_so_get_tensor(self.h, name.encode(), buf, buf.size))
+        return buf.reshape(dims, order="F")
+
+    def so_ntriples(self):
+        return self.L.afesp_ccsd_so_t_ntriples(self.so_o)
+
+    def do_ccsd_t_spinorb(self, t_begin=0, t_end=None):
+        if t_end is None:
+            t_end = self.so_ntriples()
+        e = dbl()
+        self._chk(self.L.afesp_ccsd_so_t(self.h, t_begin, t_end, C.byref(e)))
+        return e.value
 
     # ---- completely renormalised variants (src/ccsd.f90:2338-2551, :2186-2194)
     def build_cr_intermediates(self):

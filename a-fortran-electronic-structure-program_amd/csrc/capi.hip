@@ -4,12 +4,14 @@
 
 #include "../../include/afesp.h"
 #include "ccsd.h"
+#include "ccsd_so.h"
 
 using namespace afesp;
 
 struct afesp_ctx {
     Context cx;
     CCState cc;
+    SOState so;
     double* eri_mo_dev = nullptr;   // packed MO integrals left on the device by afesp_ao2mo_mp2
     int64_t eri_mo_n = 0;           // nbasis they belong to
 };
@@ -91,6 +93,7 @@ void afesp_ctx_destroy(afesp_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->cx.device);
     triples_plan_free(ctx->cc);
+    so_triples_plan_free(ctx->so);
     delete ctx;
 }
 
@@ -324,6 +327,120 @@ int afesp_ccsd_t_cr(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[6
     return guarded(ctx, [&] {
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         ccsd_triples(ctx->cx, ctx->cc, t_begin, t_end, out, true);
+    });
+}
+
+// ---------------------------------------------------------------- spin-orbital path
+int afesp_ccsd_so_init(afesp_ctx* ctx, int64_t nbasis, int64_t nel, const double* eri_mo_packed, const double* canon_levels,
+                       int diis_n_errmat, int flags)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        if (nbasis <= 0 || nbasis > 512 || nel <= 0 || nel >= 2 * nbasis) throw Error(1, "afesp_ccsd_so_init: bad extents");
+        const double* src = ctx->eri_mo_dev;
+        double* tmp = nullptr;
+        if (eri_mo_packed) {
+            tmp = cx.alloc(neri_of(nbasis));
+            AFESP_HIP(hipMemcpyAsync(tmp, eri_mo_packed, sizeof(double) * neri_of(nbasis), hipMemcpyHostToDevice, cx.stream));
+            src = tmp;
+        } else if (!src || ctx->eri_mo_n != nbasis) {
+            throw Error(1, "afesp_ccsd_so_init: no MO integrals resident for this basis size (call afesp_ao2mo_mp2 first)");
+        }
+        so_init(cx, ctx->so, (int)nbasis, (int)nel, src, canon_levels, diis_n_errmat, (flags & AFESP_SO_FOO_AS_PUBLISHED) != 0);
+        if (tmp) cx.release(tmp);
+    });
+}
+
+int afesp_ccsd_so_energy(afesp_ctx* ctx, double e_tol, double t_tol, double* energy, double* rms_sq, int* converged)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->so.ready) throw Error(1, "afesp_ccsd_so_energy: call afesp_ccsd_so_init first");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        int conv = so_energy(ctx->cx, ctx->so, e_tol, t_tol);
+        if (energy) *energy = ctx->so.energy;
+        if (rms_sq) *rms_sq = ctx->so.rms;
+        if (converged) *converged = conv;
+    });
+}
+
+int afesp_ccsd_so_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* energy, double* rms_sq, int* converged)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->so.ready) throw Error(1, "afesp_ccsd_so_iterate: call afesp_ccsd_so_init first");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        diis_save(ctx->cx, ctx->so);
+        so_intermediates(ctx->cx, ctx->so);
+        so_amplitudes(ctx->cx, ctx->so);
+        int conv = so_energy(ctx->cx, ctx->so, e_tol, t_tol);
+        if (energy) *energy = ctx->so.energy;
+        if (rms_sq) *rms_sq = ctx->so.rms;
+        if (converged) *converged = conv;
+    });
+}
+
+int afesp_ccsd_so_diis(afesp_ctx* ctx)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->so.ready) throw Error(1, "afesp_ccsd_so_diis: call afesp_ccsd_so_init first");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        diis_update(ctx->cx, ctx->so);
+    });
+}
+
+int afesp_ccsd_so_get_amplitudes(afesp_ctx* ctx, double* t1, double* t2)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->so.ready) throw Error(1, "afesp_ccsd_so_get_amplitudes: no spin-orbital CCSD state");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        SOState& s = ctx->so;
+        if (t1) AFESP_HIP(hipMemcpyAsync(t1, s.t1.d, sizeof(double) * s.t1.size(), hipMemcpyDeviceToHost, ctx->cx.stream));
+        if (t2) AFESP_HIP(hipMemcpyAsync(t2, s.t2.d, sizeof(double) * s.t2.size(), hipMemcpyDeviceToHost, ctx->cx.stream));
+        ctx->cx.sync();
+    });
+}
+
+int afesp_ccsd_so_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->so.ready) throw Error(1, "afesp_ccsd_so_set_amplitudes: no spin-orbital CCSD state");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        SOState& s = ctx->so;
+        if (t1) AFESP_HIP(hipMemcpyAsync(s.t1.d, t1, sizeof(double) * s.t1.size(), hipMemcpyHostToDevice, ctx->cx.stream));
+        if (t2) AFESP_HIP(hipMemcpyAsync(s.t2.d, t2, sizeof(double) * s.t2.size(), hipMemcpyHostToDevice, ctx->cx.stream));
+        ctx->cx.sync();
+    });
+}
+
+int afesp_ccsd_so_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t capacity)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->so.ready) throw Error(1, "afesp_ccsd_so_get_tensor: no spin-orbital CCSD state");
+        SOState& s = ctx->so;
+        struct { const char* n; const Tensor* t; } tab[] = {
+            {"F_vv", &s.F_vv}, {"F_oo", &s.F_oo}, {"F_ov", &s.F_ov}, {"W_oooo", &s.W_oooo}, {"W_vvvv", &s.W_vvvv},
+            {"W_ovvo", &s.W_ovvo}, {"tau", &s.tau}, {"tau_tilde", &s.tau_t}, {"oovv", &s.oovv}, {"vvvv", &s.vvvv},
+            {"t1", &s.t1}, {"t2", &s.t2}};
+        for (auto& e : tab)
+            if (!strcmp(e.n, name)) {
+                if (e.t->size() > capacity) throw Error(1, std::string("afesp_ccsd_so_get_tensor: buffer too small for ") + name);
+                AFESP_HIP(hipSetDevice(ctx->cx.device));
+                AFESP_HIP(hipMemcpyAsync(out, e.t->d, sizeof(double) * e.t->size(), hipMemcpyDeviceToHost, ctx->cx.stream));
+                ctx->cx.sync();
+                return;
+            }
+        throw Error(1, std::string("afesp_ccsd_so_get_tensor: unknown tensor ") + name);
+    });
+}
+
+int64_t afesp_ccsd_so_t_ntriples(int64_t nocc) { return so_triples_count((int)nocc); }
+
+int afesp_ccsd_so_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double* e_t)
+{
+    return guarded(ctx, [&] {
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        const double e = so_triples(ctx->cx, ctx->so, t_begin, t_end);
+        if (e_t) *e_t = e;
     });
 }
 

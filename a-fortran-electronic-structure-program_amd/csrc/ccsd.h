@@ -4,7 +4,22 @@
 
 namespace afesp {
 
-struct CCState {
+// DIIS ring (ccsd.f90:38-67, shared by the spin-free and the spin-orbital solver): vectors are [t1 ; t2]
+// concatenated, length nvec
+struct DiisRing {
+    int nerr = 0, nact = 0, it = 0;
+    int64_t nvec = 0;
+    double *amp = nullptr;      // [t1 ; t2] contiguous, t1 = amp, t2 = amp + o*v
+    double *amp_s = nullptr;    // amplitudes saved at the top of the iteration (t1_s/t2_s)
+    double *hist_t = nullptr, *hist_e = nullptr;   // nerr * nvec each
+    double *coef = nullptr;     // device coefficients
+    std::vector<double> B;      // host copy of the error overlap matrix (nerr x nerr, full)
+};
+void diis_alloc(Context& cx, DiisRing& r, int diis_nerr);   // r.nvec and r.amp set by the caller (init_diis_cc_t, :577-615)
+void diis_save(Context& cx, DiisRing& r);                   // ccsd.f90:342-343
+void diis_update(Context& cx, DiisRing& r);                 // update_diis_cc, ccsd.f90:617-676
+
+struct CCState : DiisRing {
     int o = 0, v = 0;
     bool ready = false;
     double* e = nullptr;   // orbital energies on device, length o+v
@@ -14,14 +29,6 @@ struct CCState {
     double* pp = nullptr;          // packed particle-particle ladder PP(i,j,p), p over a <= b
     int64_t* pp_tab = nullptr;     // offset tables of the pp-ladder GEMM: [Am | k | Bk | n]
     Tensor I_vo, I_vv, I_oo_p, I_oo, c, asym, x_voov, I_oooo, I_ovov, I_voov, I_vovv_p, I_ooov_p;
-    // DIIS ring (ccsd.f90:38-67): vectors are [t1 ; t2] concatenated, length nvec
-    int nerr = 0, nact = 0, it = 0;
-    int64_t nvec = 0;
-    double *amp = nullptr;      // [t1 ; t2] contiguous, t1 = amp, t2 = amp + o*v
-    double *amp_s = nullptr;    // amplitudes saved at the top of the iteration (t1_s/t2_s)
-    double *hist_t = nullptr, *hist_e = nullptr;   // nerr * nvec each
-    double *coef = nullptr;     // device coefficients
-    std::vector<double> B;      // host copy of the error overlap matrix (nerr x nerr, full)
     double energy = 0.0, energy_old = 0.0, rms = 0.0;
     void* tplan = nullptr;      // cached (T) launch plan (triples.hip)
     Tensor I_vovv_pp, I_ooov_pp;   // completely renormalised moments (ccsd.f90:2338-2551), built on request

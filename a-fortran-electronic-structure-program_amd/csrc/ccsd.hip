@@ -69,15 +69,7 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     // ccsd.f90:520-521: t1 = 0, t2 = v_oovv / D
     k_div(cx, s.t2.d, s.v_oovv.d, s.D2.d, o2v2);
     // ccsd.f90:577-615
-    s.nerr = diis_nerr; s.nact = 0; s.it = 0;
-    if (diis_nerr >= 2) {
-        if (diis_nerr > 15) throw Error(1, "ccsd_init: ccsd_diis_n_errmat > 15 is not supported");
-        s.amp_s = cx.alloc(s.nvec);
-        s.hist_t = cx.alloc(s.nvec * diis_nerr);
-        s.hist_e = cx.alloc(s.nvec * diis_nerr);
-        s.coef = cx.alloc(32);
-        s.B.assign((size_t)diis_nerr * diis_nerr, 0.0);
-    }
+    diis_alloc(cx, s, diis_nerr);
     s.energy = s.energy_old = s.rms = 0.0;
     s.ready = true;
     cx.sync();
@@ -96,10 +88,24 @@ void ccsd_free(Context& cx, CCState& s)
     s = CCState();
 }
 
-void ccsd_diis_save(Context& cx, CCState& s)
+void diis_alloc(Context& cx, DiisRing& s, int diis_nerr)
+{
+    s.nerr = diis_nerr; s.nact = 0; s.it = 0;
+    if (diis_nerr >= 2) {
+        if (diis_nerr > 15) throw Error(1, "ccsd_init: ccsd_diis_n_errmat > 15 is not supported");
+        s.amp_s = cx.alloc(s.nvec);
+        s.hist_t = cx.alloc(s.nvec * diis_nerr);
+        s.hist_e = cx.alloc(s.nvec * diis_nerr);
+        s.coef = cx.alloc(32);
+        s.B.assign((size_t)diis_nerr * diis_nerr, 0.0);
+    }
+}
+
+void diis_save(Context& cx, DiisRing& s)
 {
     if (s.nerr >= 2) k_copy(cx, s.amp_s, s.amp, s.nvec);   // ccsd.f90:342-343
 }
+void ccsd_diis_save(Context& cx, CCState& s) { diis_save(cx, s); }
 
 void ccsd_intermediates(Context& cx, CCState& s)
 {
@@ -295,7 +301,9 @@ static int solve_dense(int n, std::vector<double>& A, std::vector<double>& b)
     return 0;
 }
 
-void ccsd_diis_update(Context& cx, CCState& s)
+void ccsd_diis_update(Context& cx, CCState& s) { diis_update(cx, s); }
+
+void diis_update(Context& cx, DiisRing& s)
 {
     if (s.nerr < 2) return;
     // ccsd.f90:633-646

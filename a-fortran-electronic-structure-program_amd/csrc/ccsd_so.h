@@ -1,0 +1,35 @@
+// ccsd_so.h -- device-resident state of the spin-orbital CCSD solver and its (T) correction
+// (reference: do_ccsd_spinorb ccsd.f90:71-277, build_tau/F/W :678-905, update_amplitudes :907-1038,
+//  do_ccsd_t_spinorb :1812-1922).  Spin orbitals are interleaved alpha,beta as in ccsd.f90:108-143; o and v are
+// spin-orbital counts (geometry.f90:44-45: nocc = nel, nvirt = 2 nbasis - nel).
+#pragma once
+#include "ccsd.h"
+
+namespace afesp {
+
+struct SOState : DiisRing {
+    int o = 0, v = 0, n = 0;
+    bool ready = false;
+    bool foo_as_published = false;   // see so_build_F
+    double* e = nullptr;             // spatial orbital energies on device, length n
+    // antisymmetrised slices <pq||rs> (ccsd.f90:193-207)
+    Tensor oooo, ooov, ovoo, oovo, oovv, ovvo, ovvv, vovv, vvvv;
+    Tensor D1, D2, t1, t2, t2_old, r1, r2;
+    Tensor F_vv, F_oo, F_ov, W_oooo, W_vvvv, W_ovvo, tau, tau_t;
+    double energy = 0.0, energy_old = 0.0, rms = 0.0;
+    void* tplan = nullptr;           // cached (T) launch plan (triples_so.hip)
+};
+
+// eri_mo_dev: packed chemist MO integrals on the device (length neri(nbasis)); e_host: spatial orbital energies (host)
+void so_init(Context& cx, SOState& s, int nbasis, int nel, const double* eri_mo_dev, const double* e_host, int diis_nerr,
+             bool foo_as_published);
+void so_free(Context& cx, SOState& s);
+void so_intermediates(Context& cx, SOState& s);   // build_tau, build_F, build_W
+void so_amplitudes(Context& cx, SOState& s);      // update_amplitudes
+int so_energy(Context& cx, SOState& s, double e_tol, double t_tol);
+// (T): contribution of the triples i<j<k with flat index in [t_begin, t_end) to E_T (ccsd.f90:1910)
+int64_t so_triples_count(int o);
+double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end);
+void so_triples_plan_free(SOState& s);
+
+}  // namespace afesp

@@ -19,6 +19,7 @@
 #include <cmath>
 
 #include "ccsd.h"
+#include "ccsd_so.h"
 #include "triples_orbit.h"
 
 namespace afesp {
@@ -74,6 +75,7 @@ struct TriplesPlan {
     int64_t t_begin = -1, t_end = -1, nb = 0;
     int norb = 0;
     bool cr = false;
+    int mode = 0;   // 0 spin-free (i<=j<=k, six blocks per triple), 1 spin-orbital (i<j<k, three blocks)
     struct Group { int r; int64_t start, N; };
     struct Chunk { int nt; int64_t meta_off, tab_off, ntab; std::vector<Group> groups; };
     std::vector<Chunk> chunks;
@@ -83,19 +85,18 @@ struct TriplesPlan {
     int* orbits = nullptr;
 };
 
-static TriplesPlan* plan_for(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, bool cr)
+static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end, bool cr, int mode)
 {
-    TriplesPlan* p = (TriplesPlan*)s.tplan;
-    if (p && p->o == s.o && p->v == s.v && p->t_begin == t_begin && p->t_end == t_end && p->cr == cr) return p;
+    TriplesPlan* p = (TriplesPlan*)slot;
+    if (p && p->o == o && p->v == v && p->t_begin == t_begin && p->t_end == t_end && p->cr == cr && p->mode == mode) return p;
     delete p;
     p = new TriplesPlan();
-    s.tplan = p;
-    const int o = s.o, v = s.v;
+    slot = p;
     const int64_t O = o, V = v, Kc = (V + O + 15) / 16 * 16;   // padded, see ccsd_triples
-    p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = cr;
+    p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = cr; p->mode = mode;
     // chunk size: 6 X blocks of (padded) v^3 doubles per triple; W never leaves LDS
     const int64_t nt8 = (V + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;   // a block is stored cube by cube, edges padded to 8
-    const int64_t per = (cr ? 12 : 6) * vp3 * (int64_t)sizeof(double);   // CR mode keeps a second pool for the M3 blocks
+    const int64_t per = (mode == 1 ? 3 : cr ? 12 : 6) * vp3 * (int64_t)sizeof(double);   // CR mode keeps a second pool for the M3 blocks
     // pool budget: a quarter of the device memory, at most 64 GiB (MI355X: 288 GB -> 64 GiB, ~165 triples per chunk at
     // v = 200): the more triples share an integral slab, the wider each GEMM and the smaller its ragged last round
     size_t mem_free = 0, mem_total = 0;
@@ -146,15 +147,20 @@ static TriplesPlan* plan_for(Context& cx, CCState& s, int64_t t_begin, int64_t t
         cur.clear(); ords.clear();
     };
     int64_t flat = 0;
+    const int step = mode == 1 ? 1 : 0;   // spin-orbital: strictly increasing (the summand is antisymmetric in i,j,k)
     for (int i = 0; i < o && flat < t_end; ++i)
-        for (int j = i; j < o && flat < t_end; ++j)
-            for (int k = j; k < o && flat < t_end; ++k, ++flat) {
+        for (int j = i + step; j < o && flat < t_end; ++j)
+            for (int k = j + step; k < o && flat < t_end; ++k, ++flat) {
                 if (flat < t_begin) continue;
                 TripleMeta m;
                 m.i = i; m.j = j; m.k = k; m.pad = 0;
-                m.mult = (i == j && j == k) ? 1.0 : (i == j || j == k) ? 3.0 : 6.0;
+                m.mult = mode == 1 ? 1.0 : (i == j && j == k) ? 1.0 : (i == j || j == k) ? 3.0 : 6.0;
                 m.woff = 0;
-                const int P[6][3] = {{i, j, k}, {j, i, k}, {k, j, i}, {i, k, j}, {j, k, i}, {k, i, j}};
+                // ordered (p,q,r): the amplitude operand carries the pair (p,q), the integral operand carries r.
+                // spin-orbital: Y^{i;jk}, Y^{j;ik}, Y^{k;ij} (see so_triples)
+                const int P6[6][3] = {{i, j, k}, {j, i, k}, {k, j, i}, {i, k, j}, {j, k, i}, {k, i, j}};
+                const int P3[6][3] = {{j, k, i}, {i, k, j}, {i, j, k}, {j, k, i}, {j, k, i}, {j, k, i}};
+                const int (*P)[3] = mode == 1 ? P3 : P6;
                 for (int q = 0; q < 6; ++q) {
                     int found = -1;
                     for (int r = 0; r < q; ++r)
@@ -202,7 +208,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     const int64_t Kc = (V + O + 15) / 16 * 16;
     t_begin = std::max<int64_t>(0, t_begin);
     t_end = std::min<int64_t>(triples_count(o), t_end);
-    TriplesPlan* p = plan_for(cx, s, t_begin, t_end, cr);
+    TriplesPlan* p = plan_for(cx, s.tplan, s.o, s.v, t_begin, t_end, cr, 0);
     // concatenated operands, summed index kappa = [d ; l] first (the reference also moves the summed index first, :2056-2066)
     //   vt(kappa,b,c,k): kappa<v: <cb|kd> = v_vvov(c,b,k,d);  kappa=v+l: t2(l,k,b,c)
     //   tt(kappa,a,j,i): kappa<v: t2(i,j,a,d);                kappa=v+l: -<ij|al> = -v_oovo(i,j,a,l)
@@ -326,6 +332,91 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         out_host[4] = h[4];            // sum t_bar.M3     ccsd.f90:2223-2224
         out_host[5] = h[4] + h[5];     // + sum z_bar.M3   ccsd.f90:2225
     }
+}
+
+// ------------------------------------------------------------------------------------------------ spin-orbital (T)
+// do_ccsd_t_spinorb, ccsd.f90:1812-1922.  With
+//   Y^{p;qr}(a,b,c) = sum_f <fp||bc> t2(q,r,a,f) - sum_m t2(m,p,c,b) <ma||qr>
+// the connected numerator of :1877-1884 is Y^{i;jk} - Y^{j;ik} - Y^{k;ji} = Y^{i;jk} - Y^{j;ik} + Y^{k;ij}; each Y is one
+// GEMM over the concatenated index kappa = f (+) m with rows (b,c) and columns (a; pair), exactly the spin-free layout:
+//   vt(kappa,b,c,p):  kappa<v: vovv(f,p,b,c);   kappa=v+m: t2(m,p,c,b)
+//   tt(kappa,a,r,q):  kappa<v: t2(q,r,a,f);     kappa=v+m: -ovoo(m,a,q,r)
+// The summand of :1910 is antisymmetric in (i,j,k): only i<j<k is visited (weight 6/36, in the kernel).
+int64_t so_triples_count(int o) { return (int64_t)o * (o - 1) * (o - 2) / 6; }
+
+void so_triples_plan_free(SOState& s)
+{
+    delete (TriplesPlan*)s.tplan;
+    s.tplan = nullptr;
+}
+
+double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
+{
+    if (!s.ready) throw Error(1, "ccsd_so_triples: no converged spin-orbital CCSD state in this context");
+    const int o = s.o, v = s.v;
+    const int64_t O = o, V = v, v2 = V * V;
+    const int64_t nt8 = (V + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;
+    const int64_t Kc = (V + O + 15) / 16 * 16;
+    t_begin = std::max<int64_t>(0, t_begin);
+    t_end = std::min<int64_t>(so_triples_count(o), t_end);
+    k_fill(cx, cx.scal, 1, 0.0);
+    if (t_end <= t_begin) return 0.0;
+    TriplesPlan* p = plan_for(cx, s.tplan, o, v, t_begin, t_end, false, 1);
+    Tensor vt = view(cx.scratch("t_vt", Kc * v2 * O), {Kc, V, V, O}), tt = view(cx.scratch("t_tt", Kc * V * O * O), {Kc, V, O, O});
+    auto sub = [&](const Tensor& full, int64_t row0, int64_t nrows) {
+        Tensor t = full;
+        t.d = full.d + row0;
+        t.dim[0] = nrows;
+        return t;
+    };
+    if (Kc != V + O) {
+        AFESP_HIP(hipMemsetAsync(vt.d, 0, sizeof(double) * Kc * v2 * O, cx.stream));
+        AFESP_HIP(hipMemsetAsync(tt.d, 0, sizeof(double) * Kc * V * O * O, cx.stream));
+    }
+    permute_add(cx, 1.0, s.vovv, "fpbc", 0.0, sub(vt, 0, V), "fbcp");
+    permute_add(cx, 1.0, s.t2, "mpcb", 0.0, sub(vt, V, O), "mbcp");
+    permute_add(cx, 1.0, s.t2, "qraf", 0.0, sub(tt, 0, V), "farq");
+    permute_add(cx, -1.0, s.ovoo, "maqr", 0.0, sub(tt, V, O), "marq");
+    Tensor vs = view(cx.scratch("t_vs", v2 * O * O), {V, V, O, O});    // vs(x,y,p,q) = <pq||xy>
+    permute_add(cx, 1.0, s.oovv, "pqxy", 0.0, vs, "xypq");
+    double* e_so = cx.scratch("t_eso", O + V);
+    {
+        std::vector<double> es((size_t)(O + V));
+        std::vector<double> eh((size_t)s.n);
+        AFESP_HIP(hipMemcpyAsync(eh.data(), s.e, sizeof(double) * s.n, hipMemcpyDeviceToHost, cx.stream));
+        cx.sync();
+        for (int64_t x = 0; x < O + V; ++x) es[(size_t)x] = eh[(size_t)(x / 2)];   // canon_levels_spinorb, ccsd.f90:451-454
+        AFESP_HIP(hipMemcpyAsync(e_so, es.data(), sizeof(double) * (O + V), hipMemcpyHostToDevice, cx.stream));
+        cx.sync();
+    }
+    TriplesIn in{e_so, s.t1.d, vs.d, nullptr, s.t2.d, o, v};
+    double* Xpool = cx.scratch("t_xpool", 3 * p->nb * vp3);
+    double* partial = cx.scratch("t_partial", std::max<int64_t>((int64_t)p->norb * p->nb, 512));
+    for (const TriplesPlan::Chunk& ch : p->chunks) {
+        const int64_t* tabs = p->tables + ch.tab_off;
+        for (const TriplesPlan::Group& g : ch.groups) {
+            GettProblem gp;
+            gp.A = vt.d + Kc * v2 * g.r;
+            gp.B = tt.d;
+            gp.C = Xpool;
+            gp.offAm = p->tables + p->off_Am; gp.offAk = p->tables + p->off_k; gp.offBk = p->tables + p->off_k;
+            gp.offBn = tabs + g.start;
+            gp.offCm = p->tables + p->off_Cm; gp.offCn = tabs + ch.ntab + g.start;
+            gp.M = (int)v2; gp.N = (int)g.N; gp.K = (int)Kc;
+            gp.alpha = 1.0; gp.beta = 0.0;
+            gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
+            gp.a_kcontig = gp.b_kcontig = true;
+            gp.wide = (V % 2 == 0);
+            AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+        }
+        hipLaunchKernelGGL(triples_so_orbit_kernel, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,
+                           p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
+        AFESP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(triples_sum_kernel, dim3(1), dim3(256), 0, cx.stream, cx.scal, partial, p->norb * ch.nt);
+        AFESP_HIP(hipGetLastError());
+    }
+    double* h = host_scalars(cx, 1);
+    return h[0];
 }
 
 }  // namespace afesp

@@ -212,4 +212,107 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
     }
 }
 
+// Spin-orbital (T), ccsd.f90:1812-1922.  For i<j<k the three GEMM blocks Y^{i;jk}, Y^{j;ik}, Y^{k;ij} (triples.hip,
+// so_triples) give the connected numerator before P(a/bc):  R = Y^{i;jk} - Y^{j;ik} + Y^{k;ij}  (all three in the same
+// (a,b,c) orientation, so R is assembled in registers straight from the 16-byte cube loads); then
+//   t3c = R(abc) - R(bac) - R(cba)                                         :1894-1896 (reshape orders (2,1,3), (3,2,1))
+//   t3d = P(a/bc)[t1(i,a)<jk||bc> - t1(j,a)<ik||bc> - t1(k,a)<ji||bc>]     :1873-1874, :1890-1892
+//   E_T += t3c (t3c + t3d) / D / 6      (the reference sums all ordered (i,j,k) with 1/36; the summand is antisymmetric)
+// One workgroup = the orbit of one 8x8x8 cube under index permutation, as in the spin-free kernel.
+__global__ __launch_bounds__(256, 3) void triples_so_orbit_kernel(double* __restrict__ partial, const double* __restrict__ Xpool,
+                                                                 const TripleMeta* __restrict__ meta,
+                                                                 const int* __restrict__ orbits, TriplesIn in, int nblk_total)
+{
+    __shared__ __attribute__((aligned(16))) double wl[6 * CUBE];   // R on the six cubes of the orbit
+    __shared__ double vp[27 * PATCH];                              // <pq||xy> patches for pairs (j,k), (i,k), (i,j)
+    __shared__ double t1r[72];                                     // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l)
+    __shared__ int srcq[6][6];
+    __shared__ int dup[6];
+    __shared__ double red[4];
+    const TripleMeta m = meta[blockIdx.y];
+    const int o = in.o, v = in.v, t = threadIdx.x;
+    const int packed = orbits[blockIdx.x];
+    const int tile[3] = {packed & 1023, (packed >> 10) & 1023, (packed >> 20) & 1023};
+    if (t < 36) {
+        const int s = t / 6, q = t % 6;
+        int want[3];
+        for (int d = 0; d < 3; ++d) want[d] = tile[sig(q, sig(s, d))];
+        int found = 0;
+        for (int r = 5; r >= 0; --r)
+            if (tile[sig(r, 0)] == want[0] && tile[sig(r, 1)] == want[1] && tile[sig(r, 2)] == want[2]) found = r;
+        srcq[s][q] = found;
+        if (s == 0) dup[q] = (found != q);
+    }
+    const int64_t vv = (int64_t)v * v;
+    const int nt8 = (v + TT - 1) / TT;
+    const int p0 = (2 * t) & 7, p1 = (t >> 2) & 7, p2 = t >> 5;
+    const int sbase = (((p0 ^ p1 ^ p2) & 7) & ~1) | (p1 << 3) | (p2 << 6);
+    const bool flip = ((p1 ^ p2) & 1) != 0;
+    typedef double v2d_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int T0 = tile[sig(q, 0)], T1 = tile[sig(q, 1)], T2 = tile[sig(q, 2)];
+        const int64_t off = (int64_t)CUBE * (T0 + (int64_t)nt8 * (T1 + (int64_t)nt8 * T2)) + 2 * t;
+        const v2d_t x0 = *reinterpret_cast<const v2d_t*>(Xpool + m.xoff[0] + off);
+        const v2d_t x1 = *reinterpret_cast<const v2d_t*>(Xpool + m.xoff[1] + off);
+        const v2d_t x2 = *reinterpret_cast<const v2d_t*>(Xpool + m.xoff[2] + off);
+        const int g0 = T0 * TT + p0;
+        const bool rows = (T1 * TT + p1 < v) && (T2 * TT + p2 < v);
+        const double r0 = (rows && g0 < v) ? x0[0] - x1[0] + x2[0] : 0.0;
+        const double r1 = (rows && g0 + 1 < v) ? x0[1] - x1[1] + x2[1] : 0.0;
+        *reinterpret_cast<v2d_t*>(&wl[q * CUBE + sbase]) = flip ? (v2d_t){r1, r0} : (v2d_t){r0, r1};
+    }
+    const int occ[3] = {m.i, m.j, m.k};
+    const int pairp[3] = {m.j, m.i, m.i}, pairq[3] = {m.k, m.k, m.j};
+    for (int el = t; el < 27 * PATCH; el += 256) {
+        const int pr = el / (9 * PATCH), rest = el % (9 * PATCH), sx = rest / (3 * PATCH), sy = (rest / PATCH) % 3, loc = rest % PATCH;
+        const int gx = tile[sx] * TT + (loc & 7), gy = tile[sy] * TT + (loc >> 3);
+        const bool ok = gx < v && gy < v;
+        const int64_t off = ok ? gx + (int64_t)v * gy + vv * (pairp[pr] + (int64_t)o * pairq[pr]) : 0;
+        const double a = in.voovv_s[off];
+        vp[el] = ok ? a : 0.0;
+    }
+    if (t < 72) {
+        const int oc = t / 24, sl = (t / 8) % 3, l = t & 7, g = tile[sl] * TT + l;
+        t1r[t] = g < v ? in.t1[occ[oc] + o * g] : 0.0;
+    }
+    __syncthreads();
+    const int l0 = t & 7, l1 = (t >> 3) & 7, l2h[2] = {t >> 6, (t >> 6) + 4};
+    const double eo = in.e[m.i] + in.e[m.j] + in.e[m.k];
+    double acc = 0.0;
+#pragma unroll 1
+    for (int q = 0; q < 6; ++q) {
+        if (dup[q]) continue;
+        const int sa = sig(q, 0), sb = sig(q, 1), sc = sig(q, 2);
+        const int ta = sa == 0 ? tile[0] : sa == 1 ? tile[1] : tile[2];
+        const int tb = sb == 0 ? tile[0] : sb == 1 ? tile[1] : tile[2];
+        const int tc = sc == 0 ? tile[0] : sc == 1 ? tile[1] : tile[2];
+        const int slot[3] = {sa, sb, sc};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int l[3] = {l0, l1, l2h[h]};
+            const int ga = ta * TT + l[0], gb = tb * TT + l[1], gc = tc * TT + l[2];
+            const bool live = ga < v && gb < v && gc < v;
+            const double D = eo - in.e[(ga < v ? ga : 0) + o] - in.e[(gb < v ? gb : 0) + o] - in.e[(gc < v ? gc : 0) + o];
+#define WAT(s) wl[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])]
+#define T1R(oc, d) t1r[(oc) * 24 + slot[d] * 8 + l[d]]
+#define VP(pr, dx, dy) vp[((pr) * 9 + slot[dx] * 3 + slot[dy]) * PATCH + l[dx] + TT * l[dy]]
+#define RAW(x, y, z) (T1R(0, x) * VP(0, y, z) - T1R(1, x) * VP(1, y, z) + T1R(2, x) * VP(2, y, z))
+            const double t3c = wl[q * CUBE + cidx(l[0], l[1], l[2])] - WAT(1) - WAT(2);
+            const double t3d = RAW(0, 1, 2) - RAW(1, 0, 2) - RAW(2, 1, 0);
+            acc += live ? t3c * (t3c + t3d) / D : 0.0;
+#undef WAT
+#undef T1R
+#undef VP
+#undef RAW
+        }
+    }
+    const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (t == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) / 6.0;
+}
+
 }  // namespace afesp

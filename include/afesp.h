@@ -86,6 +86,33 @@ int afesp_ccsd_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[4]);
 int afesp_ccsd_cr_intermediates(afesp_ctx* ctx);
 int afesp_ccsd_t_cr(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[6]);
 
+/* Spin-orbital path: replaces `call do_ccsd_spinorb(sys, int_store, int_store_cc)` (src/main.F90:67,
+ * src/ccsd.f90:71-277) and `call do_ccsd_t_spinorb(...)` (src/main.F90:79, src/ccsd.f90:1812-1922).
+ * Spin orbitals are interleaved alpha,beta (src/ccsd.f90:108-143); the spin-orbital extents are the reference's
+ * (src/geometry.f90:44-45): nocc = nel, nvirt = 2*nbasis - nel.  Arrays: t1(nocc,nvirt), t2(nocc,nocc,nvirt,nvirt).
+ *   afesp_ccsd_so_init    = antisymmetrised integrals + slices (:108-207), init_cc(.not.restricted), init_diis_cc_t.
+ *                           eri_mo_packed NULL = the MO integrals afesp_ao2mo_mp2 left on the device; canon_levels has
+ *                           nbasis entries (spatial).  flags bit 0 (AFESP_SO_FOO_AS_PUBLISHED): put the tau~ term of F_mi
+ *                           where Stanton's Eq. 4 has it; by default it lands transposed, as src/ccsd.f90:789-794 codes it
+ *                           (the reference's shipped ref_out predates that dgemm and needs the flag to be reproduced).
+ *   afesp_ccsd_so_energy  = update_cc_energy, unrestricted branch (:1783-1806); same outputs as afesp_ccsd_energy.
+ *   afesp_ccsd_so_iterate = build_tau, build_F, build_W, update_amplitudes, update_cc_energy (:229-251 loop body).
+ *   afesp_ccsd_so_diis    = update_diis_cc (:274).
+ *   afesp_ccsd_so_t       = E_T of src/ccsd.f90:1910 restricted to the triples i<j<k numbered [t_begin, t_end) of
+ *                           afesp_ccsd_so_t_ntriples(nocc) (the summand is antisymmetric in i,j,k; shards add up). */
+#define AFESP_SO_FOO_AS_PUBLISHED 1
+int afesp_ccsd_so_init(afesp_ctx* ctx, int64_t nbasis, int64_t nel, const double* eri_mo_packed, const double* canon_levels,
+                       int diis_n_errmat, int flags);
+int afesp_ccsd_so_energy(afesp_ctx* ctx, double e_tol, double t_tol, double* energy, double* rms_sq, int* converged);
+int afesp_ccsd_so_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* energy, double* rms_sq, int* converged);
+int afesp_ccsd_so_diis(afesp_ctx* ctx);
+int afesp_ccsd_so_get_amplitudes(afesp_ctx* ctx, double* t1, double* t2);
+int afesp_ccsd_so_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2);
+/* name: F_vv F_oo F_ov W_oooo (stored i,j,m,n) W_vvvv (stored e,f,a,b) W_ovvo tau tau_tilde oovv vvvv t1 t2 */
+int afesp_ccsd_so_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t capacity);
+int64_t afesp_ccsd_so_t_ntriples(int64_t nocc);
+int afesp_ccsd_so_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double* e_t);
+
 /* Operator layer (src/linalg.fpp), exported for parity tests against the oracle.
  * afesp_gemm    = dgemm_wrapper (src/linalg.fpp:58-89): C(m x n) = alpha op(A) op(B) + beta C, host arrays.
  * afesp_permute4 = omp_reshape (src/linalg.fpp:99-156): out(perm) = beta*out + in; has_beta=0 zeroes `out` first. */
