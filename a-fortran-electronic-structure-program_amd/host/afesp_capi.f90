@@ -6,7 +6,8 @@ module afesp_capi
    private
    public :: afesp_ctx_create, afesp_ctx_destroy, afesp_last_error, afesp_ao2mo_mp2, afesp_ccsd_init, afesp_ccsd_energy, &
              afesp_ccsd_iterate, afesp_ccsd_diis, afesp_ccsd_get_amplitudes, afesp_ccsd_t, afesp_ccsd_t_ntriples, &
-             afesp_neri, afesp_error_text, afesp_ccsd_cr_intermediates, afesp_ccsd_t_cr
+             afesp_neri, afesp_error_text, afesp_ccsd_cr_intermediates, afesp_ccsd_t_cr, afesp_ccsd_so_init, &
+             afesp_ccsd_so_energy, afesp_ccsd_so_iterate, afesp_ccsd_so_diis, afesp_ccsd_so_t, afesp_ccsd_so_t_ntriples
 
    interface
       function afesp_ctx_create(device, ctx) bind(C, name='afesp_ctx_create') result(rc)
@@ -106,6 +107,54 @@ module afesp_capi
          type(c_ptr), value :: ctx
          integer(c_int64_t), value :: t_begin, t_end
          real(c_double), intent(out) :: out(6)
+         integer(c_int) :: rc
+      end function
+      !> replaces the integral/slice/init part of do_ccsd_spinorb (reference src/ccsd.f90:100-215); flags bit 0 = Stanton's
+      !> index order for the tau~ term of F_mi (see include/afesp.h)
+      function afesp_ccsd_so_init(ctx, nbasis, nel, eri_mo_packed, canon_levels, diis_n_errmat, flags) &
+         bind(C, name='afesp_ccsd_so_init') result(rc)
+         import :: c_int, c_int64_t, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int64_t), value :: nbasis, nel
+         type(c_ptr), value :: eri_mo_packed
+         real(c_double), intent(in) :: canon_levels(*)
+         integer(c_int), value :: diis_n_errmat, flags
+         integer(c_int) :: rc
+      end function
+      !> update_cc_energy, unrestricted branch (reference src/ccsd.f90:217)
+      function afesp_ccsd_so_energy(ctx, e_tol, t_tol, energy, rms_sq, converged) bind(C, name='afesp_ccsd_so_energy') result(rc)
+         import :: c_int, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         real(c_double), value :: e_tol, t_tol
+         real(c_double), intent(out) :: energy, rms_sq
+         integer(c_int), intent(out) :: converged
+         integer(c_int) :: rc
+      end function
+      !> build_tau, build_F, build_W, update_amplitudes, update_cc_energy (reference src/ccsd.f90:238-245)
+      function afesp_ccsd_so_iterate(ctx, e_tol, t_tol, energy, rms_sq, converged) bind(C, name='afesp_ccsd_so_iterate') result(rc)
+         import :: c_int, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         real(c_double), value :: e_tol, t_tol
+         real(c_double), intent(out) :: energy, rms_sq
+         integer(c_int), intent(out) :: converged
+         integer(c_int) :: rc
+      end function
+      function afesp_ccsd_so_diis(ctx) bind(C, name='afesp_ccsd_so_diis') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int) :: rc
+      end function
+      function afesp_ccsd_so_t_ntriples(nocc) bind(C, name='afesp_ccsd_so_t_ntriples') result(n)
+         import :: c_int64_t
+         integer(c_int64_t), value :: nocc
+         integer(c_int64_t) :: n
+      end function
+      !> replaces `call do_ccsd_t_spinorb(...)` (reference src/main.F90:79): e_t = E_T of src/ccsd.f90:1910
+      function afesp_ccsd_so_t(ctx, t_begin, t_end, e_t) bind(C, name='afesp_ccsd_so_t') result(rc)
+         import :: c_int, c_int64_t, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int64_t), value :: t_begin, t_end
+         real(c_double), intent(out) :: e_t
          integer(c_int) :: rc
       end function
    end interface

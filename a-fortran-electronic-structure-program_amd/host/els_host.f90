@@ -37,6 +37,7 @@ module host_config
       logical :: write_fcidump = .false., scf_read_guess = .false., scf_write_guess = .false.
       integer :: level = LEVEL_CCSD_T
       logical :: paren = .false., renorm = .false., comp_renorm = .false.
+      logical :: spinorb = .false.   ! the _spinorb calculation types (reference src/system.f90:117-137)
    end type
 contains
    !> &elsinput namelist; keys that are absent keep the defaults above (the reference leaves them undefined).
@@ -73,8 +74,11 @@ contains
       case ('RCCSD[T]_spatial'); cfg%level = LEVEL_CCSD_T; cfg%renorm = .true.
       case ('CRCCSD(T)_spatial'); cfg%level = LEVEL_CCSD_T; cfg%paren = .true.; cfg%comp_renorm = .true.
       case ('CRCCSD[T]_spatial'); cfg%level = LEVEL_CCSD_T; cfg%comp_renorm = .true.
-      case ('UHF', 'MP2_spinorb', 'CCSD_spinorb', 'CCSD(T)_spinorb')
-         call fail('system::read_system_in', 'spin-orbital calculation types are not part of the MI355X engine')
+      ! the reference runs its restricted SCF and the spin-free MP2 for these as well (src/main.F90:49-64)
+      case ('UHF');              cfg%level = LEVEL_RHF; cfg%spinorb = .true.
+      case ('MP2_spinorb');      cfg%level = LEVEL_MP2; cfg%spinorb = .true.
+      case ('CCSD_spinorb');     cfg%level = LEVEL_CCSD; cfg%spinorb = .true.
+      case ('CCSD(T)_spinorb');  cfg%level = LEVEL_CCSD_T; cfg%spinorb = .true.
       case default
          call fail('system::read_system_in', 'Unrecognised calculation type!')
       end select
@@ -391,8 +395,13 @@ program els_amd
    write (out, '(1X, 20("-"))'); write (out, '(1X, A)') 'System information'; write (out, '(1X, 20("-"))')
    write (out, '(1X, A, 1X, I0)') 'Number of electrons:', mol%nel
    write (out, '(1X, A, 1X, I0)') 'Number of basis functions:', mol%nbasis
-   write (out, '(1X, A, 1X, I0)') 'Number of occupied orbitals:', mol%nocc
-   write (out, '(1X, A, 1X, I0)') 'Number of virtual orbitals:', mol%nvirt
+   if (cfg%spinorb) then   ! spin-orbital counts, reference src/geometry.f90:44-45
+      write (out, '(1X, A, 1X, I0)') 'Number of occupied orbitals:', mol%nel
+      write (out, '(1X, A, 1X, I0)') 'Number of virtual orbitals:', 2*mol%nbasis - mol%nel
+   else
+      write (out, '(1X, A, 1X, I0)') 'Number of occupied orbitals:', mol%nocc
+      write (out, '(1X, A, 1X, I0)') 'Number of virtual orbitals:', mol%nvirt
+   end if
    write (out, '(1X, A, 1X, ES15.8)') 'E_nuc:', mol%e_nuc
    write (out, '(1X, A, 1X, A)') 'calc_type:', trim(cfg%calc_type)
 
@@ -422,7 +431,61 @@ program els_amd
       t1s = seconds()
       write (out, '(1X, A, 1X, F16.8, A)') 'Time taken for restricted MP2:', t1s - t0, 's'
 
-      if (cfg%level >= LEVEL_CCSD) then
+      if (cfg%level >= LEVEL_CCSD .and. cfg%spinorb) then
+         ! ---------------- spin-orbital CCSD (reference do_ccsd_spinorb, src/ccsd.f90:71-277), same loop structure
+         t0 = seconds()
+         write (out, '(1X, 10("-"))'); write (out, '(1X, A)') 'CCSD'; write (out, '(1X, 10("-"))')
+         write (out, '(1X, A)') 'Forming antisymmetrised spinorbital ERIs...'
+         write (out, '(1X, A)') 'Forming slices of antisymmetrised spinorbital ERIs'
+         write (out, '(1X, A)') 'Initialise CC intermediate tensors and DIIS auxilliary arrays...'
+         ! AFESP_SO_FOO_AS_PUBLISHED=1: tau~ term of F_mi in Stanton's index order (what the reference's shipped
+         ! ref_out was computed with); default: as src/ccsd.f90:789-794 accumulates it today
+         call get_environment_variable('AFESP_SO_FOO_AS_PUBLISHED', envval)
+         rc = afesp_ccsd_so_init(ctx, int(mol%nbasis, c_int64_t), int(mol%nel, c_int64_t), c_null_ptr, levels, &
+                                 int(cfg%ccsd_diis_n_errmat, c_int), merge(1_c_int, 0_c_int, trim(envval) == '1'))
+         if (rc /= 0) call fail('ccsd::init_cc', afesp_error_text(ctx))
+         write (out, '(1X, A, 1X, F8.6, A)') 'Time taken:', seconds() - t0, ' s'
+         write (out, *)
+         write (out, '(1X, A)') 'Initialisation done, now entering iterative CC solver...'
+         rc = afesp_ccsd_so_energy(ctx, cfg%ccsd_e_tol, cfg%ccsd_t_tol, energy, rms, conv)
+         if (rc /= 0) call fail('ccsd::update_cc_energy', afesp_error_text(ctx))
+         write (out, '(75("-"))')
+         write (out, '(1X, A, 3X, A, 3X, A, 3X, A, 3X, A)') 'Iteration', '     Energy    ', '    deltaE     ', '  delta RMS T2 ', '  Time  '
+         write (out, '(75("-"))')
+         write (out, '(1X, A9, 3X, F15.12, 3X, F15.12, 3X, F15.12)') 'MP1', energy, energy, rms
+         t1s = seconds()
+         do iter = 1, cfg%ccsd_maxiter
+            eold = energy
+            rc = afesp_ccsd_so_iterate(ctx, cfg%ccsd_e_tol, cfg%ccsd_t_tol, energy, rms, conv)
+            if (rc /= 0) call fail('ccsd::update_amplitudes', afesp_error_text(ctx))
+            write (out, '(1X, I9, 3X, F15.12, 3X, F15.12, 3X, F15.12, 3X, F8.6)') iter, energy, energy - eold, rms, seconds() - t1s
+            t1s = seconds()
+            if (conv /= 0) then
+               cc_ok = .true.
+               exit
+            end if
+            rc = afesp_ccsd_so_diis(ctx)
+            if (rc /= 0) call fail('ccsd::update_diis_cc', 'Linear solve failed!')
+         end do
+         if (cc_ok) then
+            write (out, '(75("-"))')
+            write (out, '(1X, A)') 'Convergence reached within tolerance.'
+            write (out, '(1X, A, 1X, F15.12)') 'Final CCSD Energy (Hartree):', energy
+            e_ccsd = energy; e_highest = e_ccsd
+         end if
+         write (out, '(1X, A, 1X, F16.8, A)') 'Time taken for unrestricted CCSD:', seconds() - t0, 's'
+         if (cfg%level == LEVEL_CCSD_T .and. cc_ok) then
+            ! ---------------- spin-orbital (T) (reference do_ccsd_t_spinorb, src/ccsd.f90:1812-1922)
+            t0 = seconds()
+            write (out, '(1X, 10("-"))'); write (out, '(1X, A)') 'CCSD(T)'; write (out, '(1X, 10("-"))')
+            rc = afesp_ccsd_so_t(ctx, 0_c_int64_t, afesp_ccsd_so_t_ntriples(int(mol%nel, c_int64_t)), tq(1))
+            if (rc /= 0) call fail('ccsd::do_ccsd_t_spinorb', afesp_error_text(ctx))
+            e_pt = e_ccsd + tq(1)
+            e_highest = e_pt
+            write (out, '(1X, A, 1X, F15.9)') 'Unrestricted CCSD(T) correlation energy (Hartree):', e_pt
+            write (out, '(1X, A, 1X, F16.8, A)') 'Time taken for unrestricted CCSD(T):', seconds() - t0, 's'
+         end if
+      else if (cfg%level >= LEVEL_CCSD) then
          ! ---------------- CCSD (reference do_ccsd_spatial): the solver loop stays here, one C call per reference call
          t0 = seconds()
          write (out, '(1X, 10("-"))'); write (out, '(1X, A)') 'CCSD'; write (out, '(1X, 10("-"))')
@@ -527,7 +590,10 @@ program els_amd
       write (out, '(1X, A, 1X, F15.10)') 'CCSD correlation energy:       ', e_ccsd
       write (out, '(1X, A, 1X, F15.10)') 'CCSD energy:                   ', e_ccsd + e_hf + mol%e_nuc
    end if
-   if (cfg%level == LEVEL_CCSD_T) then
+   if (cfg%level == LEVEL_CCSD_T .and. cfg%spinorb) then        ! reference src/main.F90:156-158
+      write (out, '(1X, A, 1X, F15.10)') 'CCSD(T) correlation energy:    ', e_pt
+      write (out, '(1X, A, 1X, F15.10)') 'CCSD(T) energy:                ', e_pt + e_hf + mol%e_nuc
+   else if (cfg%level == LEVEL_CCSD_T) then
       write (out, '(1X, A, 1X, F15.10)') 'CCSD[T] correlation energy:    ', e_bt
       write (out, '(1X, A, 1X, F15.10)') 'CCSD[T] energy:                ', e_bt + e_hf + mol%e_nuc
       if (cfg%paren) then
@@ -551,7 +617,7 @@ program els_amd
          end if
       end if
    end if
-   if (cfg%level >= LEVEL_CCSD) then
+   if (cfg%level >= LEVEL_CCSD .and. .not. cfg%spinorb) then    ! reference src/main.F90:162
       write (out, '(1X, 47("-"))')
       write (out, '(1X, A, 1X, F15.10)') 'T1 diagnostic:                 ', t1diag
    end if

@@ -7,6 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "a-fortran-electronic-structure-program_amd"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The oracle (oracle/liborc.so) is OpenMP code; a GPU box advertises far more hardware threads than its CPU share, and
+# libgomp's spinning workers then oversubscribe it (32 s instead of 1 s for one spin-orbital solve).  Must be set before
+# the library is loaded.
+os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 
 def pytest_configure(config):

@@ -73,3 +73,36 @@ def test_host_plain_ccsd_t_compat_printout(tmp_path):
 def test_host_rejects_unknown_calc_type(tmp_path):
     res, _ = run_host(tmp_path, "h2o-cc-pvdz", "CCSDT_spatial")
     assert res.returncode != 0 and "Unrecognised calculation type" in res.stderr
+
+
+def test_host_spinorbital_run_reproduces_shipped_ref_out(tmp_path):
+    """calc_type = CCSD_spinorb with the tolerances of the shipped spin-orbital run (ref_out: 1e-6 / 1e-7): the whole
+    iteration table and the final energies of that file.  AFESP_SO_FOO_AS_PUBLISHED=1, see include/afesp.h."""
+    import re
+    gold_it = [float(m.group(1)) for m in re.finditer(r"Iteration\s+\d+\s+(-0\.\d{12})\s+[\d.]+ s",
+                                                      open(os.path.join(molecules.GOLDEN, "h2o-cc-pvdz", "ref_out")).read())]
+    res, got = run_host(tmp_path, "h2o-cc-pvdz", "CCSD_spinorb", {"AFESP_SO_FOO_AS_PUBLISHED": "1"})
+    assert res.returncode == 0, res.stderr
+    assert "Number of occupied orbitals: 10" in res.stdout and "Number of virtual orbitals: 38" in res.stdout
+    rows = [r for r in got["cc_iters"] if r[0] > 0]                 # row 0 is the "MP1" line
+    assert [r[0] for r in rows] == list(range(1, 20))
+    for (it, e, de, rms), g in zip(rows, gold_it):
+        assert abs(e - g) < 2e-11
+    assert abs(got["ccsd_corr"] - (-0.3115626487)) < 2e-10          # "E_CCSD_corr" of ref_out
+    assert abs(got["total"] - (-75.8879259297)) < 2e-9              # "Total energy" of ref_out
+    assert "T1 diagnostic" not in res.stdout                        # src/main.F90:162: restricted runs only
+
+
+def test_host_spinorbital_ccsd_t_against_oracle(tmp_path):
+    """calc_type = CCSD(T)_spinorb as the current source computes it (default flags) against the CPU restatement."""
+    import orc
+    res, got = run_host(tmp_path, "h2o-cc-pvdz", "CCSD(T)_spinorb")
+    assert res.returncode == 0, res.stderr
+    si, ints, rhf_res, _ = molecules.load("h2o-cc-pvdz")
+    so = orc.OracleSO(ints.nbasis, ints.nel, orc.ao2mo(ints.nbasis, rhf_res.canon_coeff, ints.eri), rhf_res.canon_levels,
+                      si.ccsd_diis_n_errmat)
+    nit, en, _ = so.solve(si.ccsd_maxiter, si.ccsd_e_tol, si.ccsd_t_tol)
+    assert [r[0] for r in got["cc_iters"] if r[0] > 0] == list(range(1, nit + 1))
+    assert abs(got["ccsd_corr"] - so.energy) < 1e-9
+    assert abs(got["ccsd_pt_corr"] - (so.energy + so.triples())) < 1e-9
+    assert "Unrestricted CCSD(T) correlation energy (Hartree):" in res.stdout
