@@ -26,6 +26,7 @@ EXPORTS = [
     "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder", "afesp_bench_contract", "afesp_set_tuning", "afesp_bench_stream", "afesp_profile", "afesp_ccsd_cr_intermediates", "afesp_ccsd_t_cr",
     "afesp_ccsd_so_init", "afesp_ccsd_so_energy", "afesp_ccsd_so_iterate", "afesp_ccsd_so_diis", "afesp_ccsd_so_get_amplitudes",
     "afesp_ccsd_so_set_amplitudes", "afesp_ccsd_so_get_tensor", "afesp_ccsd_so_t_ntriples", "afesp_ccsd_so_t",
+    "afesp_read_eri_text", "afesp_write_fcidump",
 ]
 
 
@@ -52,7 +53,7 @@ def load_library():
     L.afesp_last_error.restype = C.c_char_p
     L.afesp_neri.argtypes = [i64]
     L.afesp_neri.restype = i64
-    L.afesp_ao2mo_mp2.argtypes = [C.c_void_p, i64, i64, _dp, _dp, _dp, _opt, C.POINTER(dbl)]
+    L.afesp_ao2mo_mp2.argtypes = [C.c_void_p, i64, i64, _dp, _dp, _opt, _opt, C.POINTER(dbl)]
     L.afesp_ccsd_init.argtypes = [C.c_void_p, i64, i64, _opt, _dp, C.c_int]
     L.afesp_ccsd_iterate.argtypes = [C.c_void_p, dbl, dbl, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_int)]
     L.afesp_ccsd_energy.argtypes = [C.c_void_p, dbl, dbl, C.POINTER(dbl), C.POINTER(dbl), C.POINTER(C.c_int)]
@@ -89,6 +90,8 @@ def load_library():
     L.afesp_ccsd_so_t_ntriples.argtypes = [i64]
     L.afesp_ccsd_so_t_ntriples.restype = i64
     L.afesp_ccsd_so_t.argtypes = [C.c_void_p, i64, i64, C.POINTER(dbl)]
+    L.afesp_read_eri_text.argtypes = [C.c_void_p, C.c_char_p, i64, _opt, C.POINTER(i64)]
+    L.afesp_write_fcidump.argtypes = [C.c_void_p, C.c_char_p, i64, C.POINTER(i64)]
     _lib = L
     return L
 
@@ -141,8 +144,11 @@ class Engine:
     def do_mp2_spatial(self, nbasis, nocc, canon_coeff, canon_levels, eri_packed, want_eri_mo=True):
         e2 = dbl(0.0)
         out = np.zeros(self.L.afesp_neri(nbasis)) if want_eri_mo else None
-        self._chk(self.L.afesp_ao2mo_mp2(self.h, nbasis, nocc, _f(canon_coeff), _f(canon_levels),
-                                         np.ascontiguousarray(eri_packed, dtype=np.float64),
+        src = None   # None: the AO integrals read_eri_text left on the device
+        if eri_packed is not None:
+            eri_packed = np.ascontiguousarray(eri_packed, dtype=np.float64)
+            src = eri_packed.ctypes.data_as(C.c_void_p)
+        self._chk(self.L.afesp_ao2mo_mp2(self.h, nbasis, nocc, _f(canon_coeff), _f(canon_levels), src,
                                          out.ctypes.data_as(C.c_void_p) if out is not None else None, C.byref(e2)))
         return e2.value, out
 
@@ -211,6 +217,20 @@ class Engine:
             t_end = self.ntriples()
         self._chk(self.L.afesp_ccsd_t(self.h, t_begin, t_end, out))
         return out
+
+    # ---- input / output side: src/integrals.f90:146-161, src/mp2.f90:451-487
+    def read_eri_text(self, path, nbasis, want_host_copy=True):
+        """-> (packed AO integrals or None, number of lines); the packed array also stays on the device."""
+        out = np.zeros(self.L.afesp_neri(nbasis)) if want_host_copy else None
+        n = i64()
+        self._chk(self.L.afesp_read_eri_text(self.h, str(path).encode(), nbasis,
+                                             out.ctypes.data_as(C.c_void_p) if out is not None else None, C.byref(n)))
+        return out, n.value
+
+    def write_fcidump(self, path, nbasis):
+        n = i64()
+        self._chk(self.L.afesp_write_fcidump(self.h, str(path).encode(), nbasis, C.byref(n)))
+        return n.value
 
     # ---- spin-orbital path: do_ccsd_spinorb (src/ccsd.f90:71-277), do_ccsd_t_spinorb (:1812-1922)
     SO_SHAPES = {"F_vv": "vv", "F_oo": "oo", "F_ov": "ov", "W_oooo": "oooo", "W_vvvv": "vvvv", "W_ovvo": "ovvo", "tau": "oovv",

@@ -1,6 +1,9 @@
 // capi.hip -- extern "C" boundary (include/afesp.h), the AO->MO transform, and the synthetic-input generators.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/afesp.h"
 #include "ccsd.h"
@@ -14,6 +17,8 @@ struct afesp_ctx {
     SOState so;
     double* eri_mo_dev = nullptr;   // packed MO integrals left on the device by afesp_ao2mo_mp2
     int64_t eri_mo_n = 0;           // nbasis they belong to
+    double* eri_ao_dev = nullptr;   // packed AO integrals uploaded by afesp_read_eri_text
+    int64_t eri_ao_n = 0;
 };
 
 namespace {
@@ -111,7 +116,13 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         const int64_t n = nbasis, o = nocc, v = n - o, ne = neri_of(n);
         if (n <= 0 || o <= 0 || v <= 0 || n > 1024) throw Error(1, "afesp_ao2mo_mp2: bad extents");
         double* packed = cx.alloc(ne);
-        AFESP_HIP(hipMemcpyAsync(packed, eri_packed, sizeof(double) * ne, hipMemcpyHostToDevice, cx.stream));
+        if (eri_packed) {
+            AFESP_HIP(hipMemcpyAsync(packed, eri_packed, sizeof(double) * ne, hipMemcpyHostToDevice, cx.stream));
+        } else {
+            if (!ctx->eri_ao_dev || ctx->eri_ao_n != n)
+                throw Error(1, "afesp_ao2mo_mp2: eri_packed is NULL and no AO integrals were read onto the device for this basis size");
+            AFESP_HIP(hipMemcpyAsync(packed, ctx->eri_ao_dev, sizeof(double) * ne, hipMemcpyDeviceToDevice, cx.stream));
+        }
         Tensor Cm = cx.tensor({n, n});
         AFESP_HIP(hipMemcpyAsync(Cm.d, canon_coeff, sizeof(double) * n * n, hipMemcpyHostToDevice, cx.stream));
         Tensor Ta = cx.tensor({n, n, n, n}), Tb = cx.tensor({n, n, n, n});
@@ -327,6 +338,113 @@ int afesp_ccsd_t_cr(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[6
     return guarded(ctx, [&] {
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         ccsd_triples(ctx->cx, ctx->cc, t_begin, t_end, out, true);
+    });
+}
+
+// ---------------------------------------------------------------- input / output side of the path
+// read_integrals_in, two-body part (src/integrals.f90:146-161): lines "i j a b value", 1-based, any blank separation, in
+// any order; a later line for the same packed slot overwrites an earlier one; slots never mentioned stay 0.
+int afesp_read_eri_text(afesp_ctx* ctx, const char* path, int64_t nbasis, double* eri_packed, int64_t* nread)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        if (nbasis <= 0 || nbasis > 1024 || !path) throw Error(1, "afesp_read_eri_text: bad arguments");
+        const int64_t ne = neri_of(nbasis);
+        FILE* f = fopen(path, "rb");
+        if (!f) throw Error(2, std::string("afesp_read_eri_text: cannot open ") + path);
+        std::vector<double> host((size_t)ne, 0.0);
+        std::vector<char> buf((size_t)(8 << 20) + 1);
+        size_t keep = 0;
+        int64_t lines = 0;
+        bool bad = false;
+        auto tri = [](int64_t i, int64_t j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; };
+        for (;;) {
+            const size_t got = fread(buf.data() + keep, 1, buf.size() - 1 - keep, f);
+            const size_t have = keep + got;
+            if (have == 0) break;
+            buf[have] = 0;
+            // parse whole lines only; the tail (an incomplete line) is carried into the next block
+            size_t end = have;
+            if (got > 0) {
+                while (end > 0 && buf[end - 1] != '\n') --end;
+                if (end == 0 && have == buf.size() - 1) { bad = true; break; }   // a "line" longer than the buffer
+                if (end == 0) end = 0;
+            }
+            const size_t stop = got > 0 ? end : have;
+            char* p = buf.data();
+            char* const lim = buf.data() + stop;
+            const char saved = *lim;
+            *lim = 0;
+            while (p < lim) {
+                while (p < lim && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) ++p;
+                if (p >= lim) break;
+                char* q;
+                long idx[4];
+                bool ok = true;
+                for (int k = 0; k < 4 && ok; ++k) {
+                    idx[k] = strtol(p, &q, 10);
+                    ok = (q != p);
+                    p = q;
+                }
+                const double val = ok ? strtod(p, &q) : 0.0;
+                ok = ok && (q != p);
+                if (!ok) { bad = true; break; }
+                p = q;
+                for (int k = 0; k < 4; ++k)
+                    if (idx[k] < 1 || idx[k] > nbasis) ok = false;
+                if (!ok) { bad = true; break; }
+                host[(size_t)tri(tri(idx[0] - 1, idx[1] - 1), tri(idx[2] - 1, idx[3] - 1))] = val;
+                ++lines;
+                while (p < lim && *p != '\n') ++p;   // ignore anything else on the line
+            }
+            *lim = saved;
+            if (bad || got == 0) break;
+            keep = have - stop;
+            memmove(buf.data(), buf.data() + stop, keep);
+        }
+        fclose(f);
+        if (bad) throw Error(2, std::string("afesp_read_eri_text: malformed line or index outside 1..nbasis in ") + path);
+        if (ctx->eri_ao_dev) cx.release(ctx->eri_ao_dev);
+        ctx->eri_ao_dev = cx.alloc(ne);
+        ctx->eri_ao_n = nbasis;
+        AFESP_HIP(hipMemcpyAsync(ctx->eri_ao_dev, host.data(), sizeof(double) * ne, hipMemcpyHostToDevice, cx.stream));
+        cx.sync();
+        if (eri_packed) memcpy(eri_packed, host.data(), sizeof(double) * ne);
+        if (nread) *nread = lines;
+    });
+}
+
+// write_fcidump (src/mp2.f90:451-487): the packed MO integrals in canonical order, one line "p q r s value" in format
+// (I3,I3,I3,I3,ES17.9) for every |value| > 1e-7 (no header, no one-electron part -- as the reference writes it).
+int afesp_write_fcidump(afesp_ctx* ctx, const char* path, int64_t nbasis, int64_t* nwritten)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        if (!ctx->eri_mo_dev || ctx->eri_mo_n != nbasis || !path)
+            throw Error(1, "afesp_write_fcidump: no MO integrals resident for this basis size (call afesp_ao2mo_mp2 first)");
+        const int64_t ne = neri_of(nbasis);
+        std::vector<double> host((size_t)ne);
+        AFESP_HIP(hipMemcpyAsync(host.data(), ctx->eri_mo_dev, sizeof(double) * ne, hipMemcpyDeviceToHost, cx.stream));
+        cx.sync();
+        FILE* f = fopen(path, "w");
+        if (!f) throw Error(2, std::string("afesp_write_fcidump: cannot open ") + path);
+        int64_t pqrs = 0, lines = 0;
+        for (int64_t p = 1; p <= nbasis; ++p)
+            for (int64_t q = 1; q <= p; ++q)
+                for (int64_t r = 1; r <= p; ++r) {
+                    const int64_t s_up = (p == r) ? q : r;
+                    for (int64_t s = 1; s <= s_up; ++s) {
+                        const double x = host[(size_t)pqrs++];
+                        if (std::fabs(x) > 1e-7) {
+                            fprintf(f, "%3d%3d%3d%3d%17.9E\n", (int)p, (int)q, (int)r, (int)s, x);
+                            ++lines;
+                        }
+                    }
+                }
+        fclose(f);
+        if (nwritten) *nwritten = lines;
     });
 }
 

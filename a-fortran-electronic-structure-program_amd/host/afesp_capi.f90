@@ -7,7 +7,8 @@ module afesp_capi
    public :: afesp_ctx_create, afesp_ctx_destroy, afesp_last_error, afesp_ao2mo_mp2, afesp_ccsd_init, afesp_ccsd_energy, &
              afesp_ccsd_iterate, afesp_ccsd_diis, afesp_ccsd_get_amplitudes, afesp_ccsd_t, afesp_ccsd_t_ntriples, &
              afesp_neri, afesp_error_text, afesp_ccsd_cr_intermediates, afesp_ccsd_t_cr, afesp_ccsd_so_init, &
-             afesp_ccsd_so_energy, afesp_ccsd_so_iterate, afesp_ccsd_so_diis, afesp_ccsd_so_t, afesp_ccsd_so_t_ntriples
+             afesp_ccsd_so_energy, afesp_ccsd_so_iterate, afesp_ccsd_so_diis, afesp_ccsd_so_t, afesp_ccsd_so_t_ntriples, &
+             afesp_read_eri_text, afesp_write_fcidump
 
    interface
       function afesp_ctx_create(device, ctx) bind(C, name='afesp_ctx_create') result(rc)
@@ -36,7 +37,8 @@ module afesp_capi
          import :: c_int, c_int64_t, c_double, c_ptr
          type(c_ptr), value :: ctx
          integer(c_int64_t), value :: nbasis, nocc
-         real(c_double), intent(in) :: canon_coeff(*), canon_levels(*), eri_packed(*)
+         real(c_double), intent(in) :: canon_coeff(*), canon_levels(*)
+         type(c_ptr), value :: eri_packed             ! c_loc(int_store%eri), or c_null_ptr after afesp_read_eri_text
          type(c_ptr), value :: eri_mo_packed          ! c_null_ptr keeps the MO integrals on the device only
          real(c_double), intent(out) :: e_mp2
          integer(c_int) :: rc
@@ -107,6 +109,26 @@ module afesp_capi
          type(c_ptr), value :: ctx
          integer(c_int64_t), value :: t_begin, t_end
          real(c_double), intent(out) :: out(6)
+         integer(c_int) :: rc
+      end function
+      !> replaces the two-body loop of read_integrals_in (reference src/integrals.f90:146-161); the packed AO integrals
+      !> also stay on the device for afesp_ao2mo_mp2(..., eri_packed = c_null_ptr, ...)
+      function afesp_read_eri_text(ctx, path, nbasis, eri_packed, nread) bind(C, name='afesp_read_eri_text') result(rc)
+         import :: c_int, c_int64_t, c_double, c_ptr, c_char
+         type(c_ptr), value :: ctx
+         character(kind=c_char), intent(in) :: path(*)
+         integer(c_int64_t), value :: nbasis
+         real(c_double), intent(out) :: eri_packed(*)
+         integer(c_int64_t), intent(out) :: nread
+         integer(c_int) :: rc
+      end function
+      !> replaces write_fcidump (reference src/mp2.f90:451-487)
+      function afesp_write_fcidump(ctx, path, nbasis, nwritten) bind(C, name='afesp_write_fcidump') result(rc)
+         import :: c_int, c_int64_t, c_ptr, c_char
+         type(c_ptr), value :: ctx
+         character(kind=c_char), intent(in) :: path(*)
+         integer(c_int64_t), value :: nbasis
+         integer(c_int64_t), intent(out) :: nwritten
          integer(c_int) :: rc
       end function
       !> replaces the integral/slice/init part of do_ccsd_spinorb (reference src/ccsd.f90:100-215); flags bit 0 = Stanton's

@@ -133,8 +133,11 @@ contains
       close (unit)
    end subroutine
 
-   subroutine read_molecule(mol)
+   !> engine_reads_eri: leave mol%eri allocated and zero -- the caller fills it with afesp_read_eri_text, which also
+   !> leaves the packed AO integrals on the device (reference loop: src/integrals.f90:146-161)
+   subroutine read_molecule(mol, engine_reads_eri)
       type(molecule), intent(out) :: mol
+      logical, intent(in) :: engine_reads_eri
       real(dp), allocatable :: ke(:, :), en(:, :), xyz(:, :)
       integer, allocatable :: z(:)
       integer :: unit, ios, i, j, k, l, a
@@ -148,14 +151,16 @@ contains
       npair = int(mol%nbasis, i8)*(mol%nbasis + 1)/2
       neri = npair*(npair + 1)/2
       allocate (mol%eri(neri)); mol%eri = 0.0_dp
-      open (newunit=unit, file='eri.dat', status='old', action='read')
-      do
-         read (unit, *, iostat=ios) i, j, k, l, x
-         if (ios /= 0) exit
-         mol%eri(eri_slot(i, j, k, l)) = x
-      end do
-      close (unit)
-      write (out, *) 'Done reading integrals!'
+      if (.not. engine_reads_eri) then
+         open (newunit=unit, file='eri.dat', status='old', action='read')
+         do
+            read (unit, *, iostat=ios) i, j, k, l, x
+            if (ios /= 0) exit
+            mol%eri(eri_slot(i, j, k, l)) = x
+         end do
+         close (unit)
+         write (out, *) 'Done reading integrals!'
+      end if
       open (newunit=unit, file='geom.dat', status='old', action='read')
       read (unit, *) mol%natoms
       allocate (z(mol%natoms), xyz(3, mol%natoms))
@@ -382,7 +387,8 @@ program els_amd
    real(dp) :: e_bt, e_pt, e_rbt, e_rpt, e_crbt, e_crpt
    integer(c_int) :: rc, conv
    integer :: iter, device
-   logical :: scf_ok, cc_ok, compat
+   logical :: scf_ok, cc_ok, compat, have_ctx
+   integer(c_int64_t) :: nlines
    character(len=32) :: envval
    character(len=80) :: calcname
 
@@ -391,7 +397,20 @@ program els_amd
    write (out, '(1X, A)') 'A Fortran Electronic Structure Programme (AFESP) -- MI355X engine host'
    write (out, '(1X, 64("="))')
    call read_config(cfg)
-   call read_molecule(mol)
+   ! Post-HF levels: the engine context exists from the start, and the engine reads eri.dat (the packed AO integrals
+   ! then stay on the device for the AO->MO transform; the host copy feeds the SCF)
+   have_ctx = cfg%level >= LEVEL_MP2
+   call read_molecule(mol, have_ctx)
+   if (have_ctx) then
+      device = 0
+      call get_environment_variable('AFESP_DEVICE', envval)
+      if (len_trim(envval) > 0) read (envval, *) device
+      rc = afesp_ctx_create(int(device, c_int), ctx)
+      if (rc /= 0) call fail('main', 'no usable MI355X device: afesp_ctx_create failed (the engine has no CPU fallback)')
+      rc = afesp_read_eri_text(ctx, 'eri.dat'//c_null_char, int(mol%nbasis, c_int64_t), mol%eri, nlines)
+      if (rc /= 0) call fail('integrals::read_integrals_in', afesp_error_text(ctx))
+      write (out, *) 'Done reading integrals!'
+   end if
    write (out, '(1X, 20("-"))'); write (out, '(1X, A)') 'System information'; write (out, '(1X, 20("-"))')
    write (out, '(1X, A, 1X, I0)') 'Number of electrons:', mol%nel
    write (out, '(1X, A, 1X, I0)') 'Number of basis functions:', mol%nbasis
@@ -413,21 +432,21 @@ program els_amd
    e_bt = 0.0_dp; e_pt = 0.0_dp; e_rbt = 0.0_dp; e_rpt = 0.0_dp; e_crbt = 0.0_dp; e_crpt = 0.0_dp
 
    if (cfg%level >= LEVEL_MP2 .and. scf_ok) then
-      device = 0
-      call get_environment_variable('AFESP_DEVICE', envval)
-      if (len_trim(envval) > 0) read (envval, *) device
-      rc = afesp_ctx_create(int(device, c_int), ctx)
-      if (rc /= 0) call fail('main', 'no usable MI355X device: afesp_ctx_create failed (the engine has no CPU fallback)')
-
       ! ---------------- MP2: AO->MO transform + energy on the device (reference do_mp2_spatial)
       t0 = seconds()
       write (out, '(1X, 10("-"))'); write (out, '(1X, A)') 'MP2'; write (out, '(1X, 10("-"))')
       write (out, '(1X, A)') 'Performing AO to MO ERI transformation...'
-      rc = afesp_ao2mo_mp2(ctx, int(mol%nbasis, c_int64_t), int(mol%nocc, c_int64_t), coeff, levels, mol%eri, c_null_ptr, e_mp2)
+      rc = afesp_ao2mo_mp2(ctx, int(mol%nbasis, c_int64_t), int(mol%nocc, c_int64_t), coeff, levels, c_null_ptr, c_null_ptr, e_mp2)
       if (rc /= 0) call fail('mp2::do_mp2_spatial', afesp_error_text(ctx))
       write (out, '(1X, A)') 'Calculating MP2 energy...'
       write (out, '(1X, A, 1X, F15.8)') 'MP2 correlation energy (Hartree):', e_mp2
       e_highest = e_mp2
+      if (cfg%write_fcidump) then        ! reference src/mp2.f90:445-447
+         write (out, '(1X, A)') 'Writing FCIDUMP file...'
+         rc = afesp_write_fcidump(ctx, 'FCIDUMP'//c_null_char, int(mol%nbasis, c_int64_t), nlines)
+         if (rc /= 0) call fail('mp2::write_fcidump', afesp_error_text(ctx))
+         write (out, '(1X, A)') 'Done writing FCIDUMP file!'
+      end if
       t1s = seconds()
       write (out, '(1X, A, 1X, F16.8, A)') 'Time taken for restricted MP2:', t1s - t0, 's'
 
@@ -573,10 +592,10 @@ program els_amd
             write (out, '(1X, A, 1X, F16.8, A)') 'Time taken for restricted '//trim(calcname)//':', seconds() - t0, 's'
          end if
       end if
-      call afesp_ctx_destroy(ctx)
    else if (scf_ok) then
       e_highest = 0.0_dp
    end if
+   if (have_ctx) call afesp_ctx_destroy(ctx)
 
    ! ---------------- final table: same labels and formats as the reference (src/main.F90:123-175)
    write (out, '(1X, 64("="))')

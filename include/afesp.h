@@ -35,7 +35,8 @@ int afesp_version(void);
 int64_t afesp_neri(int64_t nbasis); /* packed length, src/integrals.f90:175-176 */
 
 /* Replaces `call do_mp2_spatial(sys, int_store)` (src/main.F90:98, src/mp2.f90:261-449).
- *   in : nbasis n, nocc o, canon_coeff[n*n] (MO,AO), canon_levels[n], eri_packed[neri] (AO basis)
+ *   in : nbasis n, nocc o, canon_coeff[n*n] (MO,AO), canon_levels[n], eri_packed[neri] (AO basis; may be NULL after
+ *        afesp_read_eri_text -- the AO integrals are then already on the device)
  *   out: eri_mo_packed[neri] (may be NULL: the MO integrals then stay on the device only), *e_mp2
  * The transformed integrals stay resident in the context for afesp_ccsd_init(..., eri_mo_packed = NULL). */
 int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* canon_coeff, const double* canon_levels,
@@ -85,6 +86,16 @@ int afesp_ccsd_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[4]);
  * so that E_CR[T] = out[4]/out[2] and E_CR(T) = out[5]/out[3] (src/ccsd.f90:2268-2272).  Same sharding contract. */
 int afesp_ccsd_cr_intermediates(afesp_ctx* ctx);
 int afesp_ccsd_t_cr(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[6]);
+
+/* Input/output side of the path.
+ * afesp_read_eri_text replaces the two-body loop of read_integrals_in (src/integrals.f90:146-161): parses `eri.dat`
+ * ("i j a b value", 1-based) straight into the 8-fold packed array and leaves it ON THE DEVICE, so that a following
+ * afesp_ao2mo_mp2(..., eri_packed = NULL, ...) transforms without another host pass; eri_packed (may be NULL) also
+ * receives the packed host copy the SCF needs, *nread the number of lines.
+ * afesp_write_fcidump replaces write_fcidump (src/mp2.f90:451-487) from the MO integrals resident after
+ * afesp_ao2mo_mp2: same line format (I3,I3,I3,I3,ES17.9), same 1e-7 threshold, same (header-less) content. */
+int afesp_read_eri_text(afesp_ctx* ctx, const char* path, int64_t nbasis, double* eri_packed, int64_t* nread);
+int afesp_write_fcidump(afesp_ctx* ctx, const char* path, int64_t nbasis, int64_t* nwritten);
 
 /* Spin-orbital path: replaces `call do_ccsd_spinorb(sys, int_store, int_store_cc)` (src/main.F90:67,
  * src/ccsd.f90:71-277) and `call do_ccsd_t_spinorb(...)` (src/main.F90:79, src/ccsd.f90:1812-1922).

@@ -171,3 +171,45 @@ def test_errors_are_reported_not_swallowed(eng):
     from afesp_amd.capi import AfespError
     with pytest.raises(AfespError):
         eng.ccsd_init(0, 5, np.zeros(5), np.zeros(int(orc.lib().orc_neri(5))), 8)
+
+
+def test_eri_text_reader_and_fcidump_writer(eng, tmp_path):
+    """Input/output side of the path (integrals.f90:146-161, mp2.f90:451-487): eri.dat -> device -> AO->MO -> FCIDUMP."""
+    import os
+    from afesp_amd import inputs
+    si, ints, res, _ = molecules.load("h2o-cc-pvdz")
+    n, o = ints.nbasis, ints.nel // 2
+    path = os.path.join(molecules.GOLDEN, "h2o-cc-pvdz", "eri.dat")
+    packed, nlines = eng.read_eri_text(path, n)
+    assert nlines == sum(1 for _ in open(path))
+    assert np.array_equal(packed, ints.eri)                      # bit-identical to the host-side reader
+    e_mp2, eri_mo = eng.do_mp2_spatial(n, o, res.canon_coeff, res.canon_levels, None)   # integrals already resident
+    assert abs(e_mp2 - molecules.SURVEY_GOLD["h2o-cc-pvdz"]["mp2_corr"]) < 1e-9
+    out = tmp_path / "FCIDUMP"
+    nw = eng.write_fcidump(out, n)
+    # restate write_fcidump: canonical packed order, |x| > 1e-7, (I3,I3,I3,I3,ES17.9)
+    expect = []
+    k = 0
+    for p in range(1, n + 1):
+        for q in range(1, p + 1):
+            for r in range(1, p + 1):
+                for s in range(1, (q if p == r else r) + 1):
+                    x = eri_mo[k]
+                    k += 1
+                    if abs(x) > 1e-7:
+                        expect.append((p, q, r, s, x))
+    assert k == inputs.neri(n) and nw == len(expect)
+    lines = open(out).read().splitlines()
+    assert len(lines) == len(expect)
+    for line, (p, q, r, s, x) in zip(lines[::97] + lines[-3:], expect[::97] + expect[-3:]):
+        assert len(line) == 29
+        assert (int(line[0:3]), int(line[3:6]), int(line[6:9]), int(line[9:12])) == (p, q, r, s)
+        assert line[12:] == "%17.9E" % x and abs(float(line[12:]) - x) <= 5e-10 * abs(x)
+    # malformed input is an error, not a silent zero
+    bad = tmp_path / "bad.dat"
+    bad.write_text("1 1 1 1 0.5\n1 1 99 1 0.25\n")
+    from afesp_amd.capi import AfespError
+    with pytest.raises(AfespError):
+        eng.read_eri_text(bad, n)
+    with pytest.raises(AfespError):
+        eng.read_eri_text(tmp_path / "missing.dat", n)

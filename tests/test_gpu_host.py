@@ -106,3 +106,29 @@ def test_host_spinorbital_ccsd_t_against_oracle(tmp_path):
     assert abs(got["ccsd_corr"] - so.energy) < 1e-9
     assert abs(got["ccsd_pt_corr"] - (so.energy + so.triples())) < 1e-9
     assert "Unrestricted CCSD(T) correlation energy (Hartree):" in res.stdout
+
+
+def test_host_writes_fcidump_when_asked(tmp_path):
+    """write_fcidump = .true. (src/mp2.f90:445-447): the file holds the packed MO integrals above 1e-7."""
+    src = os.path.join(molecules.GOLDEN, "h2o-cc-pvdz")
+    for f in ("s.dat", "t.dat", "v.dat", "eri.dat", "geom.dat"):
+        shutil.copy(os.path.join(src, f), tmp_path)
+    text = open(os.path.join(src, "els.in")).read().replace("CRCCSD(T)_spatial", "MP2_spatial")
+    assert "write_fcidump = .false." in text
+    text = text.replace("write_fcidump = .false.", "write_fcidump = .true.")
+    (tmp_path / "els.in").write_text(text)
+    res = subprocess.run([EXE], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    assert "Writing FCIDUMP file..." in res.stdout and "Done writing FCIDUMP file!" in res.stdout
+    import orc
+    si, ints, rhf_res, _ = molecules.load("h2o-cc-pvdz")
+    ref = orc.ao2mo(ints.nbasis, rhf_res.canon_coeff, ints.eri)
+    lines = open(tmp_path / "FCIDUMP").read().splitlines()
+    assert len(lines) == int((abs(ref) > 1e-7).sum())
+    # each line addresses its packed slot; values to the 10 significant digits written (magnitudes: the host's own SCF
+    # may fix orbital phases differently from the Python mirror used for the expected numbers)
+    for line in lines[::211]:
+        p, q, r, s = (int(line[k:k + 3]) for k in (0, 3, 6, 9))
+        tri = lambda a, b: max(a, b) * (max(a, b) - 1) // 2 + min(a, b)
+        slot = tri(tri(p, q), tri(r, s)) - 1
+        assert abs(abs(float(line[12:])) - abs(ref[slot])) < 2e-9 * max(1.0, abs(ref[slot]))
