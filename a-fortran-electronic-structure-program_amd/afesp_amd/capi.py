@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libafesp_hip.so")
+# AFESP_LIBRARY: a differently built libafesp_hip (A/B kernel measurements inside one GPU session, tools/ab_gemm.py)
+LIB_PATH = os.environ.get("AFESP_LIBRARY") or os.path.join(os.path.dirname(_HERE), "csrc", "libafesp_hip.so")
 
 i64 = C.c_int64
 dbl = C.c_double

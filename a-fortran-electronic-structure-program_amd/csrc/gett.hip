@@ -304,6 +304,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
     // data of step g+1 and is written to the other LDS buffer; set (qa,qb) receives step g+2.  The single barrier sits
     // between sub-steps 2 and 3: every read of buffer `cur` has been issued before it and every write of buffer cur^1 is
     // complete, so after it the next step's first fragments can be read while sub-step 3 still multiplies.
+    // Two waves share each SIMD in the 8-wave tiles, and the younger half (waves 4-7) loses VALU arbitration to the older
+    // one at equal priority (MI355X_MICROARCH.md, two waves per SIMD): one static raise, no per-cluster flips
+    // (A/B in one session, o=20 v=200: ring 61.3 -> 62.0 TF, pp-ladder 49.5 -> 50.0 TF; flips around every MFMA
+    // cluster instead: -1 %).
+    if (NT == 512 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     int kt = 0, ctile = 0;
 #define AFESP_GETT_STEP(qa, qb, pa, pb)                                                         \
     {                                                                                           \
