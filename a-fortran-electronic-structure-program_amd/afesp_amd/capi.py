@@ -27,7 +27,7 @@ EXPORTS = [
     "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder", "afesp_bench_contract", "afesp_set_tuning", "afesp_bench_stream", "afesp_profile", "afesp_ccsd_cr_intermediates", "afesp_ccsd_t_cr",
     "afesp_ccsd_so_init", "afesp_ccsd_so_energy", "afesp_ccsd_so_iterate", "afesp_ccsd_so_diis", "afesp_ccsd_so_get_amplitudes",
     "afesp_ccsd_so_set_amplitudes", "afesp_ccsd_so_get_tensor", "afesp_ccsd_so_t_ntriples", "afesp_ccsd_so_t",
-    "afesp_read_eri_text", "afesp_write_fcidump",
+    "afesp_read_eri_text", "afesp_write_fcidump", "afesp_set_eri", "afesp_build_fock",
 ]
 
 
@@ -93,6 +93,8 @@ def load_library():
     L.afesp_ccsd_so_t.argtypes = [C.c_void_p, i64, i64, C.POINTER(dbl)]
     L.afesp_read_eri_text.argtypes = [C.c_void_p, C.c_char_p, i64, _opt, C.POINTER(i64)]
     L.afesp_write_fcidump.argtypes = [C.c_void_p, C.c_char_p, i64, C.POINTER(i64)]
+    L.afesp_set_eri.argtypes = [C.c_void_p, i64, _dp]
+    L.afesp_build_fock.argtypes = [C.c_void_p, i64, _dp, _dp, _dp]
     _lib = L
     return L
 
@@ -227,6 +229,15 @@ class Engine:
         self._chk(self.L.afesp_read_eri_text(self.h, str(path).encode(), nbasis,
                                              out.ctypes.data_as(C.c_void_p) if out is not None else None, C.byref(n)))
         return out, n.value
+
+    def set_eri(self, nbasis, eri_packed):
+        self._chk(self.L.afesp_set_eri(self.h, nbasis, np.ascontiguousarray(eri_packed, dtype=np.float64)))
+
+    def build_fock(self, nbasis, density, core_hamil):
+        """src/hf.f90:349-385 on the device-resident packed AO integrals."""
+        out = np.zeros(nbasis * nbasis)
+        self._chk(self.L.afesp_build_fock(self.h, nbasis, _f(density), _f(core_hamil), out))
+        return out.reshape((nbasis, nbasis), order="F")
 
     def write_fcidump(self, path, nbasis):
         n = i64()

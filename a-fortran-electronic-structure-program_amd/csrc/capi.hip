@@ -415,6 +415,40 @@ int afesp_read_eri_text(afesp_ctx* ctx, const char* path, int64_t nbasis, double
     });
 }
 
+// Packed AO integrals from a host array (for callers that already hold int_store%eri), same residency as the reader's.
+int afesp_set_eri(afesp_ctx* ctx, int64_t nbasis, const double* eri_packed)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        if (nbasis <= 0 || nbasis > 1024 || !eri_packed) throw Error(1, "afesp_set_eri: bad arguments");
+        const int64_t ne = neri_of(nbasis);
+        if (ctx->eri_ao_dev) cx.release(ctx->eri_ao_dev);
+        ctx->eri_ao_dev = cx.alloc(ne);
+        ctx->eri_ao_n = nbasis;
+        AFESP_HIP(hipMemcpyAsync(ctx->eri_ao_dev, eri_packed, sizeof(double) * ne, hipMemcpyHostToDevice, cx.stream));
+        cx.sync();
+    });
+}
+
+// build_fock (src/hf.f90:349-385) on the resident packed AO integrals
+int afesp_build_fock(afesp_ctx* ctx, int64_t nbasis, const double* density, const double* core_hamil, double* fock)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        if (!ctx->eri_ao_dev || ctx->eri_ao_n != nbasis || !density || !core_hamil || !fock)
+            throw Error(1, "afesp_build_fock: no AO integrals resident for this basis size (afesp_read_eri_text / afesp_set_eri)");
+        const int64_t n2 = nbasis * nbasis;
+        double* buf = cx.scratch("fock_io", 3 * n2);
+        AFESP_HIP(hipMemcpyAsync(buf, density, sizeof(double) * n2, hipMemcpyHostToDevice, cx.stream));
+        AFESP_HIP(hipMemcpyAsync(buf + n2, core_hamil, sizeof(double) * n2, hipMemcpyHostToDevice, cx.stream));
+        k_build_fock(cx, buf + 2 * n2, buf + n2, buf, ctx->eri_ao_dev, (int)nbasis);
+        AFESP_HIP(hipMemcpyAsync(fock, buf + 2 * n2, sizeof(double) * n2, hipMemcpyDeviceToHost, cx.stream));
+        cx.sync();
+    });
+}
+
 // write_fcidump (src/mp2.f90:451-487): the packed MO integrals in canonical order, one line "p q r s value" in format
 // (I3,I3,I3,I3,ES17.9) for every |value| > 1e-7 (no header, no one-electron part -- as the reference writes it).
 int afesp_write_fcidump(afesp_ctx* ctx, const char* path, int64_t nbasis, int64_t* nwritten)

@@ -240,6 +240,26 @@ __global__ void slice_phys_kernel(double* out, const double* packed, int d0, int
         out[x] = packed[tri(tri(p + b0, r + b2), tri(q + b1, s + b3))];
     }
 }
+// build_fock (hf.f90:349-385): F(i,j) = H(i,j) + sum_kl D(k,l) [2 (ij|kl) - (ik|jl)] from the packed AO integrals.
+// One workgroup per (i,j); the n^2 terms are strided over the threads and summed in a fixed order (bit-reproducible).
+__global__ __launch_bounds__(256) void build_fock_kernel(double* fock, const double* hcore, const double* dens, const double* packed, int n)
+{
+    __shared__ double red[256];
+    const int i = blockIdx.x % n, j = blockIdx.x / n;
+    const int64_t ij = tri(i, j);
+    double s = 0.0;
+    for (int kl = threadIdx.x; kl < n * n; kl += 256) {
+        const int k = kl % n, l = kl / n;
+        s += dens[kl] * (2.0 * packed[tri(ij, tri(k, l))] - packed[tri(tri(i, k), tri(j, l))]);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) fock[blockIdx.x] = hcore[blockIdx.x] + red[0];
+}
 }  // namespace
 
 #define LAUNCH(kernel, grid, ...)                                               \
@@ -330,6 +350,12 @@ void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1
 {
     int64_t n = (int64_t)d0 * d1 * d2 * d3;
     if (n > 0) LAUNCH(slice_phys_kernel, dim3(grid_for(n, 65536)), out, packed, d0, d1, d2, d3, b0, b1, b2, b3);
+}
+
+void k_build_fock(Context& cx, double* fock, const double* hcore, const double* dens, const double* packed, int n)
+{
+    hipLaunchKernelGGL(build_fock_kernel, dim3((unsigned)(n * n)), dim3(256), 0, cx.stream, fock, hcore, dens, packed, n);
+    AFESP_HIP(hipGetLastError());
 }
 
 }  // namespace afesp

@@ -8,7 +8,7 @@ module afesp_capi
              afesp_ccsd_iterate, afesp_ccsd_diis, afesp_ccsd_get_amplitudes, afesp_ccsd_t, afesp_ccsd_t_ntriples, &
              afesp_neri, afesp_error_text, afesp_ccsd_cr_intermediates, afesp_ccsd_t_cr, afesp_ccsd_so_init, &
              afesp_ccsd_so_energy, afesp_ccsd_so_iterate, afesp_ccsd_so_diis, afesp_ccsd_so_t, afesp_ccsd_so_t_ntriples, &
-             afesp_read_eri_text, afesp_write_fcidump
+             afesp_read_eri_text, afesp_write_fcidump, afesp_build_fock
 
    interface
       function afesp_ctx_create(device, ctx) bind(C, name='afesp_ctx_create') result(rc)
@@ -120,6 +120,15 @@ module afesp_capi
          integer(c_int64_t), value :: nbasis
          real(c_double), intent(out) :: eri_packed(*)
          integer(c_int64_t), intent(out) :: nread
+         integer(c_int) :: rc
+      end function
+      !> replaces build_fock (reference src/hf.f90:349-385) on the packed AO integrals resident after afesp_read_eri_text
+      function afesp_build_fock(ctx, nbasis, density, core_hamil, fock) bind(C, name='afesp_build_fock') result(rc)
+         import :: c_int, c_int64_t, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int64_t), value :: nbasis
+         real(c_double), intent(in) :: density(*), core_hamil(*)
+         real(c_double), intent(out) :: fock(*)
          integer(c_int) :: rc
       end function
       !> replaces write_fcidump (reference src/mp2.f90:451-487)

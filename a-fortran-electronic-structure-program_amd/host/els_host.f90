@@ -257,18 +257,23 @@ contains
 end module host_linalg
 
 module host_scf
+   use, intrinsic :: iso_c_binding
    use host_support
    use host_config
    use host_inputs
    use host_linalg
+   use afesp_capi
    implicit none
 contains
    !> Restricted Hartree-Fock with the reference's iteration (src/hf.f90:21-151): symmetric orthogonalisation, Fock
    !> guess = H_core or guess_in.dat, DIIS on FDS-SDF from the second stored matrix on, convergence on |dD| and |dE|.
    !> Returns canon_coeff(MO, AO) and canon_levels.
-   subroutine rhf(cfg, mol, e_hf, coeff, levels, converged)
+   !> on_device: the O(n^4) Fock build (src/hf.f90:349-385) runs on the engine, from the packed AO integrals it read.
+   subroutine rhf(cfg, mol, e_hf, coeff, levels, converged, ctx, on_device)
       type(run_config), intent(in) :: cfg
       type(molecule), intent(in) :: mol
+      type(c_ptr), intent(in) :: ctx
+      logical, intent(in) :: on_device
       real(dp), intent(out) :: e_hf
       real(dp), allocatable, intent(out) :: coeff(:, :), levels(:)
       logical, intent(out) :: converged
@@ -320,6 +325,10 @@ contains
             exit
          end if
          ! Fock build: F = H + sum_kl D(k,l) [2 (ij|kl) - (ik|jl)]
+         if (on_device) then
+            if (afesp_build_fock(ctx, int(n, c_int64_t), dens, mol%hcore, fock) /= 0) &
+               call fail('hf::build_fock', afesp_error_text(ctx))
+         else
          do j = 1, n
             do i = 1, n
                val = mol%hcore(i, j)
@@ -331,6 +340,7 @@ contains
                fock(i, j) = val
             end do
          end do
+         end if
          if (m >= 2) then
             slot = slot + 1; if (slot > m) slot = slot - m
             if (nact < m) nact = nact + 1
@@ -425,7 +435,7 @@ program els_amd
    write (out, '(1X, A, 1X, A)') 'calc_type:', trim(cfg%calc_type)
 
    t0 = seconds()
-   call rhf(cfg, mol, e_hf, coeff, levels, scf_ok)
+   call rhf(cfg, mol, e_hf, coeff, levels, scf_ok, ctx, have_ctx)
    t1s = seconds()
    write (out, '(1X, A, 1X, F16.8, A)') 'Time taken for restricted Hartree-Fock:', t1s - t0, 's'
    e_highest = 0.0_dp; e_mp2 = 0.0_dp; e_ccsd = 0.0_dp; t1diag = 0.0_dp; tq = 0.0_dp; cc_ok = .false.

@@ -95,6 +95,11 @@ int afesp_ccsd_t_cr(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[6
  * afesp_write_fcidump replaces write_fcidump (src/mp2.f90:451-487) from the MO integrals resident after
  * afesp_ao2mo_mp2: same line format (I3,I3,I3,I3,ES17.9), same 1e-7 threshold, same (header-less) content. */
 int afesp_read_eri_text(afesp_ctx* ctx, const char* path, int64_t nbasis, double* eri_packed, int64_t* nread);
+/* The same residency from an array the caller already holds (int_store%eri). */
+int afesp_set_eri(afesp_ctx* ctx, int64_t nbasis, const double* eri_packed);
+/* Replaces build_fock (src/hf.f90:349-385), the O(n^4) step of every SCF iteration, on the resident packed AO
+ * integrals: fock(i,j) = core_hamil(i,j) + sum_kl density(k,l) [2 (ij|kl) - (ik|jl)]; n x n column-major host arrays. */
+int afesp_build_fock(afesp_ctx* ctx, int64_t nbasis, const double* density, const double* core_hamil, double* fock);
 int afesp_write_fcidump(afesp_ctx* ctx, const char* path, int64_t nbasis, int64_t* nwritten);
 
 /* Spin-orbital path: replaces `call do_ccsd_spinorb(sys, int_store, int_store_cc)` (src/main.F90:67,

@@ -713,3 +713,15 @@ void orc_permute4(const i64 dims[4], const char *order, const double *in, double
             out[dst] = (has_beta ? beta * out[dst] : 0.0) + in[src];
         }
 }
+
+/* hf.f90:349-385 build_fock */
+void orc_build_fock(i64 n, const double *eri, const double *dens, const double *hcore, double *fock)
+{
+#pragma omp parallel for collapse(2)
+    for (i64 j = 0; j < n; ++j) for (i64 i = 0; i < n; ++i) {
+        double x = hcore[i + n * j];
+        for (i64 l = 0; l < n; ++l) for (i64 k = 0; k < n; ++k)
+            x += dens[k + n * l] * (2.0 * eri[orc_eri_index(i, j, k, l)] - eri[orc_eri_index(i, k, j, l)]);
+        fock[i + n * j] = x;
+    }
+}

@@ -69,6 +69,8 @@ def lib():
     L.orc_permute4.restype = None
     L.orc_linsolve.argtypes = [C.c_int, dp, dp]
     L.orc_linsolve.restype = C.c_int
+    L.orc_build_fock.argtypes = [i64, dp, dp, dp, dp]
+    L.orc_build_fock.restype = None
     # spin-orbital path (afesp_oracle_so.c)
     L.orc_so_create.restype = C.c_void_p
     L.orc_so_create.argtypes = [i64, i64, dp, dp, C.c_int]
@@ -257,3 +259,12 @@ class OracleSO:
 
     def triples(self):
         return self.L.orc_so_triples(self.h)
+
+
+def build_fock(n, eri, dens, hcore):
+    """hf.f90:349-385; dens/hcore are (n,n) arrays, returned Fock matrix too."""
+    L = lib()
+    out = np.zeros(n * n)
+    L.orc_build_fock(n, np.ascontiguousarray(eri), np.ascontiguousarray(dens.ravel(order="F")),
+                     np.ascontiguousarray(hcore.ravel(order="F")), out)
+    return out.reshape((n, n), order="F")

@@ -213,3 +213,21 @@ def test_eri_text_reader_and_fcidump_writer(eng, tmp_path):
         eng.read_eri_text(bad, n)
     with pytest.raises(AfespError):
         eng.read_eri_text(tmp_path / "missing.dat", n)
+
+
+def test_build_fock_on_device_matches_restatement(eng):
+    """hf.f90:349-385 on the resident packed AO integrals, against the CPU restatement, for a converged and a random density."""
+    si, ints, res, _ = molecules.load("h2o-cc-pvdz")
+    n, o = ints.nbasis, ints.nel // 2
+    eng.set_eri(n, ints.eri)
+    hcore = ints.core_hamil
+    rng = np.random.default_rng(5)
+    dens_rand = rng.standard_normal((n, n))
+    dens_conv = res.canon_coeff[:o, :].T @ res.canon_coeff[:o, :]
+    for dens in (dens_conv, dens_rand + dens_rand.T, dens_rand):
+        f_dev = eng.build_fock(n, dens, hcore)
+        f_ref = orc.build_fock(n, ints.eri, dens, hcore)
+        assert np.max(np.abs(f_dev - f_ref)) < 1e-12 * max(1.0, np.max(np.abs(f_ref)))
+    # the converged density reproduces the SCF energy of the reference (E = sum D (H + F), hf.f90:341)
+    e = float(np.sum(dens_conv * (hcore + eng.build_fock(n, dens_conv, hcore))))
+    assert abs(e + ints.e_nuc - molecules.SURVEY_GOLD["h2o-cc-pvdz"]["rhf_total"]) < 1e-6
