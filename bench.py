@@ -245,7 +245,7 @@ def main():
     ap.add_argument("--workload", default="h2o_tz", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
     ap.add_argument("--no-extra", dest="extra", action="store_false",
-                    help="skip the additional config-5 (o=20, v=200) measurement appended at N=1")
+                    help="skip the additional config-5 (o=20, v=200) measurement appended to the line")
     ap.add_argument("--scale", type=float, default=None)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the multi-rank path on a one-GPU box")
@@ -272,7 +272,7 @@ def main():
 
     res = measure(args, args.workload, args.steps, args.warmup, rank, world, local, dist, cdev, torch)
     extra = None
-    if world == 1 and args.extra and args.workload != "cfg5":
+    if args.extra and args.workload != "cfg5":
         # the only configuration where the fp64 MFMA roofline is meaningful: config 5, one step
         extra = measure(args, "cfg5", 1, 1, rank, world, local, dist, cdev, torch, with_roofline=True)
     if rank == 0:
