@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Wall time of the plain and the completely renormalised (T) at a synthetic size (default o=20, v=200)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "a-fortran-electronic-structure-program_amd"))
+from afesp_amd.capi import Engine
+o, v = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (20, 200)
+eng = Engine(0)
+eng.synthetic_init(o, v, 0.005, 12345, 8)
+eng.ccsd_energy()
+for it in range(2):
+    eng.ccsd_iterate(); eng.ccsd_diis()
+for rep in range(2):
+    t0 = time.perf_counter(); out = eng.do_ccsd_t_spatial(); t1 = time.perf_counter()
+    print("(T)    %.3f s" % (t1 - t0), out[:2])
+t0 = time.perf_counter(); eng.build_cr_intermediates(); t1 = time.perf_counter()
+print("CR intermediates %.3f s" % (t1 - t0))
+for rep in range(2):
+    t0 = time.perf_counter(); out = eng.do_ccsd_t_spatial_cr(); t1 = time.perf_counter()
+    print("CR-(T) %.3f s" % (t1 - t0), out[:2], out[4:])
+eng.close()
