@@ -53,6 +53,23 @@ struct Context {
     std::vector<void*> owned;             // everything freed at destroy
     GettWorkspace ws{nullptr, 0};
     bool in_repack = false;               // set while contract() runs on a re-laid-out operand
+    // Lanes: extra streams (each with its own split-K workspace) on which independent chains of small launches run side
+    // by side.  `stream` / `ws` above always denote the lane in use; lane 0 is the context's main stream.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        GettWorkspace ws{nullptr, 0};
+        hipEvent_t done = nullptr;
+    };
+    std::vector<Lane> lanes;
+    hipEvent_t fork_ev = nullptr;
+    int cur_lane = 0;
+    void fork(int nlanes);                // every lane waits for what the main stream has queued so far
+    void use_lane(int i);
+    void join();                          // the main stream waits for every lane; back on lane 0
+    int mark();                           // event after what the lane in use has queued so far ...
+    void wait(int mark_id);               // ... which the lane in use now waits for
+    std::vector<hipEvent_t> marks;
+    int marks_used = 0;
     double* scal = nullptr;               // small device scratch for reductions (64 doubles)
     double* scal_host = nullptr;          // pinned mirror
     std::map<std::string, Plan> plans;

@@ -107,49 +107,73 @@ void diis_save(Context& cx, DiisRing& s)
 }
 void ccsd_diis_save(Context& cx, CCState& s) { diis_save(cx, s); }
 
+// Lanes pay when a launch cannot fill the device anyway: o^2 v^2 up to 2^20 elements (H2O/cc-pVTZ: 70 225).
+static bool lanes_pay(const CCState& s)
+{
+    static const bool off = [] { const char* e = getenv("AFESP_NO_LANES"); return e && e[0] == '1'; }();
+    return !off && s.t2.size() <= ((int64_t)1 << 20);
+}
+
 void ccsd_intermediates(Context& cx, CCState& s)
 {
     auto C = [&](double al, const Tensor& A, const char* la, const Tensor& B, const char* lb, double be, const Tensor& Cc,
                  const char* lc) { contract(cx, al, A, la, B, lb, be, Cc, lc); };
     // asym_t2, c_oovv                                                    ccsd.f90:1063-1079
     k_asym_c(cx, s.asym.d, s.c.d, s.t1.d, s.t2.d, s.o, s.v);
+    // Small systems are bound by the latency of ~100 dependent launches: the independent chains below then run on four
+    // lanes (streams) side by side.  Each intermediate is built entirely on one lane; I_vo feeds I_oo (same lane), x_voov feeds
+    // I_voov (same lane) and the last term of I_ooov_p (explicit event).
+    const bool par = lanes_pay(s);
+    auto lane = [&](int i) { if (par) cx.use_lane(i); };
+    if (par) cx.fork(6);
+    lane(0);
     // I_vo(a,i) = (2<im|ae> - <im|ea>) t(m,e)                            ccsd.f90:1085-1092
     C(1.0, s.w_oovv, "miea", s.t1, "me", 0.0, s.I_vo, "ai");
+    lane(1);
     // I_vv(b,a)                                                          ccsd.f90:1096-1113
     C(1.0, s.w_vvov, "ebma", s.t1, "me", 0.0, s.I_vv, "ba");
     C(-1.0, s.w_oovv, "mneb", s.c, "mnea", 1.0, s.I_vv, "ba");
+    lane(0);
     // I_oo_p(j,i)                                                        ccsd.f90:1115-1132
     C(1.0, s.w_oovo, "miej", s.t1, "me", 0.0, s.I_oo_p, "ji");
     C(1.0, s.asym, "mjef", s.v_oovv, "mief", 1.0, s.I_oo_p, "ji");
     // I_oo(j,i) = I_oo_p + t(j,e) I_vo(e,i)                              ccsd.f90:1134-1137
     k_copy(cx, s.I_oo.d, s.I_oo_p.d, s.I_oo.size());
     C(1.0, s.t1, "je", s.I_vo, "ei", 1.0, s.I_oo, "ji");
+    lane(1);
     // I_oooo(k,l,i,j)                                                    ccsd.f90:1139-1156
     k_copy(cx, s.I_oooo.d, s.v_oooo.d, s.I_oooo.size());
     C(1.0, s.c, "klef", s.v_oovv, "ijef", 1.0, s.I_oooo, "klij");
     C(1.0, s.t1, "ke", s.v_oovo, "ilej", 1.0, s.I_oooo, "klij");
     C(1.0, s.t1, "le", s.v_oovo, "jkei", 1.0, s.I_oooo, "klij");
+    lane(2);
     // I_ovov(j,b,i,a)                                                    ccsd.f90:1158-1191
     k_copy(cx, s.I_ovov.d, s.v_ovov.d, s.I_ovov.size());
     C(-0.5, s.v_oovv, "mibe", s.c, "mjae", 1.0, s.I_ovov, "jbia");
     C(-1.0, s.v_oovo, "mibj", s.t1, "ma", 1.0, s.I_ovov, "jbia");
     C(1.0, s.t1, "je", s.v_vvov, "ebia", 1.0, s.I_ovov, "jbia");
+    lane(3);
     // x_voov(b,j,i,a) = <be|ia> t(j,e)                                   ccsd.f90:1275-1290
     C(1.0, s.v_vvov, "beia", s.t1, "je", 0.0, s.x_voov, "bjia");
+    const int x_voov_ready = par ? cx.mark() : 0;
     // I_voov(b,j,i,a)                                                    ccsd.f90:1193-1252
     permute_add(cx, 1.0, s.v_oovv, "jiab", 0.0, s.I_voov, "bjia");
     k_axpby(cx, s.I_voov.d, 1.0, s.x_voov.d, 1.0, s.I_voov.size());
     C(0.5, s.w_oovv, "imbe", s.t2, "mjea", 1.0, s.I_voov, "bjia");
     C(-0.5, s.v_oovv, "imbe", s.c, "mjae", 1.0, s.I_voov, "bjia");
     C(-1.0, s.v_oovo, "imbj", s.t1, "ma", 1.0, s.I_voov, "bjia");
+    lane(4);
     // I_vovv_p(c,i,a,b)                                                  ccsd.f90:1255-1272, :1296-1299
     permute_add(cx, 1.0, s.v_vvov, "baic", 0.0, s.I_vovv_p, "ciab");
     C(-1.0, s.v_oovv, "micb", s.t1, "ma", 1.0, s.I_vovv_p, "ciab");
     C(-1.0, s.v_ovov, "maic", s.t1, "mb", 1.0, s.I_vovv_p, "ciab");
+    lane(5);
     // I_ooov_p(j,k,i,a)                                                  ccsd.f90:1302-1308
     permute_add(cx, 1.0, s.v_oovo, "kjai", 0.0, s.I_ooov_p, "jkia");
     C(1.0, s.t2, "jkef", s.v_vvov, "efia", 1.0, s.I_ooov_p, "jkia");
+    if (par) cx.wait(x_voov_ready);
     C(1.0, s.t1, "je", s.x_voov, "ekia", 1.0, s.I_ooov_p, "jkia");
+    if (par) cx.join();
 }
 
 // Particle-particle ladder (src/ccsd.f90:1669), the O(o^2 v^4) term.  pp(ijab) = sum_ef c(ij,ef) <ef|ab> obeys
@@ -174,24 +198,48 @@ void ccsd_amplitudes(Context& cx, CCState& s)
 {
     auto C = [&](double al, const Tensor& A, const char* la, const Tensor& B, const char* lb, double be, const Tensor& Cc,
                  const char* lc) { contract(cx, al, A, la, B, lb, be, Cc, lc); };
+    // lanes (small systems only, see ccsd_intermediates): T1 in two groups, the pp-ladder on its own lane, the other T2 terms
+    // in three groups; all but the first group of each go into partial buffers that are added after the join
+    const bool par = lanes_pay(s);
+    auto lane = [&](int i) { if (par) cx.use_lane(i); };
+    Tensor r2b = s.r2, r2c = s.r2, r1b = s.r1;
+    if (par) {
+        r2b.d = cx.scratch("r2_lane2", s.r2.size());
+        r2c.d = cx.scratch("r2_lane3", s.r2.size());
+        r1b.d = cx.scratch("r1_lane5", s.r1.size());
+        cx.fork(6);
+    }
+    lane(0);
     // ---- T1, Eq. 43                                                    ccsd.f90:1569-1631
     C(1.0, s.t1, "ie", s.I_vv, "ea", 0.0, s.r1, "ia");
     C(-1.0, s.I_oo_p, "im", s.t1, "ma", 1.0, s.r1, "ia");
     C(1.0, s.asym, "miea", s.I_vo, "em", 1.0, s.r1, "ia");
     C(2.0, s.v_oovv, "miea", s.t1, "me", 1.0, s.r1, "ia");
-    C(-1.0, s.v_ovov, "maie", s.t1, "me", 1.0, s.r1, "ia");
-    C(-1.0, s.v_oovo, "mien", s.asym, "mnea", 1.0, s.r1, "ia");
-    C(1.0, s.asym, "mief", s.v_vvov, "efma", 1.0, s.r1, "ia");
+    lane(5);
+    C(-1.0, s.v_ovov, "maie", s.t1, "me", par ? 0.0 : 1.0, r1b, "ia");
+    C(-1.0, s.v_oovo, "mien", s.asym, "mnea", 1.0, r1b, "ia");
+    C(1.0, s.asym, "mief", s.v_vvov, "efma", 1.0, r1b, "ia");
+    lane(1);
     // ---- T2, Eq. 44                                                    ccsd.f90:1637-1716
     C(1.0, s.t2, "ijae", s.I_vv, "eb", 0.0, s.r2, "ijab");                 // :1647
     C(-1.0, s.t2, "miba", s.I_oo, "jm", 1.0, s.r2, "ijab");                // :1654-1664
+    lane(4);
     ccsd_pp_ladder(cx, s);                                                 // :1669  particle-particle ladder
+    lane(1);
     C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");              // :1673  hole-hole ladder
-    C(-1.0, s.t2, "mjae", s.I_ovov, "iemb", 1.0, s.r2, "ijab");            // :1680-1695 ring terms
-    C(-1.0, s.I_ovov, "iema", s.t2, "mjeb", 1.0, s.r2, "ijab");
-    C(1.0, s.asym, "miea", s.I_voov, "ejmb", 1.0, s.r2, "ijab");
-    C(1.0, s.t1, "ie", s.I_vovv_p, "ejab", 1.0, s.r2, "ijab");             // :1700
-    C(-1.0, s.t1, "ma", s.I_ooov_p, "ijmb", 1.0, s.r2, "ijab");            // :1705-1715
+    lane(2);
+    C(-1.0, s.t2, "mjae", s.I_ovov, "iemb", par ? 0.0 : 1.0, r2b, "ijab");   // :1680-1695 ring terms
+    C(-1.0, s.I_ovov, "iema", s.t2, "mjeb", 1.0, r2b, "ijab");
+    lane(3);
+    C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
+    C(1.0, s.t1, "ie", s.I_vovv_p, "ejab", 1.0, r2c, "ijab");              // :1700
+    C(-1.0, s.t1, "ma", s.I_ooov_p, "ijmb", 1.0, r2c, "ijab");             // :1705-1715
+    if (par) {
+        cx.join();
+        k_axpby(cx, s.r1.d, 1.0, r1b.d, 1.0, s.r1.size());
+        k_axpby(cx, s.r2.d, 1.0, r2b.d, 1.0, s.r2.size());
+        k_axpby(cx, s.r2.d, 1.0, r2c.d, 1.0, s.r2.size());
+    }
     // P(ia/jb), + v_oovv, Jacobi divide                                  ccsd.f90:1720-1728
     k_div(cx, s.t1.d, s.r1.d, s.D1.d, s.t1.size());
     k_t2_update(cx, s.t2.d, s.r2.d, s.v_oovv.d, s.D2.d, s.pp, s.o, s.v);

@@ -60,8 +60,72 @@ Tensor Context::tensor(std::initializer_list<int64_t> dims)
     return view(alloc(n), dims);
 }
 void Context::sync() { AFESP_HIP(hipStreamSynchronize(stream)); }
+
+void Context::fork(int nlanes)
+{
+    if (cur_lane != 0) throw Error(1, "Context::fork: already forked");
+    if (lanes.empty()) {
+        lanes.resize(1);
+        lanes[0].stream = stream;
+        lanes[0].ws = ws;
+        AFESP_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+    }
+    while ((int)lanes.size() < nlanes) {
+        Lane l;
+        AFESP_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        AFESP_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+        l.ws.bytes = (size_t)32 << 20;   // lanes only carry small problems
+        void* p = nullptr;
+        AFESP_HIP(hipMalloc(&p, l.ws.bytes));
+        owned.push_back(p);
+        l.ws.ptr = (double*)p;
+        lanes.push_back(l);
+    }
+    AFESP_HIP(hipEventRecord(fork_ev, lanes[0].stream));
+    for (size_t i = 1; i < lanes.size(); ++i) AFESP_HIP(hipStreamWaitEvent(lanes[i].stream, fork_ev, 0));
+}
+
+void Context::use_lane(int i)
+{
+    if (lanes.empty()) return;
+    cur_lane = i % (int)lanes.size();
+    stream = lanes[(size_t)cur_lane].stream;
+    ws = lanes[(size_t)cur_lane].ws;
+}
+
+int Context::mark()
+{
+    if (marks_used == (int)marks.size()) {
+        hipEvent_t e;
+        AFESP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        marks.push_back(e);
+    }
+    AFESP_HIP(hipEventRecord(marks[(size_t)marks_used], stream));
+    return marks_used++;
+}
+
+void Context::wait(int mark_id) { AFESP_HIP(hipStreamWaitEvent(stream, marks[(size_t)mark_id], 0)); }
+
+void Context::join()
+{
+    marks_used = 0;
+    if (lanes.empty()) return;
+    for (size_t i = 1; i < lanes.size(); ++i) {
+        AFESP_HIP(hipEventRecord(lanes[i].done, lanes[i].stream));
+        AFESP_HIP(hipStreamWaitEvent(lanes[0].stream, lanes[i].done, 0));
+    }
+    use_lane(0);
+}
 Context::~Context()
 {
+    use_lane(0);
+    for (size_t i = 1; i < lanes.size(); ++i) {
+        (void)hipStreamSynchronize(lanes[i].stream);
+        (void)hipStreamDestroy(lanes[i].stream);
+        (void)hipEventDestroy(lanes[i].done);
+    }
+    if (fork_ev) (void)hipEventDestroy(fork_ev);
+    for (hipEvent_t e : marks) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamSynchronize(stream);
     for (void* p : owned) (void)hipFree(p);
     for (auto& kv : cache) (void)hipFree(kv.second.first);
@@ -284,7 +348,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
         const Tensor& src = p.repack == 1 ? A0 : B0;
         Tensor packed = src;
         for (int i = 0; i < src.rank; ++i) packed.stride[i] = p.repack_stride[i];
-        packed.d = cx.scratch("repack:" + key, src.size());
+        packed.d = cx.scratch("repack:" + std::to_string(cx.cur_lane) + ":" + key, src.size());
         const char* ls = p.repack == 1 ? la0 : lb0;
         permute_add(cx, 1.0, src, ls, 0.0, packed, ls);
         cx.in_repack = true;
