@@ -18,6 +18,22 @@ struct afesp_ctx {
     double* eri_mo_dev = nullptr;   // packed MO integrals left on the device by afesp_ao2mo_mp2
     int64_t eri_mo_n = 0;           // nbasis they belong to
     double* eri_ao_dev = nullptr;   // packed AO integrals uploaded by afesp_read_eri_text
+    // With the chains of a small-system iteration spread over lanes, issuing ~110 launches from the host (~4 us each) is
+    // what is left; from the second call on the iteration is therefore replayed as a hipGraph (captured across the
+    // lanes).  Only used where lanes are (small systems); AFESP_NO_GRAPH=1 keeps plain launches.
+    struct GraphSlot {
+        hipGraphExec_t exec = nullptr;
+        int calls = 0;
+        bool disabled = false;
+        void reset()
+        {
+            if (exec) (void)hipGraphExecDestroy(exec);
+            exec = nullptr;
+            calls = 0;
+            const char* e = getenv("AFESP_NO_GRAPH");
+            disabled = e && e[0] == '1';
+        }
+    } graph_cc;
     int64_t eri_ao_n = 0;
 };
 
@@ -62,6 +78,49 @@ __global__ void synth_packed_kernel(double* packed, int64_t n, double scale, uin
 
 }  // namespace
 
+// Runs `body` (launches on the context's lanes, no host synchronisation) directly the first time, captures it into a graph
+// the second time and replays the graph afterwards.  Nothing executes during capture, so a failed capture simply falls
+// back to running the body.
+template <typename Body>
+static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body body)
+{
+    Context& cx = ctx->cx;
+    if (g.exec) {
+        AFESP_HIP(hipGraphLaunch(g.exec, cx.stream));
+        return;
+    }
+    if (!eligible || g.disabled || ++g.calls < 2) {
+        body();
+        return;
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(cx.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        g.disabled = true;
+        body();
+        return;
+    }
+    bool ok = true;
+    try {
+        body();
+    } catch (...) {
+        ok = false;
+    }
+    const hipError_t e = hipStreamEndCapture(cx.stream, &graph);
+    if (ok && e == hipSuccess && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        AFESP_HIP(hipGraphLaunch(g.exec, cx.stream));
+        return;
+    }
+    if (getenv("AFESP_GRAPH_DEBUG")) fprintf(stderr, "afesp: graph capture failed (body ok %d, end capture %d)\n", (int)ok, (int)e);
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    g.exec = nullptr;
+    g.disabled = true;
+    cx.use_lane(0);
+    body();
+}
+
 extern "C" {
 
 int afesp_version(void) { return 1; }
@@ -97,6 +156,7 @@ void afesp_ctx_destroy(afesp_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cx.device);
+    ctx->graph_cc.reset();
     triples_plan_free(ctx->cc);
     so_triples_plan_free(ctx->so);
     delete ctx;
@@ -170,6 +230,7 @@ int afesp_ccsd_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, const double* e
         } else if (!src || ctx->eri_mo_n != n) {
             throw Error(1, "afesp_ccsd_init: no MO integrals resident for this basis size (call afesp_ao2mo_mp2 first)");
         }
+        ctx->graph_cc.reset();
         ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, src, canon_levels, diis_n_errmat);
         if (tmp) cx.release(tmp);
     });
@@ -211,9 +272,11 @@ int afesp_ccsd_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* energ
     return guarded(ctx, [&] {
         if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_iterate: call afesp_ccsd_init first");
         AFESP_HIP(hipSetDevice(ctx->cx.device));
-        ccsd_diis_save(ctx->cx, ctx->cc);
-        ccsd_intermediates(ctx->cx, ctx->cc);
-        ccsd_amplitudes(ctx->cx, ctx->cc);
+        replay(ctx, ctx->graph_cc, ccsd_uses_lanes(ctx->cc), [&] {
+            ccsd_diis_save(ctx->cx, ctx->cc);
+            ccsd_intermediates(ctx->cx, ctx->cc);
+            ccsd_amplitudes(ctx->cx, ctx->cc);
+        });
         int conv = ccsd_energy(ctx->cx, ctx->cc, e_tol, t_tol);
         if (energy) *energy = ctx->cc.energy;
         if (rms_sq) *rms_sq = ctx->cc.rms;
@@ -245,9 +308,11 @@ int afesp_ccsd_solve(afesp_ctx* ctx, int maxiter, double e_tol, double t_tol, do
         if (iter_rms_sq) iter_rms_sq[0] = s.rms;
         int result = -1;
         for (int it = 1; it <= maxiter; ++it) {
-            ccsd_diis_save(cx, s);
-            ccsd_intermediates(cx, s);
-            ccsd_amplitudes(cx, s);
+            replay(ctx, ctx->graph_cc, ccsd_uses_lanes(s), [&] {
+                ccsd_diis_save(cx, s);
+                ccsd_intermediates(cx, s);
+                ccsd_amplitudes(cx, s);
+            });
             int conv = ccsd_energy(cx, s, e_tol, t_tol);
             if (iter_energy) iter_energy[it] = s.energy;
             if (iter_rms_sq) iter_rms_sq[it] = s.rms;
@@ -676,6 +741,7 @@ int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double sca
         double* packed = cx.alloc(ne);
         hipLaunchKernelGGL(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, packed, ne, scale, seed);
         AFESP_HIP(hipGetLastError());
+        ctx->graph_cc.reset();
         ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, packed, e.data(), diis_n_errmat);
         cx.release(packed);
     });

@@ -107,7 +107,11 @@ void diis_save(Context& cx, DiisRing& s)
 }
 void ccsd_diis_save(Context& cx, CCState& s) { diis_save(cx, s); }
 
+static bool lanes_pay(const CCState& s);
+
 // Lanes pay when a launch cannot fill the device anyway: o^2 v^2 up to 2^20 elements (H2O/cc-pVTZ: 70 225).
+bool ccsd_uses_lanes(const CCState& s) { return lanes_pay(s); }
+
 static bool lanes_pay(const CCState& s)
 {
     static const bool off = [] { const char* e = getenv("AFESP_NO_LANES"); return e && e[0] == '1'; }();
