@@ -38,6 +38,24 @@ struct GettProblem {
     bool wide = false;
 };
 
+// Grouped launch: several products that share M, K, B, C, the row tables and the K tables, but differ in the A panel, the
+// column tables and the column count, walked as ONE persistent tile stream (no ragged last round and no launch gap per
+// product).  Each group may have its own K-offset tables as long as their first K step (16 entries) is the same in all
+// groups -- the offsets of a tile's first step are fetched before the gather cursor has switched groups.  Device array
+// of ngroups + 1 entries; the last one only carries tile_start.
+struct GettGroup {
+    int64_t a_off;                 // A panel of this group: p.A + a_off
+    const int64_t* offAk;
+    const int64_t* offBk;
+    const int64_t* offBn;
+    const int64_t* offCn;
+    int N, ntiles, tile_start, pad;
+};
+// Tile shape the grouped launch uses for (M, wide): codes as in gett_launch; BM/BN in elements.
+void gett_grouped_tile(int M, bool wide, int* tm, int* tn, int* BM, int* BN);
+hipError_t gett_launch_grouped(const GettProblem& p, const GettGroup* dev_groups, int ngroups, int total_tiles, int max_ntiles,
+                               hipStream_t stream);
+
 // Workspace for split-K partial sums.  The launcher picks the tile shape and the split count itself.
 struct GettWorkspace {
     double* ptr;

@@ -115,6 +115,17 @@ struct Stager {
     }
 };
 
+// Values loaded from the group descriptors are the same in every lane; saying so keeps them in scalar registers (as
+// vector registers they pushed the grouped kernel from 13 to 31 spilled registers: 57 -> 50 TF).
+__device__ __forceinline__ int uniform_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ int64_t uniform_i64(int64_t x)
+{
+    const int lo = __builtin_amdgcn_readfirstlane((int)x), hi = __builtin_amdgcn_readfirstlane((int)(x >> 32));
+    return ((int64_t)hi << 32) | (unsigned)lo;
+}
+template <typename T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) { return reinterpret_cast<const T*>(uniform_i64(reinterpret_cast<int64_t>(p))); }
+
 struct GettKernelArgs {
     GettProblem p;
     int ksplit;   // grid.y
@@ -123,6 +134,8 @@ struct GettKernelArgs {
     int mtiles, ntiles;
     int gm;       // m-tiles per group (tile walk order)
     int dbg;      // measurement only: bit 0 skips the epilogue stores
+    const GettGroup* groups;   // grouped launch (gett.h) or nullptr
+    int total_tiles;
 };
 
 // XCD-aware bijective remap (cdna_hip_programming.md T1): blocks b, b+8, b+16... share an XCD (and its L2);
@@ -133,7 +146,8 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int W>
+// GRP = true: grouped launch (gett.h); a separate instantiation so that the plain kernels keep their register allocation
+template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int W, bool GRP = false>
 __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
 {
     constexpr int NT = 64 * WM * WN;
@@ -159,16 +173,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
     // Tile order: a group is `gm` m-tiles x all n-tiles walked m-fastest, so that the ~32 workgroups co-resident on one
     // XCD form a near-square patch of C and both operand panels are re-used out of that XCD's L2; within a round of
     // gridDim.x tiles the XCD remap gives each XCD consecutive ids.
-    const int ntiles_all = a.mtiles * a.ntiles;
+    // Grouped launch: the tile ids of all groups are concatenated; `cursor` is the group of the previous lookup (ids only
+    // grow along a workgroup's stream).
+    const int ntiles_all = GRP ? a.total_tiles : a.mtiles * a.ntiles;
     const int ntl = (ntiles_all - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    auto origin = [&](int j, int& m0, int& n0) {
+    auto origin = [&](int j, int& m0, int& n0, int& cursor) {
         const int r0 = j * (int)gridDim.x;
-        const int tile = r0 + xcd_remap(blockIdx.x, min((int)gridDim.x, ntiles_all - r0));
-        const int width = a.gm * a.ntiles, grp = tile / width, first = grp * a.gm;
+        int tile = r0 + xcd_remap(blockIdx.x, min((int)gridDim.x, ntiles_all - r0));
+        int nt = a.ntiles;
+        if (GRP) {
+            while (tile >= uniform_i32(a.groups[cursor + 1].tile_start)) ++cursor;
+            tile -= uniform_i32(a.groups[cursor].tile_start);
+            nt = uniform_i32(a.groups[cursor].ntiles);
+        }
+        const int width = a.gm * nt, grp = tile / width, first = grp * a.gm;
         const int gsz = min(a.mtiles - first, a.gm), rem = tile - grp * width;
         m0 = (first + rem % gsz) * BM;
         n0 = (rem / gsz) * BN;
     };
+    int fgrp = 0, cgrp = 0;   // group of the tile being fetched / being finished
 
     v4d acc[TM][TN];
 #pragma unroll
@@ -181,13 +204,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
         if (a.dbg & 1) return;
         const int nl = n0 + wn * 16 * TN + (lane & 15);
         const int ml = m0 + wm * 16 * TM + (lane >> 4);
+        const int64_t* offCn = GRP ? uniform_ptr(a.groups[cgrp].offCn) : p.offCn;
+        const int Ncur = GRP ? uniform_i32(a.groups[cgrp].N) : p.N;
         if (a.ksplit == 1) {
             double* Cb = p.C + (p.batchC ? p.batchC[z] : 0);
             int64_t cn[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 int n = nl + 16 * j;
-                cn[j] = p.offCn[n < p.N ? n : p.N - 1];
+                cn[j] = offCn[n < Ncur ? n : Ncur - 1];
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -199,7 +224,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         int n = nl + 16 * j;
-                        if (n >= p.N) continue;
+                        if (n >= Ncur) continue;
                         double* dst = Cb + cm + cn[j];
                         double val = p.alpha * acc[i][j][r];
                         if (p.beta != 0.0) val += p.beta * *dst;
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
     if (nk <= 0) {   // empty contraction: C = beta*C
         for (int j = 0; j < ntl; ++j) {
             int m0, n0;
-            origin(j, m0, n0);
+            origin(j, m0, n0, cgrp);
             store_tile(m0, n0);
         }
         return;
@@ -243,18 +268,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
     int fkt = 0, ftile = 0, kok = 0;
     {
         int m0, n0;
-        origin(0, m0, n0);
-        stA.init(Ab, p.offAm, p.offAk, m0, p.M, p.K, t);
-        stB.init(Bb, p.offBn, p.offBk, n0, p.N, p.K, t);
+        origin(0, m0, n0, fgrp);
+        if (GRP) {
+            const GettGroup& g = a.groups[fgrp];
+            stA.init(Ab + uniform_i64(g.a_off), p.offAm, uniform_ptr(g.offAk), m0, p.M, p.K, t);
+            stB.init(Bb, uniform_ptr(g.offBn), uniform_ptr(g.offBk), n0, uniform_i32(g.N), p.K, t);
+        } else {
+            stA.init(Ab, p.offAm, p.offAk, m0, p.M, p.K, t);
+            stB.init(Bb, p.offBn, p.offBk, n0, p.N, p.K, t);
+        }
     }
     auto advance_fetch = [&]() {
         if (++fkt == nk) {
             fkt = 0;
             if (++ftile < ntl) {
                 int m0, n0;
-                origin(ftile, m0, n0);
+                origin(ftile, m0, n0, fgrp);
                 stA.rows(p.offAm, m0, p.M, t);
-                stB.rows(p.offBn, n0, p.N, t);
+                if (GRP) {
+                    const GettGroup& g = a.groups[fgrp];
+                    stA.base = Ab + uniform_i64(g.a_off);
+                    stA.offK = uniform_ptr(g.offAk);
+                    stB.offK = uniform_ptr(g.offBk);
+                    stB.rows(uniform_ptr(g.offBn), n0, uniform_i32(g.N), t);
+                } else {
+                    stB.rows(p.offBn, n0, p.N, t);
+                }
             }
         }
     };
@@ -339,7 +378,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
         mfma(af1, bf1);                                                                         \
         if (ktn == 0) {                                                                         \
             int m0, n0;                                                                         \
-            origin(ctile, m0, n0);                                                              \
+            origin(ctile, m0, n0, cgrp);                                                        \
             store_tile(m0, n0);                                                                 \
             ++ctile;                                                                            \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                      \
@@ -408,16 +447,16 @@ static int resident_blocks(Kern kern, int threads)
     return cus * occ;
 }
 
-template <int WM, int WN, int TM, int TN, bool AK, bool BK_, int W>
+template <int WM, int WN, int TM, int TN, bool AK, bool BK_, int W, bool GRP = false>
 static void launch_one(const GettKernelArgs& a, dim3 grid, hipStream_t st)
 {
-    static const int cap = resident_blocks(gett_kernel<WM, WN, TM, TN, AK, BK_, W>, 64 * WM * WN);
+    static const int cap = resident_blocks(gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP>, 64 * WM * WN);
     // persistent grid: no more workgroups than the device holds at once, the rest of the tiles are walked in-kernel
     int per = cap / (int)(grid.y * grid.z);
     if (per < 1) per = 1;
     if (g_dbg & 2) per = 1 << 30;   // measurement only: one tile per workgroup
     if ((int)grid.x > per) grid.x = (unsigned)per;
-    hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, AK, BK_, W>), grid, dim3(64 * WM * WN), 0, st, a);
+    hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP>), grid, dim3(64 * WM * WN), 0, st, a);
 }
 
 template <int WM, int WN, int TM, int TN, int W>
@@ -500,6 +539,8 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     if (a.ksplit < 1) a.ksplit = 1;
     a.ws = ws.ptr;
     a.dbg = g_dbg;
+    a.groups = nullptr;
+    a.total_tiles = 0;
     a.gm = g_group_m > 0 ? g_group_m : (a.ntiles >= 8 ? 4 : a.ntiles >= 4 ? 8 : a.ntiles >= 2 ? 16 : 32);
     if (a.gm > a.mtiles) a.gm = a.mtiles;
     dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)a.ksplit, (unsigned)p.nbatch);
@@ -524,6 +565,43 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
         err = hipGetLastError();
     }
     return err;
+}
+
+void gett_grouped_tile(int M, bool wide, int* tm, int* tn, int* BM, int* BN)
+{
+    if (wide && M >= 2048) { *tm = 16; *tn = 8; *BM = 256; *BN = 128; }
+    else { *tm = 4; *tn = 4; *BM = 128; *BN = 128; }
+}
+
+hipError_t gett_launch_grouped(const GettProblem& p, const GettGroup* dev_groups, int ngroups, int total_tiles, int max_ntiles,
+                               hipStream_t stream)
+{
+    if (p.M <= 0 || ngroups <= 0 || total_tiles <= 0 || p.K <= 0) return hipSuccess;
+    if (p.nbatch != 1 || !p.a_kcontig || !p.b_kcontig) return hipErrorInvalidValue;
+    GettKernelArgs a;
+    a.p = p;
+    const bool wide = p.wide && g_allow_wide && (p.M % 2 == 0) && (p.K % 2 == 0);
+    int tm, tn, BM, BN;
+    gett_grouped_tile(p.M, wide, &tm, &tn, &BM, &BN);
+    a.mtiles = (p.M + BM - 1) / BM;
+    a.ntiles = max_ntiles;
+    a.ksplit = 1;
+    a.kchunk = (p.K + BK - 1) / BK * BK;
+    a.ws = nullptr;
+    a.dbg = g_dbg;
+    a.groups = dev_groups;
+    a.total_tiles = total_tiles;
+    a.gm = g_group_m > 0 ? g_group_m : (max_ntiles >= 8 ? 4 : max_ntiles >= 4 ? 8 : max_ntiles >= 2 ? 16 : 32);
+    if (a.gm > a.mtiles) a.gm = a.mtiles;
+    dim3 grid((unsigned)total_tiles, 1, 1);
+    if (tm == 16) {
+        if (wide) launch_one<4, 2, 4, 4, true, true, 2, true>(a, grid, stream);
+        else return hipErrorInvalidValue;
+    } else {
+        if (wide) launch_one<2, 4, 4, 2, true, true, 2, true>(a, grid, stream);
+        else launch_one<2, 4, 4, 2, true, true, 1, true>(a, grid, stream);
+    }
+    return hipGetLastError();
 }
 
 }  // namespace afesp

@@ -17,6 +17,7 @@
 // chunk that share k go into one launch: rows (b,c), columns (a, pair list), K = v+o.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "ccsd.h"
 #include "ccsd_so.h"
@@ -75,14 +76,17 @@ struct TriplesPlan {
     int64_t t_begin = -1, t_end = -1, nb = 0;
     int norb = 0;
     bool cr = false;
-    int mode = 0;   // 0 spin-free (i<=j<=k, six blocks per triple), 1 spin-orbital (i<j<k, three blocks)
-    struct Group { int r; int64_t start, N; };
-    struct Chunk { int nt; int64_t meta_off, tab_off, ntab; std::vector<Group> groups; };
+    int mode = 0;   // 0 spin-free (fused pairs of terms, plan_fused), 1 spin-orbital (i<j<k, three blocks, plan_for)
+    int sblock = 0; // fused scheme: occupied block size of the triple enumeration
+    struct Group { int r; int64_t start, N; int q = 0; int64_t koffA = 0, koffB = 0; };   // q, koff*: fused scheme only
+    struct Chunk { int nt; int64_t meta_off, tab_off, ntab; std::vector<Group> groups;
+                   int64_t gdesc_off = 0; int total_tiles = 0, max_ntiles = 0; };   // fused scheme: GettGroup array (device)
     std::vector<Chunk> chunks;
     int64_t* tables = nullptr;     // [kappa | Am | Cm | per chunk: offBn, offCn]
     int64_t off_k = 0, off_Am = 0, off_Cm = 0;
     TripleMeta* meta = nullptr;
     int* orbits = nullptr;
+    GettGroup* gdesc = nullptr;    // fused scheme: group descriptors of all chunks
 };
 
 static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end, bool cr, int mode)
@@ -190,6 +194,185 @@ static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_b
     return p;
 }
 
+// ---------------------------------------------------------------------------------------------------- fused scheme
+// The six terms of W pair up by the index that comes from the amplitude operand ("single"):
+//   Y^{p;qr}(x;y,z) = X^{pqr}(x;y,z) + X^{prq}(x;z,y)
+//                   = sum_kappa [ tt(kappa;x,q,p) vt(kappa;y,z,r) + tt(kappa;x,r,p) vt(kappa;z,y,q) ]
+// i.e. ONE GEMM over a summation index of length 2(v+o) whose second half reads the slab of q with (y,z) transposed
+// (a second copy vtT(kappa;y,z,q) = vt(kappa;z,y,q) right behind vt) and the amplitude column of the pair (r,p) instead
+// of (q,p) -- both are constant shifts inside a group of columns that share the unordered pair {q,r}, so they go into
+// the group's K-offset tables.  Then
+//   W^{ijk}(a,b,c) = Y^{i;jk}(a;b,c) + Y^{j;ik}(b;a,c) + Y^{k;ij}(c;a,b):
+// half as many blocks written by the GEMMs and read by the orbit kernel, and twice the K per tile.
+// A GEMM needs many columns per {q,r}: the triples are therefore enumerated by blocks of `s` occupied indices --
+// block triple (I<=J<=K) major, i<=j<=k inside -- so that one chunk (= one block triple) has up to s columns sets
+// per pair.  The flat index [t_begin, t_end) the ranks shard refers to THIS order.
+static int fused_block_size(int o, int v, bool cr, int64_t budget_bytes)
+{
+    const int64_t nt8 = (v + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;
+    const int64_t per_block = (cr ? 2 : 1) * vp3 * (int64_t)sizeof(double);
+    int smax = 1;
+    while (smax < o && (int64_t)3 * (smax + 1) * (smax + 1) * (smax + 1) * per_block <= budget_bytes) ++smax;
+    // among the three largest sizes that fit, the one whose GEMMs (M = v^2 rows in 256-row tiles, N = v*s columns in
+    // 128-column tiles) leave the fullest last round of 256 workgroups
+    int best = smax;
+    double best_fill = -1.0;
+    for (int sz = smax; sz >= std::max(1, smax - 2); --sz) {
+        const int64_t tiles = (((int64_t)v * v + 255) / 256) * (((int64_t)v * sz + 127) / 128);
+        const double fill = (double)tiles / (double)((tiles + 255) / 256 * 256);
+        if (fill > best_fill + 0.03) { best_fill = fill; best = sz; }
+    }
+    return best;
+}
+
+static int64_t device_pool_budget()
+{
+    size_t mem_free = 0, mem_total = 0;
+    AFESP_HIP(hipMemGetInfo(&mem_free, &mem_total));
+    const char* e = getenv("AFESP_T_POOL_GIB");   // tuning knob
+    if (e) return (int64_t)atoll(e) << 30;
+    return std::min<int64_t>((int64_t)64 << 30, (int64_t)(mem_total / 4));
+}
+
+static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end, bool cr)
+{
+    TriplesPlan* p = (TriplesPlan*)slot;
+    if (p && p->o == o && p->v == v && p->t_begin == t_begin && p->t_end == t_end && p->cr == cr && p->mode == 0) return p;
+    delete p;
+    p = new TriplesPlan();
+    slot = p;
+    const int64_t O = o, V = v, v2 = V * V, Kc = (V + O + 15) / 16 * 16;
+    const int64_t nt8 = (V + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;
+    p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = cr; p->mode = 0;
+    const int sb = fused_block_size(o, v, cr, device_pool_budget());
+    p->sblock = sb;
+    const int nbk = (o + sb - 1) / sb;
+    std::vector<int64_t> tab;
+    p->off_k = 0;   // unused in this scheme (every group has its own K tables)
+    p->off_Am = (int64_t)tab.size();
+    for (int64_t c = 0; c < V; ++c)
+        for (int64_t b = 0; b < V; ++b) tab.push_back(Kc * (b + V * c));      // rows (b,c) of vt(:,b,c,r) and vtT(:,b,c,q)
+    p->off_Cm = (int64_t)tab.size();
+    for (int64_t c = 0; c < V; ++c)
+        for (int64_t b = 0; b < V; ++b)
+            tab.push_back(CUBE * nt8 * (b / TT) + TT * (b % TT) + CUBE * nt8 * nt8 * (c / TT) + TT * TT * (c % TT));
+    std::vector<TripleMeta> metas;
+    int64_t flat = 0, max_blocks = 1;
+    for (int I = 0; I < nbk; ++I)
+        for (int J = I; J < nbk; ++J)
+            for (int K = J; K < nbk; ++K) {
+                // triples of this block triple inside the requested range
+                std::vector<TripleMeta> cur;
+                struct Blk { int p, q, r; int64_t buf; };
+                std::vector<Blk> blks;
+                auto block_of = [&](int pp, int qq, int rr) {
+                    if (qq > rr) std::swap(qq, rr);
+                    for (const Blk& b : blks)
+                        if (b.p == pp && b.q == qq && b.r == rr) return b.buf;
+                    blks.push_back({pp, qq, rr, (int64_t)blks.size()});
+                    return blks.back().buf;
+                };
+                for (int i = I * sb; i < std::min(o, (I + 1) * sb); ++i)
+                    for (int j = std::max(i, J * sb); j < std::min(o, (J + 1) * sb); ++j)
+                        for (int k = std::max(j, K * sb); k < std::min(o, (K + 1) * sb); ++k, ++flat) {
+                            if (flat < t_begin || flat >= t_end) continue;
+                            TripleMeta m;
+                            m.i = i; m.j = j; m.k = k; m.pad = 0;
+                            m.mult = (i == j && j == k) ? 1.0 : (i == j || j == k) ? 3.0 : 6.0;
+                            m.woff = 0;
+                            for (int q = 0; q < 6; ++q) m.xoff[q] = 0;
+                            m.xoff[0] = block_of(i, j, k) * vp3;   // Y^{i;jk}(a;b,c)
+                            m.xoff[1] = block_of(j, i, k) * vp3;   // Y^{j;ik}(b;a,c)
+                            m.xoff[5] = block_of(k, i, j) * vp3;   // Y^{k;ij}(c;a,b)
+                            cur.push_back(m);
+                        }
+                if (cur.empty()) continue;
+                TriplesPlan::Chunk ch;
+                ch.nt = (int)cur.size();
+                ch.meta_off = (int64_t)metas.size();
+                metas.insert(metas.end(), cur.begin(), cur.end());
+                max_blocks = std::max<int64_t>(max_blocks, (int64_t)blks.size());
+                // groups of columns that share {q,r}
+                std::vector<int64_t> hBn, hCn, hK;
+                for (int q = 0; q < o; ++q)
+                    for (int r = q; r < o; ++r) {
+                        const int64_t start = (int64_t)hBn.size();
+                        for (const Blk& b : blks)
+                            if (b.q == q && b.r == r)
+                                for (int64_t x = 0; x < V; ++x) {
+                                    hBn.push_back(Kc * (x + V * (q + O * b.p)));           // tt(:, x, q, p); second half: (r, p)
+                                    hCn.push_back(CUBE * (x / TT) + x % TT + vp3 * b.buf);
+                                }
+                        const int64_t N = (int64_t)hBn.size() - start;
+                        if (N == 0) continue;
+                        TriplesPlan::Group g;
+                        g.r = r; g.q = q; g.start = start; g.N = N;
+                        g.koffA = (int64_t)hK.size();
+                        for (int64_t x = 0; x < Kc; ++x) hK.push_back(x);
+                        for (int64_t x = 0; x < Kc; ++x) hK.push_back(Kc * v2 * O + Kc * v2 * ((int64_t)q - r) + x);   // vtT(:, ., ., q)
+                        g.koffB = (int64_t)hK.size();
+                        for (int64_t x = 0; x < Kc; ++x) hK.push_back(x);
+                        for (int64_t x = 0; x < Kc; ++x) hK.push_back(Kc * V * ((int64_t)r - q) + x);                  // tt(:, x, r, p)
+                        ch.groups.push_back(g);
+                    }
+                ch.ntab = (int64_t)hBn.size();
+                ch.tab_off = (int64_t)tab.size();
+                tab.insert(tab.end(), hBn.begin(), hBn.end());
+                tab.insert(tab.end(), hCn.begin(), hCn.end());
+                const int64_t kbase = (int64_t)tab.size() - ch.tab_off;
+                tab.insert(tab.end(), hK.begin(), hK.end());
+                for (TriplesPlan::Group& g : ch.groups) { g.koffA += kbase; g.koffB += kbase; }
+                p->chunks.push_back(std::move(ch));
+            }
+    p->nb = max_blocks;   // blocks (not triples) the pool must hold
+    std::vector<int> orb;
+    for (int A = 0; A < nt8; ++A)
+        for (int B = A; B < nt8; ++B)
+            for (int C = B; C < nt8; ++C) orb.push_back(A | (B << 10) | (C << 20));
+    p->norb = (int)orb.size();
+    if (metas.empty()) metas.push_back(TripleMeta());
+    p->tables = (int64_t*)cx.scratch("t_tables", (int64_t)tab.size());
+    p->meta = (TripleMeta*)cx.scratch("t_meta", (int64_t)(metas.size() * sizeof(TripleMeta) / sizeof(double) + 1));
+    p->orbits = (int*)cx.scratch("t_orbits", (int64_t)orb.size() / 2 + 1);
+    AFESP_HIP(hipMemcpyAsync(p->tables, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
+    AFESP_HIP(hipMemcpyAsync(p->meta, metas.data(), metas.size() * sizeof(TripleMeta), hipMemcpyHostToDevice, cx.stream));
+    AFESP_HIP(hipMemcpyAsync(p->orbits, orb.data(), orb.size() * sizeof(int), hipMemcpyHostToDevice, cx.stream));
+    // group descriptors of the grouped GEMM launches (one launch per chunk): tile counts for the tile shape the launcher
+    // will use, table pointers into the uploaded tables
+    int tm, tn, BM, BN;
+    gett_grouped_tile((int)v2, (Kc % 2 == 0) && (V % 2 == 0), &tm, &tn, &BM, &BN);
+    const int mtiles = (int)((v2 + BM - 1) / BM);
+    std::vector<GettGroup> gd;
+    for (TriplesPlan::Chunk& ch : p->chunks) {
+        ch.gdesc_off = (int64_t)gd.size();
+        int tile = 0;
+        const int64_t* tabs = p->tables + ch.tab_off;
+        for (const TriplesPlan::Group& g : ch.groups) {
+            GettGroup d;
+            d.a_off = Kc * v2 * g.r;
+            d.offAk = tabs + g.koffA;   // second half: vtT(x, ., ., q)
+            d.offBk = tabs + g.koffB;   // second half: tt(x, ., r, p)
+            d.offBn = tabs + g.start;
+            d.offCn = tabs + ch.ntab + g.start;
+            d.N = (int)g.N;
+            d.ntiles = (int)((g.N + BN - 1) / BN);
+            d.tile_start = tile;
+            d.pad = 0;
+            tile += mtiles * d.ntiles;
+            ch.max_ntiles = std::max(ch.max_ntiles, d.ntiles);
+            gd.push_back(d);
+        }
+        GettGroup end{};
+        end.tile_start = tile;
+        gd.push_back(end);
+        ch.total_tiles = tile;
+    }
+    p->gdesc = (GettGroup*)cx.scratch("t_gdesc", (int64_t)(gd.size() * sizeof(GettGroup) / sizeof(double) + 1));
+    AFESP_HIP(hipMemcpyAsync(p->gdesc, gd.data(), gd.size() * sizeof(GettGroup), hipMemcpyHostToDevice, cx.stream));
+    cx.sync();   // the host vectors die here
+    return p;
+}
+
 void triples_plan_free(CCState& s)
 {
     delete (TriplesPlan*)s.tplan;
@@ -208,11 +391,14 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     const int64_t Kc = (V + O + 15) / 16 * 16;
     t_begin = std::max<int64_t>(0, t_begin);
     t_end = std::min<int64_t>(triples_count(o), t_end);
-    TriplesPlan* p = plan_for(cx, s.tplan, s.o, s.v, t_begin, t_end, cr, 0);
+    TriplesPlan* p = plan_fused(cx, s.tplan, s.o, s.v, t_begin, t_end, cr);
     // concatenated operands, summed index kappa = [d ; l] first (the reference also moves the summed index first, :2056-2066)
     //   vt(kappa,b,c,k): kappa<v: <cb|kd> = v_vvov(c,b,k,d);  kappa=v+l: t2(l,k,b,c)
     //   tt(kappa,a,j,i): kappa<v: t2(i,j,a,d);                kappa=v+l: -<ij|al> = -v_oovo(i,j,a,l)
-    Tensor vt = view(cx.scratch("t_vt", Kc * v2 * O), {Kc, V, V, O}), tt = view(cx.scratch("t_tt", Kc * V * O * O), {Kc, V, O, O});
+    //   vtT(kappa,b,c,k) = vt(kappa,c,b,k) sits right behind vt (slabs o..2o-1): second half of the fused summation index
+    Tensor vt = view(cx.scratch("t_vt", 2 * Kc * v2 * O), {Kc, V, V, O}), tt = view(cx.scratch("t_tt", Kc * V * O * O), {Kc, V, O, O});
+    Tensor vtT = vt;
+    vtT.d = vt.d + Kc * v2 * O;
     auto sub = [&](const Tensor& full, int64_t row0, int64_t nrows) {
         Tensor t = full;
         t.d = full.d + row0;
@@ -220,11 +406,13 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         return t;
     };
     if (Kc != V + O) {
-        AFESP_HIP(hipMemsetAsync(vt.d, 0, sizeof(double) * Kc * v2 * O, cx.stream));
+        AFESP_HIP(hipMemsetAsync(vt.d, 0, sizeof(double) * 2 * Kc * v2 * O, cx.stream));
         AFESP_HIP(hipMemsetAsync(tt.d, 0, sizeof(double) * Kc * V * O * O, cx.stream));
     }
     permute_add(cx, 1.0, s.v_vvov, "cbkd", 0.0, sub(vt, 0, V), "dbck");
     permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vt, V, O), "lbck");
+    permute_add(cx, 1.0, s.v_vvov, "cbkd", 0.0, sub(vtT, 0, V), "dcbk");
+    permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vtT, V, O), "lcbk");
     permute_add(cx, 1.0, s.t2, "ijad", 0.0, sub(tt, 0, V), "daji");
     permute_add(cx, -1.0, s.v_oovo, "ijal", 0.0, sub(tt, V, O), "laji");
     Tensor vs = view(cx.scratch("t_vs", v2 * O * O), {V, V, O, O});    // vs(x,y,p,q)  = v_oovv(p,q,x,y)
@@ -237,23 +425,29 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     Tensor vt2, tt2;
     double* Mpool = nullptr;
     if (cr) {
-        vt2 = view(cx.scratch("t_vt2", Kc * v2 * O), {Kc, V, V, O});
+        vt2 = view(cx.scratch("t_vt2", 2 * Kc * v2 * O), {Kc, V, V, O});
         tt2 = view(cx.scratch("t_tt2", Kc * V * O * O), {Kc, V, O, O});
+        Tensor vt2T = vt2;
+        vt2T.d = vt2.d + Kc * v2 * O;
         if (Kc != V + O) {
-            AFESP_HIP(hipMemsetAsync(vt2.d, 0, sizeof(double) * Kc * v2 * O, cx.stream));
+            AFESP_HIP(hipMemsetAsync(vt2.d, 0, sizeof(double) * 2 * Kc * v2 * O, cx.stream));
             AFESP_HIP(hipMemsetAsync(tt2.d, 0, sizeof(double) * Kc * V * O * O, cx.stream));
         }
         permute_add(cx, 1.0, s.I_vovv_pp, "dkbc", 0.0, sub(vt2, 0, V), "dbck");
         permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vt2, V, O), "lbck");
+        permute_add(cx, 1.0, s.I_vovv_pp, "dkbc", 0.0, sub(vt2T, 0, V), "dcbk");
+        permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vt2T, V, O), "lcbk");
         permute_add(cx, 1.0, s.t2, "ijad", 0.0, sub(tt2, 0, V), "daji");
         permute_add(cx, -1.0, s.I_ooov_pp, "jila", 0.0, sub(tt2, V, O), "laji");
-        Mpool = cx.scratch("t_mpool", 6 * p->nb * vp3);
+        Mpool = cx.scratch("t_mpool", p->nb * vp3);
     }
     const int nq = cr ? 6 : 4;
     k_fill(cx, cx.scal, 6, 0.0);
     TriplesIn in{s.e, s.t1.d, vs.d, ts.d, s.t2.d, o, v};
-    double* Xpool = cx.scratch("t_xpool", 6 * p->nb * vp3);
-    double* partial = cx.scratch("t_partial", 6 * std::max<int64_t>((int64_t)p->norb * p->nb, 512));
+    double* Xpool = cx.scratch("t_xpool", p->nb * vp3);
+    int64_t max_nt = 1;
+    for (const TriplesPlan::Chunk& ch : p->chunks) max_nt = std::max<int64_t>(max_nt, ch.nt);
+    double* partial = cx.scratch("t_partial", 6 * std::max<int64_t>((int64_t)p->norb * max_nt, 512));
     // one stream, no host round trip until the four sums are read back: chunk c+1's GEMMs overwrite the X pool only
     // after chunk c's orbit kernel has consumed it (stream order)
     std::vector<hipEvent_t> evs;
@@ -267,44 +461,49 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     for (const TriplesPlan::Chunk& ch : p->chunks) {
         const int64_t* tabs = p->tables + ch.tab_off;
         stamp();
-        for (const TriplesPlan::Group& g : ch.groups) {
+        {
+            // all column groups of the chunk in ONE persistent launch (gett_launch_grouped): no ragged last round and no
+            // launch gap per group
             GettProblem gp;
-            gp.A = vt.d + Kc * v2 * g.r;   // vt(:,:,:,r)
+            gp.A = vt.d;
             gp.B = tt.d;
             gp.C = Xpool;
-            gp.offAm = p->tables + p->off_Am; gp.offAk = p->tables + p->off_k; gp.offBk = p->tables + p->off_k;
-            gp.offBn = tabs + g.start;
-            gp.offCm = p->tables + p->off_Cm; gp.offCn = tabs + ch.ntab + g.start;
-            gp.M = (int)v2; gp.N = (int)g.N; gp.K = (int)Kc;
+            gp.offAm = p->tables + p->off_Am;
+            gp.offAk = gp.offBk = gp.offBn = gp.offCn = nullptr;       // per group
+            gp.offCm = p->tables + p->off_Cm;
+            gp.M = (int)v2; gp.N = 0; gp.K = (int)(2 * Kc);             // [slab r ; transposed slab q] x [pair (q,p) ; pair (r,p)]
             gp.alpha = 1.0; gp.beta = 0.0;
             gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
             gp.a_kcontig = gp.b_kcontig = true;
-            gp.wide = (Kc % 2 == 0) && (V % 2 == 0);   // then every row/column offset above is even
-            AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+            gp.wide = (Kc % 2 == 0) && (V % 2 == 0);   // then every row/column/K offset and shift is even
+            const GettGroup* gd = p->gdesc + ch.gdesc_off;
+            AFESP_HIP(gett_launch_grouped(gp, gd, (int)ch.groups.size(), ch.total_tiles, ch.max_ntiles, cx.stream));
             if (cr) {
                 GettProblem gm = gp;
-                gm.A = vt2.d + Kc * v2 * g.r;
+                gm.A = vt2.d;
                 gm.B = tt2.d;
                 gm.C = Mpool;
-                AFESP_HIP(gett_launch(gm, cx.ws, cx.stream));
+                AFESP_HIP(gett_launch_grouped(gm, gd, (int)ch.groups.size(), ch.total_tiles, ch.max_ntiles, cx.stream));
             }
             if (cx.prof) {
+                int64_t ncol = 0;
+                for (const TriplesPlan::Group& g : ch.groups) ncol += g.N;
                 cx.prof_gemm_launches += 1;
-                cx.prof_gemm_flop += 2.0 * (double)gp.M * (double)gp.N * (double)(V + O);
+                cx.prof_gemm_flop += 2.0 * (double)gp.M * (double)ncol * 2.0 * (double)(V + O);
             }
         }
         stamp();
         if (cr)
-            hipLaunchKernelGGL(triples_orbit_kernel<true>, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
+            hipLaunchKernelGGL((triples_orbit_kernel<true, true>), dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
                                p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
         else
-            hipLaunchKernelGGL(triples_orbit_kernel<false>, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
+            hipLaunchKernelGGL((triples_orbit_kernel<false, true>), dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
                                p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
         AFESP_HIP(hipGetLastError());
         stamp();
         if (cx.prof) {
             cx.prof_orbit_launches += 1;
-            cx.prof_orbit_bytes += 8.0 * 6.0 * (double)v3 * ch.nt;
+            cx.prof_orbit_bytes += 8.0 * 3.0 * (double)v3 * ch.nt;
         }
         hipLaunchKernelGGL(triples_sum_kernel, dim3(nq), dim3(256), 0, cx.stream, cx.scal, partial, p->norb * ch.nt);
         AFESP_HIP(hipGetLastError());

@@ -45,7 +45,11 @@ __device__ __forceinline__ int cidx(int p0, int p1, int p2) { return ((p0 ^ p1 ^
 // CR = true additionally assembles the completely-renormalised moment M3 (ccsd.f90:2186-2194) from a second pool of
 // blocks (same offsets) and accumulates sum t_bar.M3, sum z_bar.M3 (ccsd.f90:2222-2226); M3 is only needed at (a,b,c)
 // itself, so it stays in registers.
-template <bool CR>
+// FUSED = true: the pool holds the three pair-summed blocks Y^{i;jk}, Y^{j;ik}, Y^{k;ij} (triples.hip, plan_fused) at
+// xoff[0], xoff[1], xoff[5]; they enter W at the permutations (abc), (bac), (cab) -- terms 0, 1, 5 of the six.
+__host__ __device__ constexpr int orbit_term(bool fused, int idx) { return fused ? (idx == 0 ? 0 : idx == 1 ? 1 : 5) : idx; }
+
+template <bool CR, bool FUSED>
 __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restrict__ partial, const double* __restrict__ Xpool,
                                                             const double* __restrict__ Mpool,
                                                             const TripleMeta* __restrict__ meta,
@@ -104,22 +108,23 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
 #pragma unroll
     for (int r = 0; r < (CR ? 12 : 1); ++r) mreg[r] = 0.0;
     // term s+1 is in flight while term s is permuted out of LDS
-    constexpr int NTERM = CR ? 12 : 6;
+    constexpr int NT1 = FUSED ? 3 : 6;
+    constexpr int NTERM = CR ? 2 * NT1 : NT1;
     v2d_t xin[6];
-    load_term(Xpool + m.xoff[0], xin);
+    load_term(Xpool + m.xoff[orbit_term(FUSED, 0)], xin);
 #pragma unroll
     for (int s2 = 0; s2 < NTERM; ++s2) {
-        const int s = s2 % 6;
+        const int s = orbit_term(FUSED, s2 % NT1);
         __syncthreads();   // the previous term's readers are done with `stage` (also publishes srcq on the first pass)
         park_term(xin);
-        if (s2 + 1 < NTERM) load_term((s2 + 1 < 6 ? Xpool : Mpool) + m.xoff[(s2 + 1) % 6], xin);
+        if (s2 + 1 < NTERM) load_term((s2 + 1 < NT1 ? Xpool : Mpool) + m.xoff[orbit_term(FUSED, (s2 + 1) % NT1)], xin);
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 12; ++r) {
             const int q = r >> 1;
             const int l[3] = {l0, l1, l2h[r & 1]};
             const double x = stage[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])];
-            if (s2 < 6) wreg[r] += x;
+            if (s2 < NT1) wreg[r] += x;
             else mreg[CR ? r : 0] += x;
         }
     }
