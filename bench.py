@@ -208,7 +208,8 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
                     "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s"}
             roof["frac"] = roof["achieved"] / roof["peak"]
             roof["traffic"] = None
-            roof["kernel"] = "gett_kernel, (T) launches: X(a,b,c|ijk) = sum_kappa tt(kappa;a,ij) vt(kappa;b,c,k), K = v+o"
+            roof["kernel"] = ("gett_kernel<..., GRP = true>, the grouped (T) launches (one per chunk): Y(a;b,c|i;jk) = sum over "
+                              "kappa = [d + l ; d + l] of tt(kappa;a,.)*vt(kappa;b,c,.), K = 2(v+o)")
             roof["launches"] = prof["gemm_launches"]
             roof["ms_per_launch"] = prof["gemm_ms"] / nl
             roof["flop_per_launch"] = prof["gemm_flop"] / nl
@@ -240,8 +241,8 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)     # a step of the default workload is < 1 ms: 5 steps are noise
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="h2o_tz", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
     ap.add_argument("--no-extra", dest="extra", action="store_false",
