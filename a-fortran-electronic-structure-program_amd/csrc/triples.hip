@@ -13,8 +13,9 @@
 // the hole half of term 3 gives
 //     X^{ijk}(a,b,c) = sum_d t2(i,j,a,d) <cb|kd>  -  sum_l t2(l,k,b,c) <ij|al>
 // whose two halves share the row index (b,c; k) and the column index (a; i,j): ONE GEMM over the concatenated summation
-// index kappa = d (+) l of length v+o, with no read-modify-write pass for the hole term.  All ordered triples of a
-// chunk that share k go into one launch: rows (b,c), columns (a, pair list), K = v+o.
+// index kappa = d (+) l of length v+o, with no read-modify-write pass for the hole term.  The spin-free path then fuses
+// the six X into three products of twice that length and launches them grouped (plan_fused below); the spin-orbital
+// path launches its three blocks per slab (plan_for).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -76,7 +77,8 @@ struct TriplesPlan {
     int64_t t_begin = -1, t_end = -1, nb = 0;
     int norb = 0;
     bool cr = false;
-    int mode = 0;   // 0 spin-free (fused pairs of terms, plan_fused), 1 spin-orbital (i<j<k, three blocks, plan_for)
+    int mode = 0;   // 0 spin-free (fused pairs of terms, plan_fused), 1 spin-orbital (i<j<k, three blocks, plan_for;
+                    // plan_for's mode-0 branch is the six-block scheme the fused one replaced, kept as its reference)
     int sblock = 0; // fused scheme: occupied block size of the triple enumeration
     struct Group { int r; int64_t start, N; int q = 0; int64_t koffA = 0, koffB = 0; };   // q, koff*: fused scheme only
     struct Chunk { int nt; int64_t meta_off, tab_off, ntab; std::vector<Group> groups;
