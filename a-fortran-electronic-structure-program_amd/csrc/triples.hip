@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <unordered_map>
 
 #include "ccsd.h"
 #include "ccsd_so.h"
@@ -267,11 +268,14 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
                 std::vector<TripleMeta> cur;
                 struct Blk { int p, q, r; int64_t buf; };
                 std::vector<Blk> blks;
+                std::unordered_map<int64_t, int64_t> seen;
                 auto block_of = [&](int pp, int qq, int rr) {
                     if (qq > rr) std::swap(qq, rr);
-                    for (const Blk& b : blks)
-                        if (b.p == pp && b.q == qq && b.r == rr) return b.buf;
+                    const int64_t key = ((int64_t)pp * o + qq) * o + rr;
+                    auto it = seen.find(key);
+                    if (it != seen.end()) return it->second;
                     blks.push_back({pp, qq, rr, (int64_t)blks.size()});
+                    seen.emplace(key, blks.back().buf);
                     return blks.back().buf;
                 };
                 for (int i = I * sb; i < std::min(o, (I + 1) * sb); ++i)
@@ -296,27 +300,28 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
                 max_blocks = std::max<int64_t>(max_blocks, (int64_t)blks.size());
                 // groups of columns that share {q,r}
                 std::vector<int64_t> hBn, hCn, hK;
-                for (int q = 0; q < o; ++q)
-                    for (int r = q; r < o; ++r) {
-                        const int64_t start = (int64_t)hBn.size();
-                        for (const Blk& b : blks)
-                            if (b.q == q && b.r == r)
-                                for (int64_t x = 0; x < V; ++x) {
-                                    hBn.push_back(Kc * (x + V * (q + O * b.p)));           // tt(:, x, q, p); second half: (r, p)
-                                    hCn.push_back(CUBE * (x / TT) + x % TT + vp3 * b.buf);
-                                }
-                        const int64_t N = (int64_t)hBn.size() - start;
-                        if (N == 0) continue;
-                        TriplesPlan::Group g;
-                        g.r = r; g.q = q; g.start = start; g.N = N;
-                        g.koffA = (int64_t)hK.size();
-                        for (int64_t x = 0; x < Kc; ++x) hK.push_back(x);
-                        for (int64_t x = 0; x < Kc; ++x) hK.push_back(Kc * v2 * O + Kc * v2 * ((int64_t)q - r) + x);   // vtT(:, ., ., q)
-                        g.koffB = (int64_t)hK.size();
-                        for (int64_t x = 0; x < Kc; ++x) hK.push_back(x);
-                        for (int64_t x = 0; x < Kc; ++x) hK.push_back(Kc * V * ((int64_t)r - q) + x);                  // tt(:, x, r, p)
-                        ch.groups.push_back(g);
-                    }
+                std::stable_sort(blks.begin(), blks.end(), [](const Blk& x, const Blk& y) { return x.q != y.q ? x.q < y.q : x.r < y.r; });
+                for (size_t b0 = 0; b0 < blks.size();) {
+                    const int q = blks[b0].q, r = blks[b0].r;
+                    size_t b1 = b0;
+                    while (b1 < blks.size() && blks[b1].q == q && blks[b1].r == r) ++b1;
+                    const int64_t start = (int64_t)hBn.size();
+                    for (size_t bi = b0; bi < b1; ++bi)
+                        for (int64_t x = 0; x < V; ++x) {
+                            hBn.push_back(Kc * (x + V * (q + O * blks[bi].p)));           // tt(:, x, q, p); second half: (r, p)
+                            hCn.push_back(CUBE * (x / TT) + x % TT + vp3 * blks[bi].buf);
+                        }
+                    b0 = b1;
+                    TriplesPlan::Group g;
+                    g.r = r; g.q = q; g.start = start; g.N = (int64_t)hBn.size() - start;
+                    g.koffA = (int64_t)hK.size();
+                    for (int64_t x = 0; x < Kc; ++x) hK.push_back(x);
+                    for (int64_t x = 0; x < Kc; ++x) hK.push_back(Kc * v2 * O + Kc * v2 * ((int64_t)q - r) + x);   // vtT(:, ., ., q)
+                    g.koffB = (int64_t)hK.size();
+                    for (int64_t x = 0; x < Kc; ++x) hK.push_back(x);
+                    for (int64_t x = 0; x < Kc; ++x) hK.push_back(Kc * V * ((int64_t)r - q) + x);                  // tt(:, x, r, p)
+                    ch.groups.push_back(g);
+                }
                 ch.ntab = (int64_t)hBn.size();
                 ch.tab_off = (int64_t)tab.size();
                 tab.insert(tab.end(), hBn.begin(), hBn.end());
