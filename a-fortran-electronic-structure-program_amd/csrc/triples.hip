@@ -78,8 +78,7 @@ struct TriplesPlan {
     int64_t t_begin = -1, t_end = -1, nb = 0;
     int norb = 0;
     bool cr = false;
-    int mode = 0;   // 0 spin-free (fused pairs of terms, plan_fused), 1 spin-orbital (i<j<k, three blocks, plan_for;
-                    // plan_for's mode-0 branch is the six-block scheme the fused one replaced, kept as its reference)
+    int mode = 0;   // 0 spin-free (fused pairs of terms, plan_fused), 1 spin-orbital (i<j<k, three blocks, plan_for)
     int sblock = 0; // fused scheme: occupied block size of the triple enumeration
     struct Group { int r; int64_t start, N; int q = 0; int64_t koffA = 0, koffB = 0; };   // q, koff*: fused scheme only
     struct Chunk { int nt; int64_t meta_off, tab_off, ntab; std::vector<Group> groups;
@@ -92,18 +91,19 @@ struct TriplesPlan {
     GettGroup* gdesc = nullptr;    // fused scheme: group descriptors of all chunks
 };
 
-static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end, bool cr, int mode)
+// Plan of the spin-orbital (T): i<j<k, three blocks per triple, one launch per integral slab and chunk.
+static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end)
 {
     TriplesPlan* p = (TriplesPlan*)slot;
-    if (p && p->o == o && p->v == v && p->t_begin == t_begin && p->t_end == t_end && p->cr == cr && p->mode == mode) return p;
+    if (p && p->o == o && p->v == v && p->t_begin == t_begin && p->t_end == t_end && p->mode == 1) return p;
     delete p;
     p = new TriplesPlan();
     slot = p;
     const int64_t O = o, V = v, Kc = (V + O + 15) / 16 * 16;   // padded, see ccsd_triples
-    p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = cr; p->mode = mode;
+    p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = false; p->mode = 1;
     // chunk size: 6 X blocks of (padded) v^3 doubles per triple; W never leaves LDS
     const int64_t nt8 = (V + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;   // a block is stored cube by cube, edges padded to 8
-    const int64_t per = (mode == 1 ? 3 : cr ? 12 : 6) * vp3 * (int64_t)sizeof(double);   // CR mode keeps a second pool for the M3 blocks
+    const int64_t per = 3 * vp3 * (int64_t)sizeof(double);
     // pool budget: a quarter of the device memory, at most 64 GiB (MI355X: 288 GB -> 64 GiB, ~165 triples per chunk at
     // v = 200): the more triples share an integral slab, the wider each GEMM and the smaller its ragged last round
     size_t mem_free = 0, mem_total = 0;
@@ -154,20 +154,19 @@ static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_b
         cur.clear(); ords.clear();
     };
     int64_t flat = 0;
-    const int step = mode == 1 ? 1 : 0;   // spin-orbital: strictly increasing (the summand is antisymmetric in i,j,k)
+    const int step = 1;   // strictly increasing: the summand is antisymmetric in i,j,k
     for (int i = 0; i < o && flat < t_end; ++i)
         for (int j = i + step; j < o && flat < t_end; ++j)
             for (int k = j + step; k < o && flat < t_end; ++k, ++flat) {
                 if (flat < t_begin) continue;
                 TripleMeta m;
                 m.i = i; m.j = j; m.k = k; m.pad = 0;
-                m.mult = mode == 1 ? 1.0 : (i == j && j == k) ? 1.0 : (i == j || j == k) ? 3.0 : 6.0;
+                m.mult = 1.0;
                 m.woff = 0;
                 // ordered (p,q,r): the amplitude operand carries the pair (p,q), the integral operand carries r.
                 // spin-orbital: Y^{i;jk}, Y^{j;ik}, Y^{k;ij} (see so_triples)
-                const int P6[6][3] = {{i, j, k}, {j, i, k}, {k, j, i}, {i, k, j}, {j, k, i}, {k, i, j}};
                 const int P3[6][3] = {{j, k, i}, {i, k, j}, {i, j, k}, {j, k, i}, {j, k, i}, {j, k, i}};
-                const int (*P)[3] = mode == 1 ? P3 : P6;
+                const int (*P)[3] = P3;
                 for (int q = 0; q < 6; ++q) {
                     int found = -1;
                     for (int r = 0; r < q; ++r)
@@ -466,7 +465,6 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         evs.push_back(e);
     };
     for (const TriplesPlan::Chunk& ch : p->chunks) {
-        const int64_t* tabs = p->tables + ch.tab_off;
         stamp();
         {
             // all column groups of the chunk in ONE persistent launch (gett_launch_grouped): no ragged last round and no
@@ -567,7 +565,7 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
     t_end = std::min<int64_t>(so_triples_count(o), t_end);
     k_fill(cx, cx.scal, 1, 0.0);
     if (t_end <= t_begin) return 0.0;
-    TriplesPlan* p = plan_for(cx, s.tplan, o, v, t_begin, t_end, false, 1);
+    TriplesPlan* p = plan_for(cx, s.tplan, o, v, t_begin, t_end);
     Tensor vt = view(cx.scratch("t_vt", Kc * v2 * O), {Kc, V, V, O}), tt = view(cx.scratch("t_tt", Kc * V * O * O), {Kc, V, O, O});
     auto sub = [&](const Tensor& full, int64_t row0, int64_t nrows) {
         Tensor t = full;
