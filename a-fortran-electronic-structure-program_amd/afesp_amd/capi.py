@@ -27,7 +27,7 @@ EXPORTS = [
     "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder", "afesp_bench_contract", "afesp_set_tuning", "afesp_bench_stream", "afesp_profile", "afesp_ccsd_cr_intermediates", "afesp_ccsd_t_cr",
     "afesp_ccsd_so_init", "afesp_ccsd_so_energy", "afesp_ccsd_so_iterate", "afesp_ccsd_so_diis", "afesp_ccsd_so_get_amplitudes",
     "afesp_ccsd_so_set_amplitudes", "afesp_ccsd_so_get_tensor", "afesp_ccsd_so_t_ntriples", "afesp_ccsd_so_t",
-    "afesp_read_eri_text", "afesp_write_fcidump", "afesp_set_eri", "afesp_build_fock",
+    "afesp_read_eri_text", "afesp_write_fcidump", "afesp_set_eri", "afesp_build_fock", "afesp_ccsd_t_plain",
 ]
 
 
@@ -69,6 +69,7 @@ def load_library():
     L.afesp_ccsd_t_ntriples.restype = i64
     L.afesp_ccsd_t.argtypes = [C.c_void_p, i64, i64, _dp]
     L.afesp_ccsd_t_cr.argtypes = [C.c_void_p, i64, i64, _dp]
+    L.afesp_ccsd_t_plain.argtypes = [C.c_void_p, i64, i64, _dp]
     L.afesp_ccsd_cr_intermediates.argtypes = [C.c_void_p]
     L.afesp_gemm.argtypes = [C.c_void_p, C.c_char, C.c_char, i64, i64, i64, dbl, _dp, _dp, dbl, _dp]
     L.afesp_permute4.argtypes = [C.c_void_p, C.POINTER(i64), C.c_char_p, _dp, _dp, C.c_int, dbl]
@@ -309,6 +310,14 @@ class Engine:
         e = dbl()
         self._chk(self.L.afesp_ccsd_so_t(self.h, t_begin, t_end, C.byref(e)))
         return e.value
+
+    def do_ccsd_t_spatial_plain(self, t_begin=0, t_end=None):
+        """E[T], E(T) only: what plain CCSD(T)_spatial / CCSD[T]_spatial need (no y, no D sums)."""
+        out = np.zeros(2)
+        if t_end is None:
+            t_end = self.ntriples()
+        self._chk(self.L.afesp_ccsd_t_plain(self.h, t_begin, t_end, out))
+        return out
 
     # ---- completely renormalised variants (src/ccsd.f90:2338-2551, :2186-2194)
     def build_cr_intermediates(self):

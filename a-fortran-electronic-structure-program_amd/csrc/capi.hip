@@ -389,6 +389,14 @@ int afesp_ccsd_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[4])
     });
 }
 
+int afesp_ccsd_t_plain(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[2])
+{
+    return guarded(ctx, [&] {
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        ccsd_triples(ctx->cx, ctx->cc, t_begin, t_end, out, false, false);
+    });
+}
+
 int afesp_ccsd_cr_intermediates(afesp_ctx* ctx)
 {
     return guarded(ctx, [&] {

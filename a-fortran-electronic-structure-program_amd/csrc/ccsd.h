@@ -52,7 +52,8 @@ void ccsd_free(Context& cx, CCState& s);
 // flat index in [t_begin, t_end) of the i<=j<=k enumeration; D base term (ccsd.f90:2243) added iff t_begin==0.
 int64_t triples_count(int o);
 // cr = true: also out[4] = sum t_bar.M3, out[5] = out[4] + sum z_bar.M3 (needs ccsd_cr_intermediates)
-void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host, bool cr = false);
+// want_d = false: only out[0], out[1] (what plain CCSD(T)/[T] need; the reference skips y and the D sums there too)
+void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host, bool cr = false, bool want_d = true);
 // build_cr_ccsd_t_intermediates (ccsd.f90:2338-2551) on the converged amplitudes
 void ccsd_cr_intermediates(Context& cx, CCState& s);
 

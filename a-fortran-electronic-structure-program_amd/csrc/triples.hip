@@ -385,8 +385,9 @@ void triples_plan_free(CCState& s)
     s.tplan = nullptr;
 }
 
-void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host, bool cr)
+void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host, bool cr, bool want_d)
 {
+    if (cr) want_d = true;
     if (cr && !s.have_cr) throw Error(1, "ccsd_triples: completely renormalised mode needs ccsd_cr_intermediates first");
     if (!s.ready) throw Error(1, "ccsd_triples: no converged CCSD state in this context");
     const int o = s.o, v = s.v;
@@ -424,7 +425,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     Tensor vs = view(cx.scratch("t_vs", v2 * O * O), {V, V, O, O});    // vs(x,y,p,q)  = v_oovv(p,q,x,y)
     Tensor ts = view(cx.scratch("t_ts", v2 * O * O), {V, V, O, O});    // ts(x,y,p,q)  = t2(p,q,x,y)
     permute_add(cx, 1.0, s.v_oovv, "pqxy", 0.0, vs, "xypq");
-    permute_add(cx, 1.0, s.t2, "pqxy", 0.0, ts, "xypq");
+    if (want_d) permute_add(cx, 1.0, s.t2, "pqxy", 0.0, ts, "xypq");   // only y needs the t2 patches
     // completely renormalised mode: the same GEMMs with I_vovv_pp / -I_ooov_pp in place of <cb|kd> / -<ij|al>
     //   vt2(kappa,b,c,k): kappa<v: I_vovv_pp(d,k,b,c);  kappa=v+l: t2(l,k,b,c)
     //   tt2(kappa,a,j,i): kappa<v: t2(i,j,a,d);         kappa=v+l: -I_ooov_pp(j,i,l,a)      (ccsd.f90:2188-2193)
@@ -447,7 +448,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         permute_add(cx, -1.0, s.I_ooov_pp, "jila", 0.0, sub(tt2, V, O), "laji");
         Mpool = cx.scratch("t_mpool", p->nb * vp3);
     }
-    const int nq = cr ? 6 : 4;
+    const int nq = cr ? 6 : want_d ? 4 : 2;
     k_fill(cx, cx.scal, 6, 0.0);
     TriplesIn in{s.e, s.t1.d, vs.d, ts.d, s.t2.d, o, v};
     double* Xpool = cx.scratch("t_xpool", p->nb * vp3);
@@ -501,6 +502,9 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         if (cr)
             hipLaunchKernelGGL((triples_orbit_kernel<true, true>), dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
                                p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
+        else if (!want_d)
+            hipLaunchKernelGGL((triples_orbit_kernel<false, true, false>), dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,
+                               Mpool, p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
         else
             hipLaunchKernelGGL((triples_orbit_kernel<false, true>), dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
                                p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
@@ -513,7 +517,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         hipLaunchKernelGGL(triples_sum_kernel, dim3(nq), dim3(256), 0, cx.stream, cx.scal, partial, p->norb * ch.nt);
         AFESP_HIP(hipGetLastError());
     }
-    if (t_begin == 0) {
+    if (t_begin == 0 && want_d) {
         hipLaunchKernelGGL(triples_dbase_kernel, dim3(256), dim3(256), 0, cx.stream, partial, in, 256);
         AFESP_HIP(hipGetLastError());
         hipLaunchKernelGGL(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, 256);
@@ -530,6 +534,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     for (hipEvent_t e : evs) (void)hipEventDestroy(e);
     out_host[0] = h[0];            // E[T]
     out_host[1] = h[0] + h[1];     // E(T)            ccsd.f90:2220
+    if (!want_d) return;
     out_host[2] = h[2];            // D[T]
     out_host[3] = h[2] + h[3];     // D(T)            ccsd.f90:2232
     if (cr) {

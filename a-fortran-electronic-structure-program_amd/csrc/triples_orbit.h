@@ -49,7 +49,11 @@ __device__ __forceinline__ int cidx(int p0, int p1, int p2) { return ((p0 ^ p1 ^
 // xoff[0], xoff[1], xoff[5]; they enter W at the permutations (abc), (bac), (cab) -- terms 0, 1, 5 of the six.
 __host__ __device__ constexpr int orbit_term(bool fused, int idx) { return fused ? (idx == 0 ? 0 : idx == 1 ? 1 : 5) : idx; }
 
-template <bool CR, bool FUSED>
+// WANT_D = false (plain CCSD(T)/[T], which the reference also evaluates without y and the D sums, ccsd.f90:2181-2185 and
+// :2228-2247): only E[T] and the z term.  The symmetriser P in z_bar = P Z / D is self-adjoint and D is symmetric, and a
+// workgroup sums over a set of elements closed under every permutation, so  sum z_bar W = sum Z (P W)/D = sum Z t_bar:
+// ONE evaluation of Z per element (6 LDS reads) instead of six (27), and no t2 patches.
+template <bool CR, bool FUSED, bool WANT_D = true>
 __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restrict__ partial, const double* __restrict__ Xpool,
                                                             const double* __restrict__ Mpool,
                                                             const TripleMeta* __restrict__ meta,
@@ -142,9 +146,12 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
         const int gx = tile[sx] * TT + (loc & 7), gy = tile[sy] * TT + (loc >> 3);
         const bool ok = gx < v && gy < v;
         const int64_t off = ok ? gx + (int64_t)v * gy + vv * (pairp[pr] + (int64_t)o * pairq[pr]) : 0;
-        const double a = in.voovv_s[off], b = in.t2_s[off];
+        const double a = in.voovv_s[off];
         vp[el] = ok ? a : 0.0;
-        tp[el] = ok ? b : 0.0;
+        if (WANT_D) {
+            const double b = in.t2_s[off];
+            tp[el] = ok ? b : 0.0;
+        }
     }
     if (t < 72) {
         const int oc = t / 24, sl = (t / 8) % 3, l = t & 7, g = tile[sl] * TT + l;
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
     }
     __syncthreads();
     const double eo = in.e[m.i] + in.e[m.j] + in.e[m.k];
-    constexpr int NQ = CR ? 6 : 4;
+    constexpr int NQ = CR ? 6 : WANT_D ? 4 : 2;
     double acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
@@ -179,12 +186,17 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
 #define T1R(oc, d) t1r[(oc) * 24 + slot[d] * 8 + l[d]]
 #define VP(arr, pr, dx, dy) arr[((pr) * 9 + slot[dx] * 3 + slot[dy]) * PATCH + l[dx] + TT * l[dy]]
 #define ZAT(x, y, z) (T1R(0, x) * VP(vp, 0, y, z) + T1R(1, y) * VP(vp, 1, x, z) + T1R(2, z) * VP(vp, 2, x, y))
+            const double tbar = live ? wb / D : 0.0;
+            acc[0] += tbar * w;
+            if (!WANT_D) {
+                acc[1] += tbar * ZAT(0, 1, 2);
+                continue;
+            }
             const double zb = (4.0 * ZAT(0, 1, 2) + ZAT(1, 2, 0) + ZAT(2, 0, 1) - 2.0 * (ZAT(0, 2, 1) + ZAT(1, 0, 2) + ZAT(2, 1, 0))) / 3.0;
             // y (ccsd.f90:2183-2184)
             const double y = T1R(0, 0) * T1R(1, 1) * T1R(2, 2) + T1R(0, 0) * VP(tp, 0, 1, 2) + T1R(1, 1) * VP(tp, 1, 0, 2) +
                              T1R(2, 2) * VP(tp, 2, 0, 1);
-            const double tbar = live ? wb / D : 0.0, zbar = live ? zb / D : 0.0;
-            acc[0] += tbar * w;
+            const double zbar = live ? zb / D : 0.0;
             acc[1] += zbar * w;
             acc[2] += tbar * y;
             acc[3] += zbar * y;

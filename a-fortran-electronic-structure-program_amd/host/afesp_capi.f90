@@ -8,7 +8,7 @@ module afesp_capi
              afesp_ccsd_iterate, afesp_ccsd_diis, afesp_ccsd_get_amplitudes, afesp_ccsd_t, afesp_ccsd_t_ntriples, &
              afesp_neri, afesp_error_text, afesp_ccsd_cr_intermediates, afesp_ccsd_t_cr, afesp_ccsd_so_init, &
              afesp_ccsd_so_energy, afesp_ccsd_so_iterate, afesp_ccsd_so_diis, afesp_ccsd_so_t, afesp_ccsd_so_t_ntriples, &
-             afesp_read_eri_text, afesp_write_fcidump, afesp_build_fock
+             afesp_read_eri_text, afesp_write_fcidump, afesp_build_fock, afesp_ccsd_t_plain
 
    interface
       function afesp_ctx_create(device, ctx) bind(C, name='afesp_ctx_create') result(rc)
@@ -95,6 +95,14 @@ module afesp_capi
          type(c_ptr), value :: ctx
          integer(c_int64_t), value :: t_begin, t_end
          real(c_double), intent(out) :: out(4)
+         integer(c_int) :: rc
+      end function
+      !> the same for the plain CCSD(T)/CCSD[T] types: out = E[T], E(T) (no y, no D sums -- reference src/ccsd.f90:2181-2185)
+      function afesp_ccsd_t_plain(ctx, t_begin, t_end, out) bind(C, name='afesp_ccsd_t_plain') result(rc)
+         import :: c_int, c_int64_t, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int64_t), value :: t_begin, t_end
+         real(c_double), intent(out) :: out(2)
          integer(c_int) :: rc
       end function
       !> replaces build_cr_ccsd_t_intermediates (reference src/ccsd.f90:381)

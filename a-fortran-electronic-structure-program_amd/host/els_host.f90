@@ -572,8 +572,10 @@ program els_amd
             write (out, '(1X, 10("-"))'); write (out, '(1X, A)') 'CCSD(T)'; write (out, '(1X, 10("-"))')
             if (cfg%comp_renorm) then
                rc = afesp_ccsd_t_cr(ctx, 0_c_int64_t, afesp_ccsd_t_ntriples(int(mol%nocc, c_int64_t)), tq)
-            else
+            else if (cfg%renorm) then
                rc = afesp_ccsd_t(ctx, 0_c_int64_t, afesp_ccsd_t_ntriples(int(mol%nocc, c_int64_t)), tq(1:4))
+            else                               ! plain types: no y, no D sums (reference src/ccsd.f90:2181-2185)
+               rc = afesp_ccsd_t_plain(ctx, 0_c_int64_t, afesp_ccsd_t_ntriples(int(mol%nocc, c_int64_t)), tq(1:2))
             end if
             if (rc /= 0) call fail('ccsd::do_ccsd_t_spatial', afesp_error_text(ctx))
             ! The reference's plain CCSD(T)_spatial never fills z3_bar (src/ccsd.f90:2211-2215) and therefore prints

@@ -78,6 +78,10 @@ int afesp_ccsd_update_amplitudes(afesp_ctx* ctx);
  *   out[2] = D[T]  (:2230-2231, :2243)          out[3] = D(T) (:2232) */
 int64_t afesp_ccsd_t_ntriples(int64_t nocc);
 int afesp_ccsd_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[4]);
+/* The same for the plain CCSD(T)_spatial / CCSD[T]_spatial types, which need neither y nor the D sums (the reference skips
+ * them there as well, src/ccsd.f90:2181-2185, :2228-2247): out[0] = E[T], out[1] = E(T).  Cheaper: the z term is evaluated
+ * once per element instead of at its six permutations (csrc/triples_orbit.h). */
+int afesp_ccsd_t_plain(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[2]);
 
 /* Completely renormalised CCSD[T]/(T).  afesp_ccsd_cr_intermediates replaces
  * build_cr_ccsd_t_intermediates (src/ccsd.f90:381, :2338-2551) and must be called on the converged amplitudes, before any

@@ -241,3 +241,22 @@ def test_build_fock_on_device_matches_restatement(eng):
     # the converged density reproduces the SCF energy of the reference (E = sum D (H + F), hf.f90:341)
     e = float(np.sum(dens_conv * (hcore + eng.build_fock(n, dens_conv, hcore))))
     assert abs(e + ints.e_nuc - molecules.SURVEY_GOLD["h2o-cc-pvdz"]["rhf_total"]) < 1e-6
+
+
+@pytest.mark.parametrize("o,v", [(3, 8), (5, 19), (6, 24)])
+def test_plain_triples_equal_the_full_evaluation(eng, o, v):
+    """afesp_ccsd_t_plain (one Z evaluation per element, the symmetriser moved onto W) against afesp_ccsd_t, whole range and
+    shards, and against the oracle."""
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.04, seed=3 + v)
+    eng.ccsd_init(o, v, e, eri, 6)
+    cc = orc.OracleCC(o, v, eri, e, 6)
+    eng.do_ccsd_spatial(40, 1e-9, 1e-9)
+    cc.solve(40, 1e-9, 1e-9)
+    full = eng.do_ccsd_t_spatial()
+    plain = eng.do_ccsd_t_spatial_plain()
+    ref = cc.triples(e)
+    assert np.max(np.abs(plain - full[:2])) < 1e-13 * max(1.0, np.max(np.abs(full)))
+    assert np.max(np.abs(plain - ref[:2])) < 1e-11
+    nt = eng.ntriples()
+    parts = eng.do_ccsd_t_spatial_plain(0, nt // 2) + eng.do_ccsd_t_spatial_plain(nt // 2, nt)
+    assert np.max(np.abs(parts - plain)) < 1e-13 * max(1.0, np.max(np.abs(plain)))
