@@ -23,6 +23,7 @@ struct afesp_ctx {
     // lanes).  Only used where lanes are (small systems); AFESP_NO_GRAPH=1 keeps plain launches.
     struct GraphSlot {
         hipGraphExec_t exec = nullptr;
+        int64_t epoch = -1;      // Context::scratch_epoch at capture
         int calls = 0;
         bool disabled = false;
         void reset()
@@ -85,6 +86,11 @@ template <typename Body>
 static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body body)
 {
     Context& cx = ctx->cx;
+    if (g.exec && g.epoch != cx.scratch_epoch) {   // a scratch buffer the graph refers to may have been freed since
+        (void)hipGraphExecDestroy(g.exec);
+        g.exec = nullptr;
+        g.calls = 0;
+    }
     if (g.exec) {
         AFESP_HIP(hipGraphLaunch(g.exec, cx.stream));
         return;
@@ -109,6 +115,7 @@ static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body 
     const hipError_t e = hipStreamEndCapture(cx.stream, &graph);
     if (ok && e == hipSuccess && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
         (void)hipGraphDestroy(graph);
+        g.epoch = cx.scratch_epoch;
         AFESP_HIP(hipGraphLaunch(g.exec, cx.stream));
         return;
     }

@@ -28,6 +28,7 @@ double* Context::scratch(const std::string& name, int64_t n)
     auto it = cache.find(name);
     if (it != cache.end() && it->second.second >= bytes) return (double*)it->second.first;
     if (it != cache.end()) {
+        ++scratch_epoch;
         AFESP_HIP(hipStreamSynchronize(stream));
         (void)hipFree(it->second.first);
         cache.erase(it);
@@ -39,6 +40,7 @@ double* Context::scratch(const std::string& name, int64_t n)
 }
 void Context::drop_scratch()
 {
+    ++scratch_epoch;
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto& kv : cache) (void)hipFree(kv.second.first);
     cache.clear();

@@ -260,3 +260,25 @@ def test_plain_triples_equal_the_full_evaluation(eng, o, v):
     nt = eng.ntriples()
     parts = eng.do_ccsd_t_spatial_plain(0, nt // 2) + eng.do_ccsd_t_spatial_plain(nt // 2, nt)
     assert np.max(np.abs(parts - plain)) < 1e-13 * max(1.0, np.max(np.abs(plain)))
+
+
+def test_iteration_graph_survives_other_work_in_the_same_context(eng):
+    """The small-system iteration is replayed as a captured graph; (T) calls, tensor downloads and a spin-orbital solve in
+    the same context (which frees cached scratch buffers) must not leave it replaying stale buffers."""
+    o, v = 4, 10
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05, seed=21)
+    cc = orc.OracleCC(o, v, eri, e, 6)
+    eng.ccsd_init(o, v, e, eri, 6)
+    eng.ccsd_energy(); cc.L.orc_cc_energy(cc.h, 1e-9, 1e-9)
+    for it in range(8):
+        eng.ccsd_iterate(); eng.ccsd_diis()
+        cc.L.orc_cc_diis_save(cc.h); cc.L.orc_cc_intermediates(cc.h); cc.L.orc_cc_amplitudes(cc.h)
+        cc.L.orc_cc_energy(cc.h, 1e-9, 1e-9); cc.L.orc_cc_diis_update(cc.h)
+        if it == 2:
+            eng.do_ccsd_t_spatial()
+            eng.tensor("r2")
+        if it == 4:
+            eng.init_cc_spinorb(n, 2 * o, e, eri, 4)      # frees the context's scratch cache
+            eng.so_iterate()
+        t1, t2 = eng.amplitudes()
+        assert np.max(np.abs(t2 - cc.t2)) < 1e-11 and np.max(np.abs(t1 - cc.t1)) < 1e-11, it
