@@ -166,10 +166,12 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
         # the benchmark configurations are CCSD(T)_spatial: E[T] and E(T) (the renormalised types' y / D sums are extra)
         part = np.zeros(4)
         part[:2] = eng.do_ccsd_t_spatial_plain(lo, hi)
-        red.copy_(torch.from_numpy(part))
         if dist is not None:
+            red.copy_(torch.from_numpy(part))
             dist.all_reduce(red)                        # the only collective of the path: 4 doubles over xGMI
-        acc["last"] = red.cpu().numpy()
+            acc["last"] = red.cpu().numpy()
+        else:
+            acc["last"] = part                          # one rank: nothing to reduce, no device round trip
         t2 = time.perf_counter()
         if timed:
             acc["iter"] += t1 - t0
