@@ -29,18 +29,38 @@ namespace afesp {
 
 int64_t triples_count(int o) { return (int64_t)o * (o + 1) * (o + 2) / 6; }
 
-// out[q] += sum_b partial[q][b] in a fixed order
+// out[q] += sum_b partial[q][b] in a fixed order.  gridDim.y > 1: block (q, y) sums slice y of the nblk values into
+// out[q * gridDim.y + y] (first stage of sum_partials below; a million partials per chunk at o=20, v=200 took 0.7 ms in
+// one block per quantity).
 __global__ __launch_bounds__(256) void triples_sum_kernel(double* out, const double* partial, int nblk)
 {
     __shared__ double sm[4];
     const int q = blockIdx.x;
+    const int per = (nblk + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int lo = (int)blockIdx.y * per, hi = min(nblk, lo + per);
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += partial[(int64_t)q * nblk + b];
+    for (int b = lo + threadIdx.x; b < hi; b += blockDim.x) s += partial[(int64_t)q * nblk + b];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[q] += sm[0] + sm[1] + sm[2] + sm[3];
+    if (threadIdx.x == 0) {
+        if (gridDim.y > 1) out[q * gridDim.y + blockIdx.y] = sm[0] + sm[1] + sm[2] + sm[3];
+        else out[q] += sm[0] + sm[1] + sm[2] + sm[3];
+    }
+}
+
+// out[q] += sum of partial[q][0..nblk) for q < nq, two stages when there are many partials; `tmp` holds nq * 128 doubles
+static void sum_partials(Context& cx, double* out, const double* partial, int nq, int nblk, double* tmp)
+{
+    if (nblk > 8192) {
+        hipLaunchKernelGGL(triples_sum_kernel, dim3(nq, 128), dim3(256), 0, cx.stream, tmp, partial, nblk);
+        AFESP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(triples_sum_kernel, dim3(nq), dim3(256), 0, cx.stream, out, tmp, 128);
+    } else {
+        hipLaunchKernelGGL(triples_sum_kernel, dim3(nq), dim3(256), 0, cx.stream, out, partial, nblk);
+    }
+    AFESP_HIP(hipGetLastError());
 }
 
 // ccsd.f90:2243: 1 + 2 sum t1^2 + sum asym_t2 * c_oovv.  One partial per block; the ordered sum is done by triples_sum_kernel.
@@ -455,6 +475,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     int64_t max_nt = 1;
     for (const TriplesPlan::Chunk& ch : p->chunks) max_nt = std::max<int64_t>(max_nt, ch.nt);
     double* partial = cx.scratch("t_partial", 6 * std::max<int64_t>((int64_t)p->norb * max_nt, 512));
+    double* sum_tmp = cx.scratch("t_sum_tmp", 6 * 128);
     // one stream, no host round trip until the four sums are read back: chunk c+1's GEMMs overwrite the X pool only
     // after chunk c's orbit kernel has consumed it (stream order)
     std::vector<hipEvent_t> evs;
@@ -514,8 +535,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             cx.prof_orbit_launches += 1;
             cx.prof_orbit_bytes += 8.0 * 3.0 * (double)v3 * ch.nt;
         }
-        hipLaunchKernelGGL(triples_sum_kernel, dim3(nq), dim3(256), 0, cx.stream, cx.scal, partial, p->norb * ch.nt);
-        AFESP_HIP(hipGetLastError());
+        sum_partials(cx, cx.scal, partial, nq, p->norb * ch.nt, sum_tmp);
     }
     if (t_begin == 0 && want_d) {
         hipLaunchKernelGGL(triples_dbase_kernel, dim3(256), dim3(256), 0, cx.stream, partial, in, 256);

@@ -1,16 +1,21 @@
-import sys, os, time
-sys.path.insert(0, '/root/repo/a-fortran-electronic-structure-program_amd'); sys.path.insert(0, '/root/repo/tests')
-import numpy as np, orc, molecules
+#!/usr/bin/env python3
+"""Spin-orbital CCSD / (T) wall times at the H2O/cc-pVTZ shape (n=58, 10 electrons -> o=10, v=106 spin orbitals), the
+configuration of the reference's published spin-orbital timings (2.3 s per iteration, (T) 123 s)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "a-fortran-electronic-structure-program_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from afesp_amd import inputs
 from afesp_amd.capi import Engine
-si, ints, res, _ = molecules.load("h2o-cc-pvdz")
-n, nel = ints.nbasis, ints.nel
+n, nel = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (58, 10)
+o = nel // 2
+e = np.concatenate([-2.0 + np.arange(o) / max(o - 1, 1), 1.0 + 2.0 * np.arange(n - o) / max(n - o - 1, 1)])
+eri = 0.02 * (2.0 * np.random.default_rng(1).random(inputs.neri(n)) - 1.0)
 eng = Engine(0)
-t=time.time(); e_mp2, eri_mo = eng.do_mp2_spatial(n, nel // 2, res.canon_coeff, res.canon_levels, ints.eri); print("mp2 %.2f"%(time.time()-t))
-t=time.time(); eng.init_cc_spinorb(n, nel, res.canon_levels, None, 8); print("init %.2f"%(time.time()-t))
-t=time.time(); nit, en, rm = eng.do_ccsd_spinorb(60, 1e-9, 1e-9); print("solve %d its %.2f"%(nit, time.time()-t))
-t=time.time(); eng.init_cc_spinorb(n, nel, res.canon_levels, None, 8); nit, en, rm = eng.do_ccsd_spinorb(60, 1e-9, 1e-9); print("solve again %d its %.2f"%(nit, time.time()-t))
-t=time.time(); et = eng.do_ccsd_t_spinorb(); print("(T) %.2f"%(time.time()-t), et)
-t=time.time(); et = eng.do_ccsd_t_spinorb(); print("(T) again %.2f"%(time.time()-t), et)
-t=time.time(); so = orc.OracleSO(n, nel, orc.ao2mo(n, res.canon_coeff, ints.eri), res.canon_levels, 8); print("oracle create %.2f"%(time.time()-t))
-t=time.time(); onit, oen, orm = so.solve(60, 1e-9, 1e-9); print("oracle solve %.2f"%(time.time()-t))
-t=time.time(); so.triples(); print("oracle T %.2f"%(time.time()-t))
+t0 = time.perf_counter(); eng.init_cc_spinorb(n, nel, e, eri, 8); print("init %.3f s" % (time.perf_counter() - t0))
+eng.so_energy()
+for it in range(6):
+    t0 = time.perf_counter(); r = eng.so_iterate(); eng.so_diis(); print("iteration %d: %.2f ms  E = %.10f" % (it + 1, (time.perf_counter() - t0) * 1e3, r[0]))
+for rep in range(2):
+    t0 = time.perf_counter(); et = eng.do_ccsd_t_spinorb(); print("(T): %.2f ms  E_T = %.10f" % ((time.perf_counter() - t0) * 1e3, et))
+eng.close()
