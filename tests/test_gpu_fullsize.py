@@ -43,6 +43,8 @@ def test_triples_shards_add_up_and_match_oracle_on_device_tensors(big):
     nt = big.ntriples()
     assert nt == O * (O + 1) * (O + 2) // 6
     full = big.do_ccsd_t_spatial()
+    plain = big.do_ccsd_t_spatial_plain()          # the variant bench.py times: E[T], E(T) with one Z evaluation per element
+    assert np.max(np.abs(plain - full[:2])) < 1e-12 * np.max(np.abs(full[:2]))
     cuts = [0, 2, nt // 7, nt // 2, nt - 5, nt]
     parts = sum(big.do_ccsd_t_spatial(a, b) for a, b in zip(cuts[:-1], cuts[1:]))
     assert np.max(np.abs(parts - full)) < 1e-11 * np.max(np.abs(full))
