@@ -206,9 +206,10 @@ static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_b
         for (int B = A; B < nt8; ++B)
             for (int C = B; C < nt8; ++C) orb.push_back(A | (B << 10) | (C << 20));
     p->norb = (int)orb.size();
-    p->tables = (int64_t*)cx.scratch("t_tables", (int64_t)tab.size());
-    p->meta = (TripleMeta*)cx.scratch("t_meta", (int64_t)(metas.size() * sizeof(TripleMeta) / sizeof(double) + 1));
-    p->orbits = (int*)cx.scratch("t_orbits", (int64_t)orb.size() / 2 + 1);
+    // (names of their own: a spin-free plan cached in the same context keeps pointing at its tables)
+    p->tables = (int64_t*)cx.scratch("so_tables", (int64_t)tab.size());
+    p->meta = (TripleMeta*)cx.scratch("so_meta", (int64_t)(metas.size() * sizeof(TripleMeta) / sizeof(double) + 1));
+    p->orbits = (int*)cx.scratch("so_orbits", (int64_t)orb.size() / 2 + 1);
     AFESP_HIP(hipMemcpyAsync(p->tables, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
     AFESP_HIP(hipMemcpyAsync(p->meta, metas.data(), metas.size() * sizeof(TripleMeta), hipMemcpyHostToDevice, cx.stream));
     AFESP_HIP(hipMemcpyAsync(p->orbits, orb.data(), orb.size() * sizeof(int), hipMemcpyHostToDevice, cx.stream));

@@ -123,3 +123,18 @@ def test_spinorbital_errors(eng):
         eng.init_cc_spinorb(5, 3, e, eri)       # odd electron count
     with pytest.raises(AfespError):
         eng.init_cc_spinorb(5, 10, e, eri)      # no virtual orbital
+
+
+def test_cached_triples_plans_of_both_solvers_do_not_clobber_each_other(eng):
+    """(T) of the spin-free and of the spin-orbital solver alternately in one context: each keeps a cached launch plan."""
+    o, v = 3, 7
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05, seed=5)
+    eng.ccsd_init(o, v, e, eri, 4)
+    eng.do_ccsd_spatial(40, 1e-9, 1e-9)
+    eng.init_cc_spinorb(n, 2 * o, e, eri, 4)
+    eng.do_ccsd_spinorb(60, 1e-9, 1e-9)
+    a1 = eng.do_ccsd_t_spatial()
+    b1 = eng.do_ccsd_t_spinorb()
+    a2 = eng.do_ccsd_t_spatial()
+    b2 = eng.do_ccsd_t_spinorb()
+    assert np.array_equal(a1, a2) and b1 == b2
