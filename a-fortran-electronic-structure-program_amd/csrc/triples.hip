@@ -100,6 +100,7 @@ struct TriplesPlan {
     bool cr = false;
     int mode = 0;   // 0 spin-free (fused pairs of terms, plan_fused), 1 spin-orbital (i<j<k, three blocks, plan_for)
     int sblock = 0; // fused scheme: occupied block size of the triple enumeration
+    int64_t epoch = -1;   // Context::scratch_epoch when the device tables were placed (they live in cached scratch buffers)
     struct Group { int r; int64_t start, N; int q = 0; int64_t koffA = 0, koffB = 0; };   // q, koff*: fused scheme only
     struct Chunk { int nt; int64_t meta_off, tab_off, ntab; std::vector<Group> groups;
                    int64_t gdesc_off = 0; int total_tiles = 0, max_ntiles = 0; };   // fused scheme: GettGroup array (device)
@@ -115,7 +116,7 @@ struct TriplesPlan {
 static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end)
 {
     TriplesPlan* p = (TriplesPlan*)slot;
-    if (p && p->o == o && p->v == v && p->t_begin == t_begin && p->t_end == t_end && p->mode == 1) return p;
+    if (p && p->o == o && p->v == v && p->t_begin == t_begin && p->t_end == t_end && p->mode == 1 && p->epoch == cx.scratch_epoch) return p;
     delete p;
     p = new TriplesPlan();
     slot = p;
@@ -214,6 +215,7 @@ static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_b
     AFESP_HIP(hipMemcpyAsync(p->meta, metas.data(), metas.size() * sizeof(TripleMeta), hipMemcpyHostToDevice, cx.stream));
     AFESP_HIP(hipMemcpyAsync(p->orbits, orb.data(), orb.size() * sizeof(int), hipMemcpyHostToDevice, cx.stream));
     cx.sync();   // the host vectors die here
+    p->epoch = cx.scratch_epoch;
     return p;
 }
 
@@ -260,7 +262,9 @@ static int64_t device_pool_budget()
 static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end, bool cr)
 {
     TriplesPlan* p = (TriplesPlan*)slot;
-    if (p && p->o == o && p->v == v && p->t_begin == t_begin && p->t_end == t_end && p->cr == cr && p->mode == 0) return p;
+    if (p && p->o == o && p->v == v && p->t_begin == t_begin && p->t_end == t_end && p->cr == cr && p->mode == 0 &&
+        p->epoch == cx.scratch_epoch)
+        return p;
     delete p;
     p = new TriplesPlan();
     slot = p;
@@ -397,6 +401,7 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
     p->gdesc = (GettGroup*)cx.scratch("t_gdesc", (int64_t)(gd.size() * sizeof(GettGroup) / sizeof(double) + 1));
     AFESP_HIP(hipMemcpyAsync(p->gdesc, gd.data(), gd.size() * sizeof(GettGroup), hipMemcpyHostToDevice, cx.stream));
     cx.sync();   // the host vectors die here
+    p->epoch = cx.scratch_epoch;
     return p;
 }
 

@@ -138,3 +138,9 @@ def test_cached_triples_plans_of_both_solvers_do_not_clobber_each_other(eng):
     a2 = eng.do_ccsd_t_spatial()
     b2 = eng.do_ccsd_t_spinorb()
     assert np.array_equal(a1, a2) and b1 == b2
+    # re-initialising one solver frees the context's cached scratch buffers: the other solver's plan must notice
+    eng.init_cc_spinorb(n, 2 * o, e, eri, 4)
+    eng.do_ccsd_spinorb(60, 1e-9, 1e-9)
+    a3 = eng.do_ccsd_t_spatial()
+    assert np.max(np.abs(a3 - a1)) < 1e-14
+    assert abs(eng.do_ccsd_t_spinorb() - b1) < 1e-14
