@@ -592,7 +592,9 @@ hipError_t gett_launch_grouped(const GettProblem& p, const GettGroup* dev_groups
     a.dbg = g_dbg;
     a.groups = dev_groups;
     a.total_tiles = total_tiles;
-    a.gm = g_group_m > 0 ? g_group_m : (max_ntiles >= 8 ? 4 : max_ntiles >= 4 ? 8 : max_ntiles >= 2 ? 16 : 32);
+    // a patch of gm m-tiles x all n-tiles of a group should be the ~32 tiles one XCD works on in a round (its L2 then
+    // serves every operand panel of the patch once)
+    a.gm = g_group_m > 0 ? g_group_m : std::max(1, (32 + max_ntiles / 2) / std::max(1, max_ntiles));
     if (a.gm > a.mtiles) a.gm = a.mtiles;
     dim3 grid((unsigned)total_tiles, 1, 1);
     if (tm == 16) {
