@@ -282,3 +282,23 @@ def test_iteration_graph_survives_other_work_in_the_same_context(eng):
             eng.so_iterate()
         t1, t2 = eng.amplitudes()
         assert np.max(np.abs(t2 - cc.t2)) < 1e-11 and np.max(np.abs(t1 - cc.t1)) < 1e-11, it
+
+
+@pytest.mark.parametrize("o,v", [(4, 10), (3, 16), (6, 7)])
+def test_completely_renormalised_triples_on_synthetic_extents(eng, o, v):
+    """CR moments through the grouped 16-byte-staged launches (even v) and the plain ones (odd v), whole range and shards,
+    against the oracle (the molecules above all have an odd number of virtuals)."""
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.04, seed=11 + o)
+    eng.ccsd_init(o, v, e, eri, 6)
+    cc = orc.OracleCC(o, v, eri, e, 6)
+    nit, _, _ = eng.do_ccsd_spatial(60, 1e-9, 1e-9)
+    onit, _, _ = cc.solve(60, 1e-9, 1e-9)
+    assert nit == onit and nit > 0
+    eng.build_cr_intermediates()
+    ipp, ioo = cc.cr_intermediates()
+    out = eng.do_ccsd_t_spatial_cr()
+    ref = cc.triples_cr(e)
+    assert np.max(np.abs(out - ref)) < 1e-10 * max(1.0, np.max(np.abs(ref)))
+    nt = eng.ntriples()
+    parts = eng.do_ccsd_t_spatial_cr(0, nt // 3) + eng.do_ccsd_t_spatial_cr(nt // 3, nt)
+    assert np.max(np.abs(parts - out)) < 1e-12 * max(1.0, np.max(np.abs(out)))
