@@ -91,6 +91,44 @@ __global__ __launch_bounds__(256) void triples_dbase_kernel(double* partial, Tri
     }
 }
 
+// The concatenated (T) operands in one pass each (instead of a memset and four or two permutations):
+//   vt (kappa,b,c,k) and vtT(kappa,c,b,k):  kappa < v: X(b,c,k,kappa) through the strides sx[] = (b,c,k,d);
+//                                           v <= kappa < v+o: t2(kappa-v, k, b, c);  else 0 (K padding)
+__global__ __launch_bounds__(256) void triples_build_vt_kernel(double* vt, double* vtT, const double* X, int64_t sb, int64_t sc, int64_t sk,
+                                                             int64_t sd, const double* t2, int o, int v, int Kc)
+{
+    const int64_t n = (int64_t)Kc * v * v * o;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
+        const int kap = (int)(x % Kc);
+        int64_t r = x / Kc;
+        const int b = (int)(r % v);
+        r /= v;
+        const int c = (int)(r % v), k = (int)(r / v);
+        double val = 0.0;
+        if (kap < v) val = X[sb * b + sc * c + sk * k + sd * kap];
+        else if (kap < v + o) val = t2[(kap - v) + (int64_t)o * (k + (int64_t)o * (b + (int64_t)v * c))];
+        vt[x] = val;
+        vtT[kap + (int64_t)Kc * (c + (int64_t)v * (b + (int64_t)v * k))] = val;
+    }
+}
+//   tt(kappa,a,j,i):  kappa < v: t2(i,j,a,kappa);  v <= kappa < v+o: -Y(i,j,a,kappa-v) through sy[] = (i,j,a,l);  else 0
+__global__ __launch_bounds__(256) void triples_build_tt_kernel(double* tt, const double* t2, const double* Y, int64_t si, int64_t sj, int64_t sa,
+                                                             int64_t sl, int o, int v, int Kc)
+{
+    const int64_t n = (int64_t)Kc * v * o * o;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
+        const int kap = (int)(x % Kc);
+        int64_t r = x / Kc;
+        const int a = (int)(r % v);
+        r /= v;
+        const int j = (int)(r % o), i = (int)(r / o);
+        double val = 0.0;
+        if (kap < v) val = t2[i + (int64_t)o * (j + (int64_t)o * (a + (int64_t)v * kap))];
+        else if (kap < v + o) val = -Y[si * i + sj * j + sa * a + sl * (kap - v)];
+        tt[x] = val;
+    }
+}
+
 // Everything about a (T) evaluation that depends only on (o, v, triple range): chunking, per-chunk GEMM column tables,
 // per-triple metadata, the cube-orbit list.  Built once, kept in device memory, reused by every later call.
 struct TriplesPlan {
@@ -432,22 +470,14 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     Tensor vt = view(cx.scratch("t_vt", 2 * Kc * v2 * O), {Kc, V, V, O}), tt = view(cx.scratch("t_tt", Kc * V * O * O), {Kc, V, O, O});
     Tensor vtT = vt;
     vtT.d = vt.d + Kc * v2 * O;
-    auto sub = [&](const Tensor& full, int64_t row0, int64_t nrows) {
-        Tensor t = full;
-        t.d = full.d + row0;
-        t.dim[0] = nrows;
-        return t;
-    };
-    if (Kc != V + O) {
-        AFESP_HIP(hipMemsetAsync(vt.d, 0, sizeof(double) * 2 * Kc * v2 * O, cx.stream));
-        AFESP_HIP(hipMemsetAsync(tt.d, 0, sizeof(double) * Kc * V * O * O, cx.stream));
-    }
-    permute_add(cx, 1.0, s.v_vvov, "cbkd", 0.0, sub(vt, 0, V), "dbck");
-    permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vt, V, O), "lbck");
-    permute_add(cx, 1.0, s.v_vvov, "cbkd", 0.0, sub(vtT, 0, V), "dcbk");
-    permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vtT, V, O), "lcbk");
-    permute_add(cx, 1.0, s.t2, "ijad", 0.0, sub(tt, 0, V), "daji");
-    permute_add(cx, -1.0, s.v_oovo, "ijal", 0.0, sub(tt, V, O), "laji");
+    auto blocks = [](int64_t n) { return dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)); };
+    // v_vvov(c,b,k,d): strides of (b,c,k,d) = (V, 1, V^2, V^2 O);  v_oovo(i,j,a,l): (1, O, O^2, O^2 V)
+    hipLaunchKernelGGL(triples_build_vt_kernel, blocks(Kc * v2 * O), dim3(256), 0, cx.stream, vt.d, vtT.d, s.v_vvov.d, V, (int64_t)1,
+                       v2, v2 * O, s.t2.d, o, v, (int)Kc);
+    AFESP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(triples_build_tt_kernel, blocks(Kc * V * O * O), dim3(256), 0, cx.stream, tt.d, s.t2.d, s.v_oovo.d, (int64_t)1, O,
+                       O * O, O * O * V, o, v, (int)Kc);
+    AFESP_HIP(hipGetLastError());
     Tensor vs = view(cx.scratch("t_vs", v2 * O * O), {V, V, O, O});    // vs(x,y,p,q)  = v_oovv(p,q,x,y)
     Tensor ts = view(cx.scratch("t_ts", v2 * O * O), {V, V, O, O});    // ts(x,y,p,q)  = t2(p,q,x,y)
     permute_add(cx, 1.0, s.v_oovv, "pqxy", 0.0, vs, "xypq");
@@ -462,16 +492,13 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         tt2 = view(cx.scratch("t_tt2", Kc * V * O * O), {Kc, V, O, O});
         Tensor vt2T = vt2;
         vt2T.d = vt2.d + Kc * v2 * O;
-        if (Kc != V + O) {
-            AFESP_HIP(hipMemsetAsync(vt2.d, 0, sizeof(double) * 2 * Kc * v2 * O, cx.stream));
-            AFESP_HIP(hipMemsetAsync(tt2.d, 0, sizeof(double) * Kc * V * O * O, cx.stream));
-        }
-        permute_add(cx, 1.0, s.I_vovv_pp, "dkbc", 0.0, sub(vt2, 0, V), "dbck");
-        permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vt2, V, O), "lbck");
-        permute_add(cx, 1.0, s.I_vovv_pp, "dkbc", 0.0, sub(vt2T, 0, V), "dcbk");
-        permute_add(cx, 1.0, s.t2, "lkbc", 0.0, sub(vt2T, V, O), "lcbk");
-        permute_add(cx, 1.0, s.t2, "ijad", 0.0, sub(tt2, 0, V), "daji");
-        permute_add(cx, -1.0, s.I_ooov_pp, "jila", 0.0, sub(tt2, V, O), "laji");
+        // I_vovv_pp(d,k,b,c): strides of (b,c,k,d) = (V O, V^2 O, V, 1);  I_ooov_pp(j,i,l,a): (i,j,a,l) = (O, 1, O^3, O^2)
+        hipLaunchKernelGGL(triples_build_vt_kernel, blocks(Kc * v2 * O), dim3(256), 0, cx.stream, vt2.d, vt2T.d, s.I_vovv_pp.d, V * O,
+                           v2 * O, V, (int64_t)1, s.t2.d, o, v, (int)Kc);
+        AFESP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(triples_build_tt_kernel, blocks(Kc * V * O * O), dim3(256), 0, cx.stream, tt2.d, s.t2.d, s.I_ooov_pp.d, O,
+                           (int64_t)1, O * O * O, O * O, o, v, (int)Kc);
+        AFESP_HIP(hipGetLastError());
         Mpool = cx.scratch("t_mpool", p->nb * vp3);
     }
     const int nq = cr ? 6 : want_d ? 4 : 2;
