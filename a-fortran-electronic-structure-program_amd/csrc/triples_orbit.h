@@ -53,14 +53,19 @@ __host__ __device__ constexpr int orbit_term(bool fused, int idx) { return fused
 // :2228-2247): only E[T] and the z term.  The symmetriser P in z_bar = P Z / D is self-adjoint and D is symmetric, and a
 // workgroup sums over a set of elements closed under every permutation, so  sum z_bar W = sum Z (P W)/D = sum Z t_bar:
 // ONE evaluation of Z per element (6 LDS reads) instead of six (27), and no t2 patches.
+// The plain variant also folds W onto the staging area once the last term has been permuted out (its patches fit behind
+// it), which brings a workgroup under 40 KiB of LDS: four per CU instead of three.
 template <bool CR, bool FUSED, bool WANT_D = true>
-__global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restrict__ partial, const double* __restrict__ Xpool,
+__global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(double* __restrict__ partial, const double* __restrict__ Xpool,
                                                             const double* __restrict__ Mpool,
                                                             const TripleMeta* __restrict__ meta,
                                                             const int* __restrict__ orbits, TriplesIn in, int nblk_total)
 {
-    __shared__ __attribute__((aligned(16))) double stage[6 * CUBE + 512];   // X cubes of one term; later the V / T2 patches and t1 rows
-    __shared__ double wl[6 * CUBE];            // W on the six cubes of the orbit
+    constexpr bool ALIAS = !WANT_D;
+    // X cubes of one term; later the V / T2 patches and t1 rows (ALIAS: W, then the V patches and t1 rows)
+    __shared__ __attribute__((aligned(16))) double stage[ALIAS ? 6 * CUBE + 27 * PATCH + 72 : 6 * CUBE + 512];
+    __shared__ double wl_own[ALIAS ? 1 : 6 * CUBE];
+    double* const wl = ALIAS ? stage : wl_own;   // W on the six cubes of the orbit
     __shared__ int srcq[6][6];                 // srcq[s][q]: which cube of the orbit is sigma_s applied to cube q
     __shared__ int dup[6];                     // 1 if cube q repeats an earlier cube (degenerate orbit)
     __shared__ double red[24];
@@ -132,13 +137,14 @@ __global__ __launch_bounds__(256, 3) void triples_orbit_kernel(double* __restric
             else mreg[CR ? r : 0] += x;
         }
     }
+    if (ALIAS) __syncthreads();   // the last term's readers are done with `stage`
 #pragma unroll
     for (int r = 0; r < 12; ++r) wl[(r >> 1) * CUBE + cidx(l0, l1, l2h[r & 1])] = wreg[r];
-    __syncthreads();
+    if (!ALIAS) __syncthreads();  // ALIAS: the patches sit behind W, one barrier below publishes both
     // patches: vp[pair][sx][sy][lx + 8 ly] = V_pair(x in tile[sx], y in tile[sy]); pairs (j,k), (i,k), (i,j)
-    double* vp = stage;                  // 3*9*64
-    double* tp = stage + 27 * PATCH;     // 3*9*64
-    double* t1r = stage + 54 * PATCH;    // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l)
+    double* vp = ALIAS ? stage + 6 * CUBE : stage;   // 3*9*64
+    double* tp = stage + 27 * PATCH;                 // 3*9*64 (WANT_D only)
+    double* t1r = ALIAS ? stage + 6 * CUBE + 27 * PATCH : stage + 54 * PATCH;   // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l)
     const int occ[3] = {m.i, m.j, m.k};
     const int pairp[3] = {m.j, m.i, m.i}, pairq[3] = {m.k, m.k, m.j};
     for (int el = t; el < 27 * PATCH; el += 256) {
