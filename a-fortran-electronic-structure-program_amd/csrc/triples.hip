@@ -141,7 +141,11 @@ struct TriplesPlan {
     int64_t epoch = -1;   // Context::scratch_epoch when the device tables were placed (they live in cached scratch buffers)
     struct Group { int r; int64_t start, N; int q = 0; int64_t koffA = 0, koffB = 0; };   // q, koff*: fused scheme only
     struct Chunk { int nt; int64_t meta_off, tab_off, ntab; std::vector<Group> groups;
-                   int64_t gdesc_off = 0; int total_tiles = 0, max_ntiles = 0; };   // fused scheme: GettGroup array (device)
+                   int64_t gdesc_off = 0; int total_tiles = 0, max_ntiles = 0;      // fused scheme: GettGroup array (device)
+                   // fused scheme, groups with q == r: Y^{p;qq}(x;y,z) = X(x;y,z) + X(x;z,y), only X is computed (half the
+                   // summation length, a launch of its own) and the orbit kernel adds the transpose (TripleMeta::pad)
+                   int64_t gdesc_diag_off = 0; int ngroups_diag = 0, total_tiles_diag = 0, max_ntiles_diag = 0, ngroups_off = 0;
+                   int64_t ncol_off = 0, ncol_diag = 0; bool split_diag = false; };
     std::vector<Chunk> chunks;
     int64_t* tables = nullptr;     // [kappa | Am | Cm | per chunk: offBn, offCn]
     int64_t off_k = 0, off_Am = 0, off_Cm = 0;
@@ -323,6 +327,11 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
             tab.push_back(CUBE * nt8 * (b / TT) + TT * (b % TT) + CUBE * nt8 * nt8 * (c / TT) + TT * TT * (c % TT));
     std::vector<TripleMeta> metas;
     int64_t flat = 0, max_blocks = 1;
+    int tm, tn, BM, BN;
+    gett_grouped_tile((int)v2, (Kc % 2 == 0) && (V % 2 == 0), &tm, &tn, &BM, &BN);
+    const int mtiles = (int)((v2 + BM - 1) / BM);
+    const char* split_env = getenv("AFESP_T_SPLIT_TILES");   // test / tuning knob, read when a plan is built
+    const int64_t split_min_tiles = split_env ? atoll(split_env) : 1024;
     for (int I = 0; I < nbk; ++I)
         for (int J = I; J < nbk; ++J)
             for (int K = J; K < nbk; ++K) {
@@ -345,7 +354,9 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
                         for (int k = std::max(j, K * sb); k < std::min(o, (K + 1) * sb); ++k, ++flat) {
                             if (flat < t_begin || flat >= t_end) continue;
                             TripleMeta m;
-                            m.i = i; m.j = j; m.k = k; m.pad = 0;
+                            m.i = i; m.j = j; m.k = k;
+                            // blocks Y^{i;jk}, Y^{j;ik}, Y^{k;ij} whose pair coincides hold only X (see Chunk)
+                            m.pad = (j == k ? 1 : 0) | (i == k ? 2 : 0) | (i == j ? 4 : 0);
                             m.mult = (i == j && j == k) ? 1.0 : (i == j || j == k) ? 3.0 : 6.0;
                             m.woff = 0;
                             for (int q = 0; q < 6; ++q) m.xoff[q] = 0;
@@ -384,6 +395,14 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
                     for (int64_t x = 0; x < Kc; ++x) hK.push_back(Kc * V * ((int64_t)r - q) + x);                  // tt(:, x, r, p)
                     ch.groups.push_back(g);
                 }
+                // the q == r groups get a launch of their own (half the summation length) when it fills the device a few
+                // times over; a small system keeps them in the one launch, computed in full
+                int64_t diag_tiles = 0;
+                for (const TriplesPlan::Group& g : ch.groups)
+                    if (g.q == g.r) diag_tiles += mtiles * ((g.N + BN - 1) / BN);
+                ch.split_diag = diag_tiles >= split_min_tiles;
+                if (!ch.split_diag)
+                    for (int t = 0; t < ch.nt; ++t) metas[ch.meta_off + t].pad = 0;
                 ch.ntab = (int64_t)hBn.size();
                 ch.tab_off = (int64_t)tab.size();
                 tab.insert(tab.end(), hBn.begin(), hBn.end());
@@ -408,15 +427,15 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
     AFESP_HIP(hipMemcpyAsync(p->orbits, orb.data(), orb.size() * sizeof(int), hipMemcpyHostToDevice, cx.stream));
     // group descriptors of the grouped GEMM launches (one launch per chunk): tile counts for the tile shape the launcher
     // will use, table pointers into the uploaded tables
-    int tm, tn, BM, BN;
-    gett_grouped_tile((int)v2, (Kc % 2 == 0) && (V % 2 == 0), &tm, &tn, &BM, &BN);
-    const int mtiles = (int)((v2 + BM - 1) / BM);
     std::vector<GettGroup> gd;
     for (TriplesPlan::Chunk& ch : p->chunks) {
-        ch.gdesc_off = (int64_t)gd.size();
-        int tile = 0;
         const int64_t* tabs = p->tables + ch.tab_off;
+      for (int diag = 0; diag < 2; ++diag) {
+        (diag ? ch.gdesc_diag_off : ch.gdesc_off) = (int64_t)gd.size();
+        int tile = 0, ng = 0, mx = 0;
+        int64_t ncol = 0;
         for (const TriplesPlan::Group& g : ch.groups) {
+            if ((ch.split_diag && g.q == g.r) != (diag == 1)) continue;
             GettGroup d;
             d.a_off = Kc * v2 * g.r;
             d.offAk = tabs + g.koffA;   // second half: vtT(x, ., ., q)
@@ -428,13 +447,17 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
             d.tile_start = tile;
             d.pad = 0;
             tile += mtiles * d.ntiles;
-            ch.max_ntiles = std::max(ch.max_ntiles, d.ntiles);
+            mx = std::max(mx, d.ntiles);
+            ncol += g.N;
+            ++ng;
             gd.push_back(d);
         }
         GettGroup end{};
         end.tile_start = tile;
         gd.push_back(end);
-        ch.total_tiles = tile;
+        if (diag) { ch.total_tiles_diag = tile; ch.ngroups_diag = ng; ch.max_ntiles_diag = mx; ch.ncol_diag = ncol; }
+        else { ch.total_tiles = tile; ch.ngroups_off = ng; ch.max_ntiles = mx; ch.ncol_off = ncol; }
+      }
     }
     p->gdesc = (GettGroup*)cx.scratch("t_gdesc", (int64_t)(gd.size() * sizeof(GettGroup) / sizeof(double) + 1));
     AFESP_HIP(hipMemcpyAsync(p->gdesc, gd.data(), gd.size() * sizeof(GettGroup), hipMemcpyHostToDevice, cx.stream));
@@ -536,20 +559,24 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
             gp.a_kcontig = gp.b_kcontig = true;
             gp.wide = (Kc % 2 == 0) && (V % 2 == 0);   // then every row/column/K offset and shift is even
-            const GettGroup* gd = p->gdesc + ch.gdesc_off;
-            AFESP_HIP(gett_launch_grouped(gp, gd, (int)ch.groups.size(), ch.total_tiles, ch.max_ntiles, cx.stream));
-            if (cr) {
-                GettProblem gm = gp;
-                gm.A = vt2.d;
-                gm.B = tt2.d;
-                gm.C = Mpool;
-                AFESP_HIP(gett_launch_grouped(gm, gd, (int)ch.groups.size(), ch.total_tiles, ch.max_ntiles, cx.stream));
+            GettProblem gm = gp;
+            gm.A = vt2.d;
+            gm.B = tt2.d;
+            gm.C = Mpool;
+            if (ch.ngroups_off > 0) {
+                const GettGroup* gd = p->gdesc + ch.gdesc_off;
+                AFESP_HIP(gett_launch_grouped(gp, gd, ch.ngroups_off, ch.total_tiles, ch.max_ntiles, cx.stream));
+                if (cr) AFESP_HIP(gett_launch_grouped(gm, gd, ch.ngroups_off, ch.total_tiles, ch.max_ntiles, cx.stream));
+            }
+            if (ch.ngroups_diag > 0) {   // pairs q == r: the first half of the summation index only
+                const GettGroup* gd = p->gdesc + ch.gdesc_diag_off;
+                gp.K = gm.K = (int)Kc;
+                AFESP_HIP(gett_launch_grouped(gp, gd, ch.ngroups_diag, ch.total_tiles_diag, ch.max_ntiles_diag, cx.stream));
+                if (cr) AFESP_HIP(gett_launch_grouped(gm, gd, ch.ngroups_diag, ch.total_tiles_diag, ch.max_ntiles_diag, cx.stream));
             }
             if (cx.prof) {
-                int64_t ncol = 0;
-                for (const TriplesPlan::Group& g : ch.groups) ncol += g.N;
-                cx.prof_gemm_launches += 1;
-                cx.prof_gemm_flop += 2.0 * (double)gp.M * (double)ncol * 2.0 * (double)(V + O);
+                cx.prof_gemm_launches += (ch.ngroups_off > 0) + (ch.ngroups_diag > 0);
+                cx.prof_gemm_flop += 2.0 * (double)gp.M * (double)(2 * ch.ncol_off + ch.ncol_diag) * (double)(V + O);
             }
         }
         stamp();

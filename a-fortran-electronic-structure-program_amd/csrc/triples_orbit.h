@@ -6,7 +6,7 @@
 namespace afesp {
 
 struct TripleMeta {
-    int i, j, k, pad;
+    int i, j, k, pad;   // pad: fused scheme, bit t set = block t of (Y^{i;jk}, Y^{j;ik}, Y^{k;ij}) holds X only (triples.hip)
     double mult;       // number of distinct ordered permutations of (i,j,k): 6, 3 or 1
     int64_t xoff[6];   // element offsets of X^{ijk}, X^{jik}, X^{kji}, X^{ikj}, X^{jki}, X^{kij} in the X pool
     int64_t woff;
@@ -124,6 +124,10 @@ __global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(doub
 #pragma unroll
     for (int s2 = 0; s2 < NTERM; ++s2) {
         const int s = orbit_term(FUSED, s2 % NT1);
+        // a block whose occupied pair coincides (Y^{p;qq}) holds X(x;y,z) only: Y = X + X with (y,z) exchanged, i.e. the same
+        // staged cubes read through the permutation s followed by that exchange: (abc)->(acb), (bac)->(bca), (cab)->(cba)
+        const int sT = s == 0 ? 3 : s == 1 ? 4 : 2;
+        const bool sym = FUSED && ((m.pad >> (s2 % NT1)) & 1);
         __syncthreads();   // the previous term's readers are done with `stage` (also publishes srcq on the first pass)
         park_term(xin);
         if (s2 + 1 < NTERM) load_term((s2 + 1 < NT1 ? Xpool : Mpool) + m.xoff[orbit_term(FUSED, (s2 + 1) % NT1)], xin);
@@ -132,7 +136,8 @@ __global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(doub
         for (int r = 0; r < 12; ++r) {
             const int q = r >> 1;
             const int l[3] = {l0, l1, l2h[r & 1]};
-            const double x = stage[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])];
+            double x = stage[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])];
+            if (FUSED && sym) x += stage[srcq[sT][q] * CUBE + cidx(l[sig(sT, 0)], l[sig(sT, 1)], l[sig(sT, 2)])];
             if (s2 < NT1) wreg[r] += x;
             else mreg[CR ? r : 0] += x;
         }

@@ -302,3 +302,37 @@ def test_completely_renormalised_triples_on_synthetic_extents(eng, o, v):
     nt = eng.ntriples()
     parts = eng.do_ccsd_t_spatial_cr(0, nt // 3) + eng.do_ccsd_t_spatial_cr(nt // 3, nt)
     assert np.max(np.abs(parts - out)) < 1e-12 * max(1.0, np.max(np.abs(out)))
+
+
+@pytest.mark.parametrize("o,v,tiny_pool", [(5, 12, False), (7, 10, True), (4, 17, False)])
+def test_coinciding_pair_blocks_in_their_own_launch(o, v, tiny_pool, monkeypatch):
+    """Blocks Y^{p;qq} are computed as X over half the summation index in a launch of their own and symmetrised by the orbit
+    kernel; at small sizes that launch is normally folded into the main one, so force it (AFESP_T_SPLIT_TILES=1) and check
+    the plain, the full and the completely renormalised evaluation against the oracle, whole range and shards.  A tiny
+    pool gives one chunk per triple (chunks with and without coinciding pairs)."""
+    from afesp_amd.capi import Engine
+    monkeypatch.setenv("AFESP_T_SPLIT_TILES", "1")
+    if tiny_pool:
+        monkeypatch.setenv("AFESP_T_POOL_GIB", "0")   # occupied blocks of one index: a chunk per triple
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.04, seed=31 + v)
+    cc = orc.OracleCC(o, v, eri, e, 6)
+    cc.solve(60, 1e-9, 1e-9)
+    ref = cc.triples(e)
+    ipp, ioo = cc.cr_intermediates()
+    ref_cr = cc.triples_cr(e)
+    eng = Engine(0)
+    try:
+        eng.ccsd_init(o, v, e, eri, 6)
+        eng.do_ccsd_spatial(60, 1e-9, 1e-9)
+        full = eng.do_ccsd_t_spatial()
+        plain = eng.do_ccsd_t_spatial_plain()
+        assert np.max(np.abs(full[:4] - ref[:4])) < 1e-11 * max(1.0, np.max(np.abs(ref)))
+        assert np.max(np.abs(plain - ref[:2])) < 1e-11
+        nt = eng.ntriples()
+        parts = eng.do_ccsd_t_spatial_plain(0, nt // 3) + eng.do_ccsd_t_spatial_plain(nt // 3, nt)
+        assert np.max(np.abs(parts - plain)) < 1e-13 * max(1.0, np.max(np.abs(plain)))
+        eng.build_cr_intermediates()
+        out = eng.do_ccsd_t_spatial_cr()
+        assert np.max(np.abs(out - ref_cr)) < 1e-10 * max(1.0, np.max(np.abs(ref_cr)))
+    finally:
+        eng.close()
