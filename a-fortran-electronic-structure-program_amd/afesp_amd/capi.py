@@ -23,7 +23,7 @@ EXPORTS = [
     "afesp_ctx_create", "afesp_ctx_destroy", "afesp_last_error", "afesp_version", "afesp_neri", "afesp_ao2mo_mp2",
     "afesp_ccsd_init", "afesp_ccsd_iterate", "afesp_ccsd_energy", "afesp_ccsd_diis", "afesp_ccsd_solve",
     "afesp_ccsd_get_amplitudes", "afesp_ccsd_set_amplitudes", "afesp_ccsd_get_tensor", "afesp_ccsd_update_intermediates",
-    "afesp_ccsd_update_amplitudes", "afesp_ccsd_t_ntriples", "afesp_ccsd_t", "afesp_gemm", "afesp_permute4",
+    "afesp_ccsd_update_amplitudes", "afesp_ccsd_t_ntriples", "afesp_ccsd_t", "afesp_ccsd_t_shard_bounds", "afesp_gemm", "afesp_permute4",
     "afesp_contract", "afesp_synthetic_init", "afesp_time_pp_ladder", "afesp_bench_contract", "afesp_set_tuning", "afesp_bench_stream", "afesp_profile", "afesp_ccsd_cr_intermediates", "afesp_ccsd_t_cr",
     "afesp_ccsd_so_init", "afesp_ccsd_so_energy", "afesp_ccsd_so_iterate", "afesp_ccsd_so_diis", "afesp_ccsd_so_get_amplitudes",
     "afesp_ccsd_so_set_amplitudes", "afesp_ccsd_so_get_tensor", "afesp_ccsd_so_t_ntriples", "afesp_ccsd_so_t",
@@ -67,6 +67,7 @@ def load_library():
     L.afesp_ccsd_update_amplitudes.argtypes = [C.c_void_p]
     L.afesp_ccsd_t_ntriples.argtypes = [i64]
     L.afesp_ccsd_t_ntriples.restype = i64
+    L.afesp_ccsd_t_shard_bounds.argtypes = [C.c_void_p, i64, i64, C.c_int, C.c_int, C.POINTER(i64)]
     L.afesp_ccsd_t.argtypes = [C.c_void_p, i64, i64, _dp]
     L.afesp_ccsd_t_cr.argtypes = [C.c_void_p, i64, i64, _dp]
     L.afesp_ccsd_t_plain.argtypes = [C.c_void_p, i64, i64, _dp]
@@ -214,6 +215,12 @@ class Engine:
     # ---- src/ccsd.f90:2018-2293
     def ntriples(self):
         return self.L.afesp_ccsd_t_ntriples(self.o)
+
+    def shard_bounds(self, world, cr=False):
+        """Cost-balanced shard boundaries of the (i<=j<=k) list: rank r evaluates [b[r], b[r+1])."""
+        b = (i64 * (world + 1))()
+        self._chk(self.L.afesp_ccsd_t_shard_bounds(self.h, self.o, self.v, 1 if cr else 0, world, b))
+        return [int(x) for x in b]
 
     def do_ccsd_t_spatial(self, t_begin=0, t_end=None):
         out = np.zeros(4)

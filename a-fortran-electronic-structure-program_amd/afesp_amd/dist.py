@@ -9,7 +9,8 @@ import numpy as np
 
 
 def shard_range(ntriples: int, rank: int, world: int) -> tuple[int, int]:
-    """Contiguous, exhaustive, non-overlapping: rank r gets [r*n//w, (r+1)*n//w)."""
+    """Contiguous, exhaustive, non-overlapping: rank r gets [r*n//w, (r+1)*n//w).  Equal counts; the spin-free (T) on the
+    GPU uses Engine.shard_bounds (afesp_ccsd_t_shard_bounds) instead, which equalises estimated device time."""
     return rank * ntriples // world, (rank + 1) * ntriples // world
 
 

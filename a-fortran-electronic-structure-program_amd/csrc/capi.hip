@@ -388,6 +388,15 @@ int afesp_ccsd_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t
 
 int64_t afesp_ccsd_t_ntriples(int64_t nocc) { return triples_count((int)nocc); }
 
+int afesp_ccsd_t_shard_bounds(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr, int world, int64_t* bounds)
+{
+    return guarded(ctx, [&] {
+        if (nocc < 1 || nvirt < 1 || world < 1 || !bounds) throw Error(1, "afesp_ccsd_t_shard_bounds: bad arguments");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        triples_shard_bounds((int)nocc, (int)nvirt, cr != 0, world, bounds);
+    });
+}
+
 int afesp_ccsd_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[4])
 {
     return guarded(ctx, [&] {

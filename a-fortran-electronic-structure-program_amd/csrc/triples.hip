@@ -466,6 +466,81 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
     return p;
 }
 
+// Estimated device time (seconds, nominal rates) of the fused evaluation of the flat range [b, e): the grouped GEMM tiles
+// of every block triple the range touches (a block triple cut by a range end keeps its pair groups but with fewer
+// columns each, so cost is not additive in the range) plus the orbit kernel's reads.  Only ratios matter: it balances
+// the shards of triples_shard_bounds.
+static double fused_range_cost(int o, int v, int sb, int64_t b, int64_t e, int BM, int BN, int64_t split_min_tiles)
+{
+    const int64_t V = v, O = o, v2 = V * V, Kc = (V + O + 15) / 16 * 16;
+    const int64_t nt8 = (V + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;
+    const int64_t mtiles = (v2 + BM - 1) / BM;
+    const int nbk = (o + sb - 1) / sb;
+    const double half_tile_s = 2.0 * BM * BN * (double)Kc / 58e12;   // one tile over half the summation index, whole device
+    const double triple_s = 3.0 * (double)vp3 * 8.0 / 3.9e12;       // orbit kernel: three blocks read once
+    double cost = 0.0;
+    int64_t flat = 0;
+    std::unordered_map<int64_t, int> npair;   // (q,r) -> number of blocks (distinct p)
+    std::unordered_map<int64_t, char> seen;
+    for (int I = 0; I < nbk && flat < e; ++I)
+        for (int J = I; J < nbk && flat < e; ++J)
+            for (int K = J; K < nbk && flat < e; ++K) {
+                npair.clear();
+                seen.clear();
+                int64_t nt = 0;
+                auto need = [&](int pp, int qq, int rr) {
+                    if (qq > rr) std::swap(qq, rr);
+                    if (seen.emplace(((int64_t)pp * o + qq) * o + rr, 1).second) ++npair[(int64_t)qq * o + rr];
+                };
+                for (int i = I * sb; i < std::min(o, (I + 1) * sb); ++i)
+                    for (int j = std::max(i, J * sb); j < std::min(o, (J + 1) * sb); ++j)
+                        for (int k = std::max(j, K * sb); k < std::min(o, (K + 1) * sb); ++k, ++flat) {
+                            if (flat < b || flat >= e) continue;
+                            ++nt;
+                            need(i, j, k);
+                            need(j, i, k);
+                            need(k, i, j);
+                        }
+                if (nt == 0) continue;
+                int64_t off = 0, diag = 0;
+                for (const auto& g : npair) {
+                    const int64_t tiles = mtiles * ((V * g.second + BN - 1) / BN);
+                    (g.first / o == g.first % o ? diag : off) += tiles;
+                }
+                const double halves = 2.0 * (double)off + (diag >= split_min_tiles ? 1.0 : 2.0) * (double)diag;
+                // (a launch of fewer tiles than CUs still takes one tile's time; ~40 us of launches per block triple)
+                cost += std::max(halves, 512.0) * half_tile_s + (double)nt * triple_s + 40e-6;
+            }
+    return cost;
+}
+
+// Shard boundaries of the flat triple list for `world` ranks, balanced by fused_range_cost: rank r evaluates
+// [bounds[r], bounds[r+1]).  Every rank computes the same boundaries (they depend on o, v, the device memory size and
+// the tuning environment only).
+void triples_shard_bounds(int o, int v, bool cr, int world, int64_t* bounds)
+{
+    const int64_t V = v, O = o, Kc = (V + O + 15) / 16 * 16, nt = triples_count(o);
+    int tm, tn, BM, BN;
+    gett_grouped_tile((int)(V * V), (Kc % 2 == 0) && (V % 2 == 0), &tm, &tn, &BM, &BN);
+    const int sb = fused_block_size(o, v, cr, device_pool_budget());
+    const char* split_env = getenv("AFESP_T_SPLIT_TILES");
+    const int64_t split_min_tiles = split_env ? atoll(split_env) : 1024;
+    auto cost = [&](int64_t b, int64_t e) { return fused_range_cost(o, v, sb, b, e, BM, BN, split_min_tiles); };
+    bounds[0] = 0;
+    for (int r = 0; r < world; ++r) {
+        const int64_t b = bounds[r];
+        if (r == world - 1 || b >= nt) { bounds[r + 1] = nt; continue; }
+        const double target = cost(b, nt) / (double)(world - r);
+        int64_t lo = b, hi = nt;   // smallest end whose cost reaches the target
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) / 2;
+            if (cost(b, mid) >= target) hi = mid; else lo = mid + 1;
+        }
+        if (lo > b + 1 && target - cost(b, lo - 1) < cost(b, lo) - target) --lo;   // the nearer of the two
+        bounds[r + 1] = lo;
+    }
+}
+
 void triples_plan_free(CCState& s)
 {
     delete (TriplesPlan*)s.tplan;

@@ -140,7 +140,6 @@ DEFAULT_SCALE = {"cfg5": 0.005}     # magnitude of the hashed integrals: keeps t
 def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch, with_roofline=True):
     """Run `warmup` untimed + `steps` timed steps of one workload; returns the result dictionary (rank 0) or None."""
     from afesp_amd.capi import Engine
-    from afesp_amd.dist import shard_range
     o, v = WORKLOADS[workload]
     scale = args.scale if args.scale is not None else DEFAULT_SCALE.get(workload, 0.02)
     seed = 12345
@@ -148,7 +147,7 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
     eng.synthetic_init(o, v, scale, seed, 8)
     eng.ccsd_energy()                                   # the "MP1" line: primes t2_old
     nt = eng.ntriples()
-    lo, hi = shard_range(nt, rank, world)               # contiguous shard of the i<=j<=k list
+    lo, hi = eng.shard_bounds(world)[rank:rank + 2]     # contiguous shard of the i<=j<=k list, balanced by cost
     red = torch.zeros(4, dtype=torch.float64, device=cdev)
 
     def barrier():

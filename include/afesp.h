@@ -78,6 +78,13 @@ int afesp_ccsd_update_amplitudes(afesp_ctx* ctx);
  *   out[2] = D[T]  (:2230-2231, :2243)          out[3] = D(T) (:2232) */
 int64_t afesp_ccsd_t_ntriples(int64_t nocc);
 int afesp_ccsd_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double out[4]);
+/* Shard boundaries for `world` ranks: rank r evaluates [bounds[r], bounds[r+1]) (bounds has world+1 entries, bounds[0] = 0,
+ * bounds[world] = afesp_ccsd_t_ntriples).  The reference splits the (i,j,k) loop `collapse(3) schedule(static,10)` over its
+ * threads (src/ccsd.f90:2091); here the triples are evaluated block triple by block triple of the occupied index, and a block
+ * triple cut by a shard end costs more per triple, so equal counts are not equal times: the boundaries equalise a cost
+ * estimate instead.  Identical on every rank; cr != 0 for shards of afesp_ccsd_t_cr (its pool holds two sets of blocks).
+ * Any other partition of the list is valid too -- the sums of the shards add up to the whole. */
+int afesp_ccsd_t_shard_bounds(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr, int world, int64_t* bounds);
 /* The same for the plain CCSD(T)_spatial / CCSD[T]_spatial types, which need neither y nor the D sums (the reference skips
  * them there as well, src/ccsd.f90:2181-2185, :2228-2247): out[0] = E[T], out[1] = E(T).  Cheaper: the z term is evaluated
  * once per element instead of at its six permutations (csrc/triples_orbit.h). */

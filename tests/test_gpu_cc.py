@@ -336,3 +336,30 @@ def test_coinciding_pair_blocks_in_their_own_launch(o, v, tiny_pool, monkeypatch
         assert np.max(np.abs(out - ref_cr)) < 1e-10 * max(1.0, np.max(np.abs(ref_cr)))
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("o,v,tiny_pool", [(6, 16, True), (7, 12, False)])
+def test_cost_balanced_shard_bounds_partition_the_list(o, v, tiny_pool, monkeypatch):
+    """afesp_ccsd_t_shard_bounds: monotone, exhaustive for every world size (also more ranks than triples), and the shards
+    add up to the whole evaluation."""
+    from afesp_amd.capi import Engine
+    if tiny_pool:
+        monkeypatch.setenv("AFESP_T_POOL_GIB", "0")
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.04, seed=5 + v)
+    eng = Engine(0)
+    try:
+        eng.ccsd_init(o, v, e, eri, 6)
+        eng.do_ccsd_spatial(40, 1e-9, 1e-9)
+        nt = eng.ntriples()
+        whole = eng.do_ccsd_t_spatial()
+        for world in (1, 2, 3, 8, nt + 3):
+            b = eng.shard_bounds(world)
+            assert len(b) == world + 1 and b[0] == 0 and b[-1] == nt
+            assert all(b[r] <= b[r + 1] for r in range(world))
+        for world in (3, 8):
+            b = eng.shard_bounds(world)
+            parts = sum(eng.do_ccsd_t_spatial(b[r], b[r + 1]) for r in range(world))
+            assert np.max(np.abs(parts - whole)) < 1e-12 * max(1.0, np.max(np.abs(whole)))
+        assert eng.shard_bounds(4, cr=True)[-1] == nt
+    finally:
+        eng.close()

@@ -14,8 +14,9 @@ nt = eng.ntriples()
 eng.do_ccsd_t_spatial_plain(0, nt)
 for N in (1, 2, 4, 8):
     ts = []
+    bounds = eng.shard_bounds(N) if len(sys.argv) < 2 else None   # any argument: equal counts instead
     for r in range(N):
-        lo, hi = shard_range(nt, r, N)
+        lo, hi = (bounds[r], bounds[r + 1]) if bounds else shard_range(nt, r, N)
         eng.do_ccsd_t_spatial_plain(lo, hi)               # plan + warm
         t0 = time.perf_counter(); eng.do_ccsd_t_spatial_plain(lo, hi); ts.append(time.perf_counter() - t0)
     print(f"N={N}: shard times (ms) " + " ".join("%.0f" % (x * 1e3) for x in ts) + f"  max {max(ts)*1e3:.0f} ms  sum/max/N = {sum(ts)/max(ts)/N:.2f}  speed-up of (T) {ts and (601.0/ (max(ts)*1e3)):.2f}x")
