@@ -15,7 +15,11 @@ for (o, v, reps) in ((20, 200, 4), (5, 53, 200)):
     e = eng.do_ccsd_t_spatial_plain()
     t0 = time.perf_counter()
     for r in range(reps): e = eng.do_ccsd_t_spatial_plain()
-    out.append("o=%%d v=%%d (T) %%.3f ms  E=%%.12e" %% (o, v, (time.perf_counter() - t0) / reps * 1e3, e[0]))
+    out.append("o=%%d v=%%d plain %%.3f ms  E=%%.12e" %% (o, v, (time.perf_counter() - t0) / reps * 1e3, e[0]))
+    e = eng.do_ccsd_t_spatial()
+    t0 = time.perf_counter()
+    for r in range(reps): e = eng.do_ccsd_t_spatial()
+    out.append("full %%.3f ms" %% ((time.perf_counter() - t0) / reps * 1e3))
 print("  ".join(out))
 eng.close()
 ''' % ROOT
