@@ -123,8 +123,15 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t x)
     const int lo = __builtin_amdgcn_readfirstlane((int)x), hi = __builtin_amdgcn_readfirstlane((int)(x >> 32));
     return ((int64_t)hi << 32) | (unsigned)lo;
 }
+// (the round trip through the global address space tells the compiler what a pointer read from memory cannot: loads
+// through it are global_load, not flat_load -- a flat load also counts on lgkmcnt, so every wait for LDS fragments would
+// wait for the table fetch as well)
 template <typename T>
-__device__ __forceinline__ const T* uniform_ptr(const T* p) { return reinterpret_cast<const T*>(uniform_i64(reinterpret_cast<int64_t>(p))); }
+__device__ __forceinline__ const T* uniform_ptr(const T* p)
+{
+    typedef const T __attribute__((address_space(1)))* gptr;
+    return (const T*)reinterpret_cast<gptr>(uniform_i64(reinterpret_cast<int64_t>(p)));
+}
 
 struct GettKernelArgs {
     GettProblem p;
