@@ -212,7 +212,8 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             roof["frac"] = roof["achieved"] / roof["peak"]
             roof["traffic"] = None
             roof["kernel"] = ("gett_kernel<..., GRP = true>, the grouped (T) launches (one per chunk): Y(a;b,c|i;jk) = sum over "
-                              "kappa = [d + l ; d + l] of tt(kappa;a,.)*vt(kappa;b,c,.), K = 2(v+o)")
+                              "kappa = [d + l ; d + l] of tt(kappa;a,.)*vt(kappa;b,c,.), K = 2(v+o); "
+                              "pairs j == k in a second launch per chunk over K = v+o (the orbit kernel adds the transpose)")
             roof["launches"] = prof["gemm_launches"]
             roof["ms_per_launch"] = prof["gemm_ms"] / nl
             roof["flop_per_launch"] = prof["gemm_flop"] / nl

@@ -6,7 +6,7 @@ wl, fdir, wdir, outp = sys.argv[1:5]
 def avg(d, counter):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if "gett_kernel" in r["Kernel_Name"] and ", true>" in r["Kernel_Name"] and r["Counter_Name"] == counter]   # GRP = true: the grouped (T) launches
+            if "gett_kernel" in r["Kernel_Name"] and ", true, false>" in r["Kernel_Name"] and r["Counter_Name"] == counter]   # <..., GRP = true, RAG = false>: the grouped (T) launches
     return sum(vals) / len(vals), len(vals)
 fetch, nf = avg(fdir, "FETCH_SIZE")
 write, nw = avg(wdir, "WRITE_SIZE")
@@ -14,7 +14,7 @@ try:
     out = json.load(open(outp))
 except Exception:
     out = {}
-out[wl + "_t_gemm"] = {"kernel": "gett_kernel<..., GRP = true> (the grouped (T) GEMM launches, one per chunk)", "dispatches": nf,
+out[wl + "_t_gemm"] = {"kernel": "gett_kernel<..., GRP = true> (the grouped (T) GEMM launches, one or two per chunk)", "dispatches": nf,
                        "fetch_bytes_per_launch": fetch * 1024 * 2, "write_bytes_per_launch": write * 1024,
                        "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
                        "correction": "FETCH_SIZE [KB] x1024 x2 (gfx950 counts 128-B requests as 64 B; verified on an 8 B/lane stream of known size, r01_pmc_*), WRITE_SIZE [KB] x1024",

@@ -18,12 +18,6 @@ python3 $R/tools/summarize_profile.py /tmp/kt_def > $O/${TAG}_bench_default_kern
 python3 $R/tools/summarize_profile.py /tmp/kt_cfg5 > $O/${TAG}_bench_cfg5_kernels.json
 python3 $R/tools/small_system_gaps.py /tmp/kt_def 600 > $O/${TAG}_bench_default_gaps.txt
 echo "== PMC passes (one counter per pass)"; date
-for wl in cfg5 h2o_tz; do
-  for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES; do
-    rocprofv3 --kernel-trace --output-format csv --pmc $c -d /tmp/pmc_${wl}_$c -- python3 $R/bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $O/pmc_${wl}_$c.log 2>&1 || exit 1
-    python3 $R/tools/summarize_profile.py /tmp/pmc_${wl}_$c > $O/${TAG}_pmc_${c}_${wl}.json
-  done
-  python3 $R/tools/pmc_bench_traffic.py $wl /tmp/pmc_${wl}_FETCH_SIZE /tmp/pmc_${wl}_WRITE_SIZE $O/${TAG}_traffic.json > /dev/null
-done
+bash $R/tools/refresh_traffic.sh $TAG || exit 1
 date
 echo done
