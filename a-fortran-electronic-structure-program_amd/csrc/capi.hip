@@ -95,8 +95,16 @@ static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body 
         AFESP_HIP(hipGraphLaunch(g.exec, cx.stream));
         return;
     }
-    if (!eligible || g.disabled || ++g.calls < 2) {
+    if (!eligible || g.disabled) {
         body();
+        return;
+    }
+    if (g.calls == 0 || g.epoch != cx.scratch_epoch) {
+        // first call, or cached scratch buffers were dropped since the last one: whatever the body (re)builds or allocates is
+        // done here, outside any capture
+        body();
+        g.calls = 1;
+        g.epoch = cx.scratch_epoch;
         return;
     }
     hipGraph_t graph = nullptr;
