@@ -64,7 +64,7 @@ struct Stager {
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
             int mn = mn0 + T::mn_of(t, r);
-            rowoff[r] = offMN[mn < MN ? mn : MN - W];   // (W = 2: MN is even, so MN - 2 is the last group)
+            rowoff[r] = offMN[mn < MN ? mn : MN - (KC ? 1 : W)];   // (!KC, W = 2: MN is even, so MN - 2 is the last group)
         }
     }
     // row (or column) offsets of another tile, same operand
@@ -73,7 +73,7 @@ struct Stager {
 #pragma unroll
         for (int r = 0; r < NROW; ++r) {
             int mn = mn0 + T::mn_of(t, r);
-            rowoff[r] = offMN[mn < MN ? mn : MN - W];
+            rowoff[r] = offMN[mn < MN ? mn : MN - (KC ? 1 : W)];
         }
     }
     // offsets of the K step starting at k0 (clamped: always a valid table entry)
@@ -503,7 +503,10 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     if (!force_tm) force_tm = g_force_tm;
     if (!force_tn) force_tn = g_force_tn;
     if (!force_split) force_split = g_force_split;
-    const bool wide = p.wide && g_allow_wide && (p.M % 2 == 0) && (p.N % 2 == 0) && (p.K % 2 == 0) && p.nbatch == 1;
+    // 16-byte staging pairs two elements along an operand's contiguous direction: K for a K-contiguous operand (K even),
+    // otherwise its row / column index (M or N even)
+    const bool wide = p.wide && g_allow_wide && (p.a_kcontig || p.M % 2 == 0) && (p.b_kcontig || p.N % 2 == 0) && (p.K % 2 == 0) &&
+                      p.nbatch == 1;
     int tm = force_tm ? force_tm : pick_t(p.M), tn = force_tn ? force_tn : pick_t(p.N);
     // tall problems with 16-byte staging: the 256x128 tile (8 waves, 4x4 MFMA grid per wave) halves the staging
     // instructions per MFMA once more (62 TF against 55 TF for 128x128 on the o^3 v^3 ring contraction at o=20, v=200)
@@ -594,7 +597,7 @@ hipError_t gett_launch_grouped(const GettProblem& p, const GettGroup* dev_groups
     if (p.nbatch != 1 || !p.a_kcontig || !p.b_kcontig || p.K % BK != 0) return hipErrorInvalidValue;
     GettKernelArgs a;
     a.p = p;
-    const bool wide = p.wide && g_allow_wide && (p.M % 2 == 0) && (p.K % 2 == 0);
+    const bool wide = p.wide && g_allow_wide && (p.K % 2 == 0);   // (both operands are K-contiguous here: M, N of any parity)
     int tm, tn, BM, BN;
     gett_grouped_tile(p.M, wide, &tm, &tn, &BM, &BN);
     a.mtiles = (p.M + BM - 1) / BM;

@@ -328,7 +328,7 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
     std::vector<TripleMeta> metas;
     int64_t flat = 0, max_blocks = 1;
     int tm, tn, BM, BN;
-    gett_grouped_tile((int)v2, (Kc % 2 == 0) && (V % 2 == 0), &tm, &tn, &BM, &BN);
+    gett_grouped_tile((int)v2, true, &tm, &tn, &BM, &BN);
     const int mtiles = (int)((v2 + BM - 1) / BM);
     const char* split_env = getenv("AFESP_T_SPLIT_TILES");   // test / tuning knob, read when a plan is built
     const int64_t split_min_tiles = split_env ? atoll(split_env) : 1024;
@@ -519,9 +519,9 @@ static double fused_range_cost(int o, int v, int sb, int64_t b, int64_t e, int B
 // the tuning environment only).
 void triples_shard_bounds(int o, int v, bool cr, int world, int64_t* bounds)
 {
-    const int64_t V = v, O = o, Kc = (V + O + 15) / 16 * 16, nt = triples_count(o);
+    const int64_t V = v, nt = triples_count(o);
     int tm, tn, BM, BN;
-    gett_grouped_tile((int)(V * V), (Kc % 2 == 0) && (V % 2 == 0), &tm, &tn, &BM, &BN);
+    gett_grouped_tile((int)(V * V), true, &tm, &tn, &BM, &BN);
     const int sb = fused_block_size(o, v, cr, device_pool_budget());
     const char* split_env = getenv("AFESP_T_SPLIT_TILES");
     const int64_t split_min_tiles = split_env ? atoll(split_env) : 1024;
@@ -633,7 +633,8 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             gp.alpha = 1.0; gp.beta = 0.0;
             gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
             gp.a_kcontig = gp.b_kcontig = true;
-            gp.wide = (Kc % 2 == 0) && (V % 2 == 0);   // then every row/column/K offset and shift is even
+            gp.wide = true;   // both operands are contiguous along kappa and Kc is a multiple of 16: every row, column and K
+                              // offset and every group shift is even, whatever the parity of v
             GettProblem gm = gp;
             gm.A = vt2.d;
             gm.B = tt2.d;
@@ -770,7 +771,7 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
             gp.alpha = 1.0; gp.beta = 0.0;
             gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
             gp.a_kcontig = gp.b_kcontig = true;
-            gp.wide = (V % 2 == 0);
+            gp.wide = true;   // (as in the spin-free plan: K-contiguous operands, Kc a multiple of 16)
             AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
         }
         hipLaunchKernelGGL(triples_so_orbit_kernel, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,
