@@ -32,6 +32,16 @@ __host__ __device__ constexpr int sig(int s, int d)
     return s == 0 ? d : s == 1 ? (d == 0 ? 1 : d == 1 ? 0 : 2) : s == 2 ? 2 - d : s == 3 ? (d == 0 ? 0 : d == 1 ? 2 : 1)
                       : s == 4 ? (d + 1) % 3 : (d + 2) % 3;
 }
+// 1/x for the energy denominators (sums of orbital-energy differences: finite, far from the ends of the exponent range):
+// v_rcp_f64 and two Newton steps, 5 instructions against the ~25 of an IEEE division with its scaling and fix-up -- the orbit
+// kernels are bound by instruction issue (~1800 per thread and item), not by HBM.  Relative error ~1e-16.
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
 // XOR-swizzled cube image: any one coordinate may run along the lanes without bank conflicts
 __device__ __forceinline__ int cidx(int p0, int p1, int p2) { return ((p0 ^ p1 ^ p2) & 7) | (p1 << 3) | (p2 << 6); }
 
@@ -63,7 +73,7 @@ __global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(doub
 {
     constexpr bool ALIAS = !WANT_D;
     // X cubes of one term; later the V / T2 patches and t1 rows (ALIAS: W, then the V patches and t1 rows)
-    __shared__ __attribute__((aligned(16))) double stage[ALIAS ? 6 * CUBE + 27 * PATCH + 72 : 6 * CUBE + 512];
+    __shared__ __attribute__((aligned(16))) double stage[ALIAS ? 6 * CUBE + 27 * PATCH + 96 : 6 * CUBE + 512];
     __shared__ double wl_own[ALIAS ? 1 : 6 * CUBE];
     double* const wl = ALIAS ? stage : wl_own;   // W on the six cubes of the orbit
     __shared__ int srcq[6][6];                 // srcq[s][q]: which cube of the orbit is sigma_s applied to cube q
@@ -150,6 +160,9 @@ __global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(doub
     double* vp = ALIAS ? stage + 6 * CUBE : stage;   // 3*9*64
     double* tp = stage + 27 * PATCH;                 // 3*9*64 (WANT_D only)
     double* t1r = ALIAS ? stage + 6 * CUBE + 27 * PATCH : stage + 54 * PATCH;   // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l)
+    double* evl = t1r + 72;              // evl[slot][l] = e(o + tile[slot]*8 + l): virtual orbital energies of the three tiles
+                                         // (LDS is granted in 1280-byte steps: an array of its own cost the full variant its
+                                         // third workgroup per CU)
     const int occ[3] = {m.i, m.j, m.k};
     const int pairp[3] = {m.j, m.i, m.i}, pairq[3] = {m.k, m.k, m.j};
     for (int el = t; el < 27 * PATCH; el += 256) {
@@ -167,6 +180,9 @@ __global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(doub
     if (t < 72) {
         const int oc = t / 24, sl = (t / 8) % 3, l = t & 7, g = tile[sl] * TT + l;
         t1r[t] = g < v ? in.t1[occ[oc] + o * g] : 0.0;
+    } else if (t < 96) {
+        const int sl = (t - 72) / 8, l = t & 7, g = tile[sl] * TT + l;
+        evl[t - 72] = in.e[(g < v ? g : 0) + o];
     }
     __syncthreads();
     const double eo = in.e[m.i] + in.e[m.j] + in.e[m.k];
@@ -189,25 +205,26 @@ __global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(doub
             const int l[3] = {l0, l1, l2h[h]};
             const int ga = ta * TT + l[0], gb = tb * TT + l[1], gc = tc * TT + l[2];
             const bool live = ga < v && gb < v && gc < v;
-            const double D = eo - in.e[(ga < v ? ga : 0) + o] - in.e[(gb < v ? gb : 0) + o] - in.e[(gc < v ? gc : 0) + o];
+            const double D = eo - evl[sa * TT + l[0]] - evl[sb * TT + l[1]] - evl[sc * TT + l[2]];
 #define WAT(s) wl[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])]
             const double w = wl[q * CUBE + cidx(l[0], l[1], l[2])];
-            const double wb = (4.0 * w + WAT(4) + WAT(5) - 2.0 * (WAT(3) + WAT(1) + WAT(2))) / 3.0;
+            const double wb = 4.0 * w + WAT(4) + WAT(5) - 2.0 * (WAT(3) + WAT(1) + WAT(2));   // 3 x the bar of ccsd.f90:2314-2318
+            const double r3D = rcp_nr(3.0 * D);
             // Z(x,y,z) = t1(i,x) V_jk(y,z) + t1(j,y) V_ik(x,z) + t1(k,z) V_ij(x,y)      ccsd.f90:2178-2179 (numerator)
 #define T1R(oc, d) t1r[(oc) * 24 + slot[d] * 8 + l[d]]
 #define VP(arr, pr, dx, dy) arr[((pr) * 9 + slot[dx] * 3 + slot[dy]) * PATCH + l[dx] + TT * l[dy]]
 #define ZAT(x, y, z) (T1R(0, x) * VP(vp, 0, y, z) + T1R(1, y) * VP(vp, 1, x, z) + T1R(2, z) * VP(vp, 2, x, y))
-            const double tbar = live ? wb / D : 0.0;
+            const double tbar = live ? wb * r3D : 0.0;
             acc[0] += tbar * w;
             if (!WANT_D) {
                 acc[1] += tbar * ZAT(0, 1, 2);
                 continue;
             }
-            const double zb = (4.0 * ZAT(0, 1, 2) + ZAT(1, 2, 0) + ZAT(2, 0, 1) - 2.0 * (ZAT(0, 2, 1) + ZAT(1, 0, 2) + ZAT(2, 1, 0))) / 3.0;
+            const double zb = 4.0 * ZAT(0, 1, 2) + ZAT(1, 2, 0) + ZAT(2, 0, 1) - 2.0 * (ZAT(0, 2, 1) + ZAT(1, 0, 2) + ZAT(2, 1, 0));
             // y (ccsd.f90:2183-2184)
             const double y = T1R(0, 0) * T1R(1, 1) * T1R(2, 2) + T1R(0, 0) * VP(tp, 0, 1, 2) + T1R(1, 1) * VP(tp, 1, 0, 2) +
                              T1R(2, 2) * VP(tp, 2, 0, 1);
-            const double zbar = live ? zb / D : 0.0;
+            const double zbar = live ? zb * r3D : 0.0;
             acc[1] += zbar * w;
             acc[2] += tbar * y;
             acc[3] += zbar * y;
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(256, 3) void triples_so_orbit_kernel(double* __rest
 {
     __shared__ __attribute__((aligned(16))) double wl[6 * CUBE];   // R on the six cubes of the orbit
     __shared__ double vp[27 * PATCH];                              // <pq||xy> patches for pairs (j,k), (i,k), (i,j)
-    __shared__ double t1r[72];                                     // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l)
+    __shared__ double t1r[96];                                     // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l); then evl
     __shared__ int srcq[6][6];
     __shared__ int dup[6];
     __shared__ double red[4];
@@ -303,7 +320,11 @@ __global__ __launch_bounds__(256, 3) void triples_so_orbit_kernel(double* __rest
     if (t < 72) {
         const int oc = t / 24, sl = (t / 8) % 3, l = t & 7, g = tile[sl] * TT + l;
         t1r[t] = g < v ? in.t1[occ[oc] + o * g] : 0.0;
+    } else if (t < 96) {
+        const int sl = (t - 72) / 8, l = t & 7, g = tile[sl] * TT + l;
+        t1r[t] = in.e[(g < v ? g : 0) + o];
     }
+    const double* evl = t1r + 72;   // evl[slot][l] = e(o + tile[slot]*8 + l)
     __syncthreads();
     const int l0 = t & 7, l1 = (t >> 3) & 7, l2h[2] = {t >> 6, (t >> 6) + 4};
     const double eo = in.e[m.i] + in.e[m.j] + in.e[m.k];
@@ -321,14 +342,14 @@ __global__ __launch_bounds__(256, 3) void triples_so_orbit_kernel(double* __rest
             const int l[3] = {l0, l1, l2h[h]};
             const int ga = ta * TT + l[0], gb = tb * TT + l[1], gc = tc * TT + l[2];
             const bool live = ga < v && gb < v && gc < v;
-            const double D = eo - in.e[(ga < v ? ga : 0) + o] - in.e[(gb < v ? gb : 0) + o] - in.e[(gc < v ? gc : 0) + o];
+            const double D = eo - evl[sa * TT + l[0]] - evl[sb * TT + l[1]] - evl[sc * TT + l[2]];
 #define WAT(s) wl[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])]
 #define T1R(oc, d) t1r[(oc) * 24 + slot[d] * 8 + l[d]]
 #define VP(pr, dx, dy) vp[((pr) * 9 + slot[dx] * 3 + slot[dy]) * PATCH + l[dx] + TT * l[dy]]
 #define RAW(x, y, z) (T1R(0, x) * VP(0, y, z) - T1R(1, x) * VP(1, y, z) + T1R(2, x) * VP(2, y, z))
             const double t3c = wl[q * CUBE + cidx(l[0], l[1], l[2])] - WAT(1) - WAT(2);
             const double t3d = RAW(0, 1, 2) - RAW(1, 0, 2) - RAW(2, 1, 0);
-            acc += live ? t3c * (t3c + t3d) / D : 0.0;
+            acc += live ? t3c * (t3c + t3d) * rcp_nr(D) : 0.0;
 #undef WAT
 #undef T1R
 #undef VP
