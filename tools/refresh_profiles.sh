@@ -3,7 +3,7 @@
 # and are copied to profiles/ afterwards).  usage: tools/refresh_profiles.sh r01
 set -o pipefail
 TAG=${1:-r01}
-R=$PWD
+R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
