@@ -115,6 +115,10 @@ void k_asym_c(Context& cx, double* asym, double* c, const double* t1, const doub
 void k_t2_update(Context& cx, double* t2, const double* r2, const double* v_oovv, const double* D2, const double* pp, int o, int v);
 void k_r2_full(Context& cx, double* out, const double* r2, const double* pp, int o, int v);
 void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v);
+// symmetric / antisymmetric operands of the pp-ladder (pairs x <= y indexed y(y+1)/2 + x, pairs x < y indexed y(y-1)/2 + x)
+void k_vvvv_sympack(Context& cx, double* vs, double* va, const double* vvvv, int v, int64_t ks, int64_t ka);
+void k_c_sympack(Context& cx, double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na);
+void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na);
 // out[0] = sum (2 v(ijab) - v(ijba)) (t2 + t1 t1), out[1] = sum (t2 - t2_old)^2 ; then t2_old = t2
 void k_cc_energy(Context& cx, double* out2, const double* v_oovv, const double* t1, const double* t2, double* t2_old,
                  int o, int v);

@@ -28,6 +28,10 @@ struct CCState : DiisRing {
     Tensor D1, D2, t1, t2, t2_old, r1, r2;
     double* pp = nullptr;          // packed particle-particle ladder PP(i,j,p), p over a <= b
     int64_t* pp_tab = nullptr;     // offset tables of the pp-ladder GEMM: [Am | k | Bk | n]
+    // symmetric / antisymmetric form (large systems): V+-(ef,ab) built at init, c+-(ij,ef) and the two products per iteration
+    bool pp_sym = false;
+    double *pp_vs = nullptr, *pp_va = nullptr, *pp_cs = nullptr, *pp_ca = nullptr, *pp_ps = nullptr, *pp_pa = nullptr;
+    int64_t pp_ks = 0, pp_ka = 0, pp_ns = 0, pp_na = 0, pp_kn = 0;   // even leading dimensions of those operands
     Tensor I_vo, I_vv, I_oo_p, I_oo, c, asym, x_voov, I_oooo, I_ovov, I_voov, I_vovv_p, I_ooov_p;
     double energy = 0.0, energy_old = 0.0, rms = 0.0;
     void* tplan = nullptr;      // cached (T) launch plan (triples.hip)
@@ -43,6 +47,7 @@ void ccsd_diis_save(Context& cx, CCState& s);
 void ccsd_intermediates(Context& cx, CCState& s);
 void ccsd_amplitudes(Context& cx, CCState& s);
 void ccsd_pp_ladder(Context& cx, CCState& s);
+bool pp_sym_pays(int64_t o, int64_t v);   // whether ccsd_init chooses the split form (AFESP_PP_SYM=0/1 overrides)
 // updates s.energy / s.energy_old / s.rms (un-rooted, as ccsd.f90:1806); returns 1 if converged
 int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol);
 void ccsd_diis_update(Context& cx, CCState& s);

@@ -8,6 +8,7 @@
 // :1089,:1101-1126; here the three "2x - x^T" companions are built once at init).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "ccsd.h"
@@ -50,21 +51,43 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     s.c = cx.tensor({O, O, V, V}); s.asym = cx.tensor({O, O, V, V}); s.x_voov = cx.tensor({V, O, O, V});
     s.I_oooo = cx.tensor({O, O, O, O}); s.I_ovov = cx.tensor({O, V, O, V}); s.I_voov = cx.tensor({V, O, O, V});
     s.I_vovv_p = cx.tensor({V, O, V, V}); s.I_ooov_p = cx.tensor({O, O, O, V});
-    // pp-ladder (ccsd.f90:1669) over the symmetry-unique column pairs a <= b: rows p of <ef|ab> viewed as [ef x ab]
+    // pp-ladder (ccsd.f90:1669) over the symmetry-unique column pairs a <= b
     {
         const int64_t np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
+        s.pp = cx.alloc(N2 * np);
+        s.pp_sym = pp_sym_pays(O, V);
         std::vector<int64_t> tab;
-        tab.reserve((size_t)(np + 2 * K2 + N2));
-        for (int64_t b = 0; b < V; ++b)
-            for (int64_t a = 0; a <= b; ++a) tab.push_back((a + V * b) * K2);     // offAm[p]: column (a,b) of v_vvvv
-        for (int64_t k = 0; k < K2; ++k) tab.push_back(k);                        // offAk[(e,f)]
-        for (int64_t k = 0; k < K2; ++k) tab.push_back(N2 * k);                   // offBk[(e,f)] in c(i,j,e,f)
-        for (int64_t x = 0; x < N2; ++x) tab.push_back(x);                        // offBn = offCn[(i,j)]
-        for (int64_t pz = 0; pz < np; ++pz) tab.push_back(N2 * pz);               // offCm[p] in PP(i,j,p)
+        if (!s.pp_sym) {
+            // rows p of <ef|ab> viewed as [ef x ab], all (i,j) columns
+            tab.reserve((size_t)(np + 2 * K2 + N2));
+            for (int64_t b = 0; b < V; ++b)
+                for (int64_t a = 0; a <= b; ++a) tab.push_back((a + V * b) * K2);     // offAm[p]: column (a,b) of v_vvvv
+            for (int64_t k = 0; k < K2; ++k) tab.push_back(k);                        // offAk[(e,f)]
+            for (int64_t k = 0; k < K2; ++k) tab.push_back(N2 * k);                   // offBk[(e,f)] in c(i,j,e,f)
+            for (int64_t x = 0; x < N2; ++x) tab.push_back(x);                        // offBn = offCn[(i,j)]
+            for (int64_t pz = 0; pz < np; ++pz) tab.push_back(N2 * pz);               // offCm[p] in PP(i,j,p)
+        } else {
+            // symmetric + antisymmetric halves (see ccsd_pp_ladder): dense operands with even leading dimensions, so the
+            // 16-byte staging applies whatever the parity of o and v
+            auto even = [](int64_t x) { return (x + 1) & ~(int64_t)1; };
+            const int64_t npa = V * (V - 1) / 2, ks = even(np), ka = even(npa), ns = even(O * (O + 1) / 2), na = even(O * (O - 1) / 2);
+            s.pp_ks = ks; s.pp_ka = ka; s.pp_ns = ns; s.pp_na = na;
+            s.pp_vs = cx.alloc(ks * np); s.pp_cs = cx.alloc(ns * ks); s.pp_ps = cx.alloc(ns * np);
+            if (npa > 0 && na > 0) { s.pp_va = cx.alloc(ka * npa); s.pp_ca = cx.alloc(na * ka); s.pp_pa = cx.alloc(na * npa); }
+            k_vvvv_sympack(cx, s.pp_vs, s.pp_va, s.v_vvvv.d, v, ks, ka);
+            // [ x (k or n) | ks*m | ka*m | ns*k | na*k | ns*m | na*m ]: entries beyond the antisymmetric extents unused
+            s.pp_kn = std::max(ks, ns);
+            for (int64_t k = 0; k < s.pp_kn; ++k) tab.push_back(k);
+            for (int64_t m = 0; m < np; ++m) tab.push_back(ks * m);
+            for (int64_t m = 0; m < np; ++m) tab.push_back(ka * m);
+            for (int64_t k = 0; k < ks; ++k) tab.push_back(ns * k);
+            for (int64_t k = 0; k < ks; ++k) tab.push_back(na * k);
+            for (int64_t m = 0; m < np; ++m) tab.push_back(ns * m);
+            for (int64_t m = 0; m < np; ++m) tab.push_back(na * m);
+        }
         s.pp_tab = cx.alloc_i64((int64_t)tab.size());
         AFESP_HIP(hipMemcpyAsync(s.pp_tab, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
         cx.sync();
-        s.pp = cx.alloc(N2 * np);
     }
     // ccsd.f90:520-521: t1 = 0, t2 = v_oovv / D
     k_div(cx, s.t2.d, s.v_oovv.d, s.D2.d, o2v2);
@@ -81,7 +104,8 @@ void ccsd_free(Context& cx, CCState& s)
     double* bufs[] = {s.e, s.v_oovv.d, s.v_ovov.d, s.v_vvov.d, s.v_oovo.d, s.v_oooo.d, s.v_vvvv.d, s.w_oovv.d, s.w_vvov.d,
                       s.w_oovo.d, s.D1.d, s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.I_vo.d, s.I_vv.d, s.I_oo_p.d, s.I_oo.d, s.c.d,
                       s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_vovv_p.d, s.I_ooov_p.d, s.amp_s, s.hist_t,
-                      s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d, s.pp, (double*)s.pp_tab};
+                      s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d, s.pp, (double*)s.pp_tab, s.pp_vs, s.pp_va, s.pp_cs,
+                      s.pp_ca, s.pp_ps, s.pp_pa};
     for (double* b : bufs) cx.release(b);
     cx.drop_scratch();
     triples_plan_free(s);
@@ -181,21 +205,58 @@ void ccsd_intermediates(Context& cx, CCState& s)
 }
 
 // Particle-particle ladder (src/ccsd.f90:1669), the O(o^2 v^4) term.  pp(ijab) = sum_ef c(ij,ef) <ef|ab> obeys
-// pp(ijab) = pp(jiba), so only the v(v+1)/2 column pairs a <= b are contracted (half the flops of the reference's dgemm);
-// the packed result PP(ij,p) enters the amplitude update directly (t2_update_kernel) instead of being accumulated into r2.
+// pp(ijab) = pp(jiba), so only the v(v+1)/2 column pairs a <= b are needed; the packed result PP(ij,p) enters the amplitude
+// update directly (t2_update_kernel) instead of being accumulated into r2.
+//
+// Large systems split it once more (Scuseria, Janssen, Schaefer 1988): with c+- = c(ijef) +- c(ijfe) and
+// V+- = <ef|ab> +- <fe|ab>, both (anti)symmetric under e <-> f, under i <-> j resp. a <-> b,
+//   pp(ijab) = sum_{e<=f}' 1/2 c+ V+  +  sum_{e<f} 1/2 c- V-  =  Ps(ij,ab) + Pa(ij,ab),    pp(jiab) = Ps - Pa   (i <= j, a <= b),
+// two products over pair indices only -- [o(o+1)/2] x [v(v+1)/2]^2 and [o(o-1)/2] x [v(v-1)/2]^2, a quarter of the
+// reference's dgemm.  V+- are built once (the integrals are immutable), c+- per iteration.
+static int tile_cols(int64_t n) { return n <= 32 ? 32 : n <= 64 ? 64 : (int)((n + 127) / 128 * 128); }
+bool pp_sym_pays(int64_t O, int64_t V)
+{
+    if (const char* e = getenv("AFESP_PP_SYM")) return e[0] == '1';
+    // the split pays when it still halves the work after padding the o-pair extents to whole column tiles
+    const double plain = (double)tile_cols(O * O) * (double)(V * V) * (double)(V * (V + 1) / 2);
+    const double split = (double)tile_cols(O * (O + 1) / 2) * (double)(V * (V + 1) / 2) * (double)(V * (V + 1) / 2) +
+                         (double)tile_cols(O * (O - 1) / 2) * (double)(V * (V - 1) / 2) * (double)(V * (V - 1) / 2);
+    return plain > 1.5 * split;
+}
+
 void ccsd_pp_ladder(Context& cx, CCState& s)
 {
     const int64_t O = s.o, V = s.v, np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
     GettProblem gp;
-    gp.A = s.v_vvvv.d; gp.B = s.c.d; gp.C = s.pp;
-    gp.offAm = s.pp_tab; gp.offAk = s.pp_tab + np; gp.offBk = s.pp_tab + np + K2; gp.offBn = s.pp_tab + np + 2 * K2;
-    gp.offCm = s.pp_tab + np + 2 * K2 + N2; gp.offCn = gp.offBn;
-    gp.M = (int)np; gp.N = (int)N2; gp.K = (int)K2;
     gp.alpha = 1.0; gp.beta = 0.0;
     gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
     gp.a_kcontig = true; gp.b_kcontig = false;
-    gp.wide = (O % 2 == 0) && (V % 2 == 0) && (np % 2 == 0);
+    if (!s.pp_sym) {
+        gp.A = s.v_vvvv.d; gp.B = s.c.d; gp.C = s.pp;
+        gp.offAm = s.pp_tab; gp.offAk = s.pp_tab + np; gp.offBk = s.pp_tab + np + K2; gp.offBn = s.pp_tab + np + 2 * K2;
+        gp.offCm = s.pp_tab + np + 2 * K2 + N2; gp.offCn = gp.offBn;
+        gp.M = (int)np; gp.N = (int)N2; gp.K = (int)K2;
+        gp.wide = (O % 2 == 0) && (V % 2 == 0) && (np % 2 == 0);
+        AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+        return;
+    }
+    const int64_t npa = V * (V - 1) / 2, ks = s.pp_ks, ka = s.pp_ka, ns = s.pp_ns, na = s.pp_na;
+    const int64_t* t = s.pp_tab;
+    const int64_t* u = t + s.pp_kn;   // [ ks*m | ka*m | ns*k | na*k | ns*m | na*m ]
+    k_c_sympack(cx, s.pp_cs, s.pp_ca, s.c.d, s.o, s.v, ns, na);
+    gp.wide = true;
+    gp.offAk = t; gp.offBn = gp.offCn = t;
+    gp.A = s.pp_vs; gp.B = s.pp_cs; gp.C = s.pp_ps;
+    gp.offAm = u; gp.offBk = u + 2 * np; gp.offCm = u + 2 * np + 2 * ks;
+    gp.M = (int)np; gp.N = (int)ns; gp.K = (int)ks;
     AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+    if (s.pp_pa) {
+        gp.A = s.pp_va; gp.B = s.pp_ca; gp.C = s.pp_pa;
+        gp.offAm = u + np; gp.offBk = u + 2 * np + ks; gp.offCm = u + 3 * np + 2 * ks;
+        gp.M = (int)npa; gp.N = (int)na; gp.K = (int)ka;
+        AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+    }
+    k_pp_expand(cx, s.pp, s.pp_ps, s.pp_pa, s.o, s.v, ns, na);
 }
 
 void ccsd_amplitudes(Context& cx, CCState& s)

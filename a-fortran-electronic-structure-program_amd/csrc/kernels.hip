@@ -309,6 +309,84 @@ void k_r2_full(Context& cx, double* out, const double* r2, const double* pp, int
 {
     LAUNCH(r2_full_kernel, dim3(grid_for((int64_t)o * o * v * v)), out, r2, pp, o, v);
 }
+// ---- symmetric / antisymmetric form of the particle-particle ladder (ccsd.hip, ccsd_pp_ladder)
+// pair index of x <= y: y(y+1)/2 + x; inverse of it
+__device__ __forceinline__ void unpair(int64_t p, int& lo, int& hi)
+{
+    int64_t h = (int64_t)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while (h * (h + 1) / 2 > p) --h;
+    while ((h + 1) * (h + 2) / 2 <= p) ++h;
+    hi = (int)h;
+    lo = (int)(p - h * (h + 1) / 2);
+}
+// Vs(ef,ab) = 1/2 (<ef|ab> + <fe|ab>) (x 1/2 on e == f) over e <= f, a <= b;  Va(ef,ab) = 1/2 (<ef|ab> - <fe|ab>) over
+// e < f, a < b.  Columns (a,b) have leading dimensions ks / ka; built once per calculation.
+__global__ void vvvv_sympack_kernel(double* vs, double* va, const double* vvvv, int v, int64_t ks, int64_t ka)
+{
+    const int64_t V = v, nps = V * (V + 1) / 2, n = V * V * nps;
+    GRID_STRIDE(x, n)
+    {
+        const int e = (int)(x % V), f = (int)((x / V) % V);
+        if (e > f) continue;
+        const int64_t mp = x / (V * V);
+        int a, b;
+        unpair(mp, a, b);
+        const int64_t col = V * V * (a + V * b);
+        const double p = vvvv[e + V * f + col], q = vvvv[f + V * e + col];
+        vs[(int64_t)f * (f + 1) / 2 + e + ks * mp] = (e == f ? 0.25 : 0.5) * (p + q);
+        if (va && e < f && a < b) va[(int64_t)f * (f - 1) / 2 + e + ka * ((int64_t)b * (b - 1) / 2 + a)] = 0.5 * (p - q);
+    }
+}
+// cs(ij,ef) = c(ijef) + c(ijfe) over i <= j, e <= f;  ca(ij,ef) = c(ijef) - c(ijfe) over i < j, e < f; leading dimensions ns / na
+__global__ void c_sympack_kernel(double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na)
+{
+    const int64_t O = o, V = v, n = O * O * V * V;
+    GRID_STRIDE(x, n)
+    {
+        const int i = (int)(x % O);
+        int64_t r = x / O;
+        const int j = (int)(r % O);
+        r /= O;
+        const int e = (int)(r % V), f = (int)(r / V);
+        if (i > j || e > f) continue;
+        const double p = c[x], q = c[i + O * (j + O * (f + V * e))];
+        cs[(int64_t)j * (j + 1) / 2 + i + ns * ((int64_t)f * (f + 1) / 2 + e)] = p + q;
+        if (ca && i < j && e < f) ca[(int64_t)j * (j - 1) / 2 + i + na * ((int64_t)f * (f - 1) / 2 + e)] = p - q;
+    }
+}
+// PP(i,j,p) = Ps(ij,p) +/- Pa(ij,p): + for i < j, - for i > j (p over a <= b; Pa vanishes on i == j and on a == b)
+__global__ void pp_expand_kernel(double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na)
+{
+    const int64_t O = o, V = v, n = O * O * (V * (V + 1) / 2);
+    GRID_STRIDE(x, n)
+    {
+        const int i = (int)(x % O), j = (int)((x / O) % O);
+        const int64_t p = x / (O * O);
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        double val = ps[(int64_t)hi * (hi + 1) / 2 + lo + ns * p];
+        if (i != j) {
+            int a, b;
+            unpair(p, a, b);
+            if (a != b) {
+                const double w = pa[(int64_t)hi * (hi - 1) / 2 + lo + na * ((int64_t)b * (b - 1) / 2 + a)];
+                val += i < j ? w : -w;
+            }
+        }
+        pp[x] = val;
+    }
+}
+void k_vvvv_sympack(Context& cx, double* vs, double* va, const double* vvvv, int v, int64_t ks, int64_t ka)
+{
+    LAUNCH(vvvv_sympack_kernel, dim3(grid_for((int64_t)v * v * ((int64_t)v * (v + 1) / 2), 65536)), vs, va, vvvv, v, ks, ka);
+}
+void k_c_sympack(Context& cx, double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na)
+{
+    LAUNCH(c_sympack_kernel, dim3(grid_for((int64_t)o * o * v * v)), cs, ca, c, o, v, ns, na);
+}
+void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na)
+{
+    LAUNCH(pp_expand_kernel, dim3(grid_for((int64_t)o * o * ((int64_t)v * (v + 1) / 2))), pp, ps, pa, o, v, ns, na);
+}
 void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v)
 {
     LAUNCH(denominators_kernel, dim3(grid_for((int64_t)o * o * v * v)), D1, D2, e, o, v);

@@ -93,7 +93,7 @@ def test_one_iteration_term_by_term(eng, o, v):
     """Every intermediate and both residuals after one update from non-trivial amplitudes (t1 != 0).  The second size is
     the largest the oracle does in seconds and is past the thresholds where the launcher switches to the kernels config 5
     runs on: 256x128 / 128x128 tiles with 16-byte staging, K slicing by the wave-quantisation score, re-laid-out operands,
-    the pp-ladder over a<=b pairs with M = v(v+1)/2 = 2628 rows."""
+    the pp-ladder in its symmetric/antisymmetric pair form with M = v(v+1)/2 = 2628 rows."""
     if o * v > 100:
         from afesp_amd import inputs
         n = o + v
@@ -121,6 +121,34 @@ def test_one_iteration_term_by_term(eng, o, v):
         assert np.max(np.abs(eng.tensor(name) - cc.field(name))) < tol, name
     g1, g2 = eng.amplitudes()
     assert np.max(np.abs(g1 - cc.t1)) < tol and np.max(np.abs(g2 - cc.t2)) < tol
+
+
+@pytest.mark.parametrize("o,v", [(1, 3), (2, 2), (3, 8), (6, 4), (5, 9), (2, 17), (7, 21), (9, 2)])
+def test_pp_ladder_split_form_on_ragged_extents(eng, o, v, monkeypatch):
+    """The symmetric/antisymmetric pair form of the particle-particle ladder (chosen by itself from about o = 10, v = 70 on;
+    forced here) on shapes with a single occupied orbital (no antisymmetric part), o > v, odd pair counts."""
+    monkeypatch.setenv("AFESP_PP_SYM", "1")
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05, seed=o * 100 + v)
+    cc = orc.OracleCC(o, v, eri, e, 3)
+    eng.ccsd_init(o, v, e, eri, 3)
+    rng = np.random.default_rng(o + 31 * v)
+    t1 = 0.05 * rng.standard_normal((o, v))
+    t2 = 0.05 * rng.standard_normal((o, o, v, v))
+    t2 = 0.5 * (t2 + t2.transpose(1, 0, 3, 2))
+    cc.t1[...] = t1
+    cc.t2[...] = t2
+    eng.set_amplitudes(t1, t2)
+    cc.L.orc_cc_intermediates(cc.h); cc.L.orc_cc_amplitudes(cc.h)
+    eng.update_intermediates(); eng.update_amplitudes()
+    assert np.max(np.abs(eng.tensor("r2") - cc.field("r2"))) < 1e-12
+    g1, g2 = eng.amplitudes()
+    assert np.max(np.abs(g1 - cc.t1)) < 1e-12 and np.max(np.abs(g2 - cc.t2)) < 1e-12
+    monkeypatch.setenv("AFESP_PP_SYM", "0")
+    eng.ccsd_init(o, v, e, eri, 3)
+    eng.set_amplitudes(t1, t2)
+    eng.update_intermediates(); eng.update_amplitudes()
+    h1, h2 = eng.amplitudes()
+    assert np.max(np.abs(h2 - g2)) < 1e-13
 
 
 def test_h2o_tz_shape_synthetic(eng):
