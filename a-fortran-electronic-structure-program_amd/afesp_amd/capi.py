@@ -78,6 +78,8 @@ def load_library():
                                  _dp, C.c_char_p, C.POINTER(i64), C.c_int, C.c_int, C.c_int]
     L.afesp_synthetic_init.argtypes = [C.c_void_p, i64, i64, dbl, C.c_uint64, C.c_int]
     L.afesp_time_pp_ladder.argtypes = [C.c_void_p, C.c_int, C.POINTER(dbl)]
+    L.afesp_synthetic_ao.argtypes = [C.c_void_p, i64, dbl, C.c_uint64]
+    L.afesp_ccsd_pp_ladder_flop.argtypes = [C.c_void_p, C.POINTER(dbl)]
     L.afesp_bench_contract.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(i64), C.c_char_p, C.POINTER(i64), C.c_char_p,
                                        C.POINTER(i64), C.c_int, C.POINTER(dbl)]
     L.afesp_set_tuning.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
@@ -377,6 +379,14 @@ class Engine:
 
     def set_tuning(self, group_m=0, tm=0, tn=0, split=0):
         self.L.afesp_set_tuning(group_m, tm, tn, split)
+
+    def synthetic_ao(self, nbasis, scale=0.02, seed=12345):
+        self._chk(self.L.afesp_synthetic_ao(self.h, nbasis, scale, seed))
+
+    def pp_ladder_flop(self):
+        f = dbl()
+        self._chk(self.L.afesp_ccsd_pp_ladder_flop(self.h, C.byref(f)))
+        return f.value
 
     def time_pp_ladder(self, reps=10):
         ms = dbl()

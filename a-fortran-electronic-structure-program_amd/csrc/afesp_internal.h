@@ -81,6 +81,7 @@ struct Context {
     int64_t prof_gemm_launches = 0, prof_orbit_launches = 0;
 
     double* alloc(int64_t n);             // zero-initialised doubles
+    double* alloc_raw(int64_t n);         // uninitialised (large temporaries that are fully overwritten)
     int64_t* alloc_i64(int64_t n);
     void release(void* p);                // early free of an `owned` buffer
     double* scratch(const std::string& name, int64_t ndoubles);   // cached, uninitialised, grows on demand
@@ -128,8 +129,10 @@ void k_dots(Context& cx, double* out, const double* x, const double* ybase, int6
 void k_lincomb(Context& cx, double* out, const double* xbase, int64_t xstride, const double* coef_dev, int nx,
                int64_t n);      // out = sum_j coef[j] * x_j
 void k_sub(Context& cx, double* out, const double* a, const double* b, int64_t n);
-void k_unpack_eri(Context& cx, double* full, const double* packed, int n);
-void k_pack_eri(Context& cx, double* packed, const double* full, int n);
+// pair-symmetric AO->MO: u(i,j,KL) from the packed array; out(k,l,PQ) = in(q,p,tri(k,l)); packed[tri(PQ,RS)] = full(s,r,PQ)
+void k_unpack_half(Context& cx, double* u, const double* packed, int n);
+void k_pair_transpose(Context& cx, double* out, const double* in, int n);
+void k_pack_pairs(Context& cx, double* packed, const double* full, int n);
 // out(p,q,r,s) = packed[ index( (p+b0)(r+b2) | (q+b1)(s+b3) ) ]  physicist <pq|rs> from packed chemist (pr|qs)
 void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1, int d2, int d3, int b0, int b1, int b2,
                   int b3);

@@ -179,9 +179,8 @@ void afesp_ctx_destroy(afesp_ctx* ctx)
 
 const char* afesp_last_error(const afesp_ctx* ctx) { return ctx ? ctx->cx.last_error.c_str() : "null context"; }
 
-// src/mp2.f90:261-449.  Four quarter transforms as MFMA GEMMs on the unpacked tensor; each pass contracts the
-// leading AO index with C(MO,AO) and the planner writes the result with the new MO index in place, so after four
-// passes the tensor is (pq|rs) in natural order with no transposes in between.
+// src/mp2.f90:261-449.  Four quarter transforms as MFMA GEMMs; each pass contracts the leading AO index with C(MO,AO) and
+// the planner writes the result with the new MO index in place.
 int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* canon_coeff, const double* canon_levels,
                     const double* eri_packed, double* eri_mo_packed, double* e_mp2)
 {
@@ -200,16 +199,20 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         }
         Tensor Cm = cx.tensor({n, n});
         AFESP_HIP(hipMemcpyAsync(Cm.d, canon_coeff, sizeof(double) * n * n, hipMemcpyHostToDevice, cx.stream));
-        Tensor Ta = cx.tensor({n, n, n, n}), Tb = cx.tensor({n, n, n, n});
-        k_unpack_eri(cx, Ta.d, packed, (int)n);
-        contract(cx, 1.0, Cm, "pi", Ta, "ijkl", 0.0, Tb, "pjkl");   // mp2.f90:321-333
-        contract(cx, 1.0, Cm, "qj", Tb, "pjkl", 0.0, Ta, "pqkl");   // mp2.f90:338-348
-        contract(cx, 1.0, Cm, "rk", Ta, "pqkl", 0.0, Tb, "pqrl");   // mp2.f90:357-367
-        contract(cx, 1.0, Cm, "sl", Tb, "pqrl", 0.0, Ta, "pqrs");   // mp2.f90:375-385
+        // Pair symmetry: (ij|kl) is transformed for the n(n+1)/2 pairs k >= l only, the half-transformed (pq|kl) kept for
+        // p >= q only -- 4 n^5 flop and two buffers of n^2 x npair instead of 8 n^5 and two of n^4.
+        const int64_t np = n * (n + 1) / 2;
+        Tensor Ta = view(cx.alloc_raw(n * n * np), {n, n, np}), Tb = view(cx.alloc_raw(n * n * np), {n, n, np});
+        k_unpack_half(cx, Ta.d, packed, (int)n);                     // (ij|KL), ij squared up
+        contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
+        contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348
+        k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                    // (kl|PQ), kl squared up, p >= q
+        contract(cx, 1.0, Cm, "rk", Tb, "klP", 0.0, Ta, "rlP");      // mp2.f90:357-367
+        contract(cx, 1.0, Cm, "sl", Ta, "rlP", 0.0, Tb, "rsP");      // mp2.f90:375-385
         if (ctx->eri_mo_dev) cx.release(ctx->eri_mo_dev);
         ctx->eri_mo_dev = packed;   // reuse the upload buffer for the packed MO integrals
         ctx->eri_mo_n = n;
-        k_pack_eri(cx, packed, Ta.d, (int)n);                        // mp2.f90:388-410
+        k_pack_pairs(cx, packed, Tb.d, (int)n);                      // mp2.f90:388-410
         // MP2 energy on the <ij|ab> slice (mp2.f90:418-440)
         Tensor voovv = cx.tensor({o, o, v, v}), D1 = cx.tensor({o, v}), D2 = cx.tensor({o, o, v, v});
         double* e_dev = cx.alloc(n);
@@ -776,6 +779,34 @@ int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double sca
         ctx->graph_cc.reset();
         ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, packed, e.data(), diis_n_errmat);
         cx.release(packed);
+    });
+}
+
+// Hashed packed AO integrals left on the device as afesp_read_eri_text would leave them (AO->MO timing: bench.py)
+int afesp_synthetic_ao(afesp_ctx* ctx, int64_t nbasis, double scale, uint64_t seed)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        if (nbasis <= 0 || nbasis > 1024) throw Error(1, "afesp_synthetic_ao: bad extents");
+        const int64_t ne = neri_of(nbasis);
+        if (ctx->eri_ao_dev) cx.release(ctx->eri_ao_dev);
+        ctx->eri_ao_dev = cx.alloc(ne);
+        ctx->eri_ao_n = nbasis;
+        hipLaunchKernelGGL(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, ctx->eri_ao_dev, ne, scale, seed);
+        AFESP_HIP(hipGetLastError());
+        cx.sync();
+    });
+}
+
+// Floating-point operations of one particle-particle ladder as this context evaluates it (plain a <= b form or the
+// symmetric/antisymmetric pair form, ccsd.hip)
+int afesp_ccsd_pp_ladder_flop(afesp_ctx* ctx, double* flop)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_pp_ladder_flop: no CCSD state");
+        const double O = ctx->cc.o, V = ctx->cc.v, ps = V * (V + 1) / 2, pa = V * (V - 1) / 2;
+        if (flop) *flop = ctx->cc.pp_sym ? 2.0 * (O * (O + 1) / 2 * ps * ps + O * (O - 1) / 2 * pa * pa) : 2.0 * O * O * V * V * ps;
     });
 }
 

@@ -21,6 +21,13 @@ double* Context::alloc(int64_t n)
     owned.push_back(p);
     return (double*)p;
 }
+double* Context::alloc_raw(int64_t n)
+{
+    void* p = nullptr;
+    AFESP_HIP(hipMalloc(&p, (size_t)(n > 0 ? n : 1) * sizeof(double)));
+    owned.push_back(p);
+    return (double*)p;
+}
 int64_t* Context::alloc_i64(int64_t n) { return (int64_t*)alloc(n); }
 double* Context::scratch(const std::string& name, int64_t n)
 {

@@ -190,42 +190,16 @@ __global__ void lincomb_kernel(double* out, const double* xbase, int64_t xstride
 }
 
 __device__ __forceinline__ int64_t tri(int64_t i, int64_t j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+// pair index of x <= y: y(y+1)/2 + x; inverse of it
+__device__ __forceinline__ void unpair(int64_t p, int& lo, int& hi)
+{
+    int64_t h = (int64_t)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+    while (h * (h + 1) / 2 > p) --h;
+    while ((h + 1) * (h + 2) / 2 <= p) ++h;
+    hi = (int)h;
+    lo = (int)(p - h * (h + 1) / 2);
+}
 
-// integrals.f90:196-210 applied per element: full(i,j,k,l) = packed[tri(tri(i,j),tri(k,l))]
-__global__ void unpack_eri_kernel(double* full, const double* packed, int n)
-{
-    const int64_t n4 = (int64_t)n * n * n * n;
-    GRID_STRIDE(x, n4)
-    {
-        int i = (int)(x % n);
-        int64_t r = x / n;
-        int j = (int)(r % n);
-        r /= n;
-        int k = (int)(r % n), l = (int)(r / n);
-        full[x] = packed[tri(tri(i, j), tri(k, l))];
-    }
-}
-// mp2.f90:388-410: packed[tri(pq, rs)] = full(s,r,q,p); one thread per (pq >= rs) pair
-__global__ void pack_eri_kernel(double* packed, const double* full, int n)
-{
-    const int64_t np = (int64_t)n * (n + 1) / 2;
-    const int64_t tot = np * np;
-    GRID_STRIDE(x, tot)
-    {
-        int64_t rs = x % np, pq = x / np;
-        if (rs > pq) continue;
-        // invert the triangular index
-        int64_t p = (int64_t)((sqrt(8.0 * (double)pq + 1.0) - 1.0) * 0.5);
-        while (p * (p + 1) / 2 > pq) --p;
-        while ((p + 1) * (p + 2) / 2 <= pq) ++p;
-        int64_t q = pq - p * (p + 1) / 2;
-        int64_t r = (int64_t)((sqrt(8.0 * (double)rs + 1.0) - 1.0) * 0.5);
-        while (r * (r + 1) / 2 > rs) --r;
-        while ((r + 1) * (r + 2) / 2 <= rs) ++r;
-        int64_t s = rs - r * (r + 1) / 2;
-        packed[pq * (pq + 1) / 2 + rs] = full[s + (int64_t)n * (r + (int64_t)n * (q + (int64_t)n * p))];
-    }
-}
 // ccsd.f90:496-512: out(p,q,r,s) = <p+b0 q+b1 | r+b2 s+b3> = (pr|qs) read from the packed chemist array
 __global__ void slice_phys_kernel(double* out, const double* packed, int d0, int d1, int d2, int d3, int b0, int b1, int b2, int b3)
 {
@@ -310,15 +284,6 @@ void k_r2_full(Context& cx, double* out, const double* r2, const double* pp, int
     LAUNCH(r2_full_kernel, dim3(grid_for((int64_t)o * o * v * v)), out, r2, pp, o, v);
 }
 // ---- symmetric / antisymmetric form of the particle-particle ladder (ccsd.hip, ccsd_pp_ladder)
-// pair index of x <= y: y(y+1)/2 + x; inverse of it
-__device__ __forceinline__ void unpair(int64_t p, int& lo, int& hi)
-{
-    int64_t h = (int64_t)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
-    while (h * (h + 1) / 2 > p) --h;
-    while ((h + 1) * (h + 2) / 2 <= p) ++h;
-    hi = (int)h;
-    lo = (int)(p - h * (h + 1) / 2);
-}
 // Vs(ef,ab) = 1/2 (<ef|ab> + <fe|ab>) (x 1/2 on e == f) over e <= f, a <= b;  Va(ef,ab) = 1/2 (<ef|ab> - <fe|ab>) over
 // e < f, a < b.  Columns (a,b) have leading dimensions ks / ka; built once per calculation.
 __global__ void vvvv_sympack_kernel(double* vs, double* va, const double* vvvv, int v, int64_t ks, int64_t ka)
@@ -415,14 +380,56 @@ void k_lincomb(Context& cx, double* out, const double* xbase, int64_t xstride, c
 {
     if (n > 0) LAUNCH(lincomb_kernel, dim3(grid_for(n)), out, xbase, xstride, coef_dev, nx, n);
 }
-void k_unpack_eri(Context& cx, double* full, const double* packed, int n)
+// ---- pair-symmetric AO->MO (capi.hip, afesp_ao2mo_mp2): the three layout steps between the quarter transforms
+// u(i,j,KL) = (ij|kl) for every pair KL = tri(k,l): the packed array squared up along its first pair only
+__global__ void unpack_half_kernel(double* u, const double* packed, int n)
 {
-    LAUNCH(unpack_eri_kernel, dim3(grid_for((int64_t)n * n * n * n, 65536)), full, packed, n);
+    const int64_t N = n, np = N * (N + 1) / 2, tot = N * N * np;
+    GRID_STRIDE(x, tot)
+    {
+        const int i = (int)(x % N), j = (int)((x / N) % N);
+        u[x] = packed[tri(tri(i, j), x / (N * N))];
+    }
 }
-void k_pack_eri(Context& cx, double* packed, const double* full, int n)
+// out(k,l,PQ) = in(q,p,tri(k,l)) for PQ = tri(p,q), p >= q: the half-transformed integrals (pq|kl) turned so that the
+// untransformed pair is unpacked and leads (in is symmetric in its first two indices)
+__global__ void pair_transpose_kernel(double* out, const double* in, int n)
+{
+    const int64_t N = n, np = N * (N + 1) / 2, tot = N * N * np;
+    GRID_STRIDE(x, tot)
+    {
+        const int k = (int)(x % N), l = (int)((x / N) % N);
+        const int64_t pq = x / (N * N);
+        int q, p;
+        unpair(pq, q, p);
+        out[x] = in[q + N * p + N * N * tri(k, l)];
+    }
+}
+// packed[tri(PQ,RS)] = full(s,r,PQ) for RS = tri(r,s) <= PQ  (mp2.f90:388-410 on the pair-packed result)
+__global__ void pack_pairs_kernel(double* packed, const double* full, int n)
+{
+    const int64_t N = n, np = N * (N + 1) / 2, tot = np * np;
+    GRID_STRIDE(x, tot)
+    {
+        const int64_t rs = x % np, pq = x / np;
+        if (rs > pq) continue;
+        int s_, r_;
+        unpair(rs, s_, r_);
+        packed[pq * (pq + 1) / 2 + rs] = full[s_ + N * r_ + N * N * pq];
+    }
+}
+void k_unpack_half(Context& cx, double* u, const double* packed, int n)
+{
+    LAUNCH(unpack_half_kernel, dim3(grid_for((int64_t)n * n * ((int64_t)n * (n + 1) / 2), 65536)), u, packed, n);
+}
+void k_pair_transpose(Context& cx, double* out, const double* in, int n)
+{
+    LAUNCH(pair_transpose_kernel, dim3(grid_for((int64_t)n * n * ((int64_t)n * (n + 1) / 2), 65536)), out, in, n);
+}
+void k_pack_pairs(Context& cx, double* packed, const double* full, int n)
 {
     int64_t np = (int64_t)n * (n + 1) / 2;
-    LAUNCH(pack_eri_kernel, dim3(grid_for(np * np, 65536)), packed, full, n);
+    LAUNCH(pack_pairs_kernel, dim3(grid_for(np * np, 65536)), packed, full, n);
 }
 void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1, int d2, int d3, int b0, int b1, int b2, int b3)
 {

@@ -156,6 +156,11 @@ int afesp_contract(afesp_ctx* ctx, double alpha, const double* A, const char* la
  * Fill the context with the SURVEY.md 8(d) synthetic system: identity C, ladder orbital energies, hashed ERIs of
  * magnitude `scale` carrying the 8-fold symmetry, written straight into the physicist slices. */
 int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double scale, uint64_t seed, int diis_n_errmat);
+/* Hashed packed AO integrals of magnitude `scale` left resident on the device, as afesp_read_eri_text leaves a file's:
+ * afesp_ao2mo_mp2(eri_packed = NULL) then transforms them (AO->MO timing at sizes with no bundled eri.dat). */
+int afesp_synthetic_ao(afesp_ctx* ctx, int64_t nbasis, double scale, uint64_t seed);
+/* Floating-point operations of one particle-particle ladder (src/ccsd.f90:1669) as this context evaluates it. */
+int afesp_ccsd_pp_ladder_flop(afesp_ctx* ctx, double* flop);
 /* Kernel-only timing helpers: average HIP-event milliseconds per launch over `reps` launches on the context stream. */
 int afesp_time_pp_ladder(afesp_ctx* ctx, int reps, double* ms_per_launch);
 /* y = a x + b y on n doubles (8 B per lane, 24 n bytes of HBM traffic per launch): PMC calibration / achievable-bandwidth probe. */

@@ -151,6 +151,25 @@ def test_pp_ladder_split_form_on_ragged_extents(eng, o, v, monkeypatch):
     assert np.max(np.abs(h2 - g2)) < 1e-13
 
 
+@pytest.mark.parametrize("n,o", [(2, 1), (3, 2), (7, 3), (13, 4), (24, 5), (33, 16)])
+def test_ao2mo_pair_symmetric_transform(eng, n, o):
+    """AO->MO over the unique pairs (kl), then (pq): every packed MO integral and E(MP2) against the restatement of the four
+    quarter transforms (src/mp2.f90:321-410), with a general (non-orthogonal) coefficient matrix and odd extents."""
+    from afesp_amd import inputs
+    rng = np.random.default_rng(100 * n + o)
+    eri = rng.standard_normal(inputs.neri(n))
+    c = rng.standard_normal((n, n))
+    e = np.concatenate([-2.0 - rng.random(o), 1.0 + rng.random(n - o)])
+    e_mp2, eri_mo = eng.do_mp2_spatial(n, o, c, e, eri)
+    ref = orc.ao2mo(n, c, eri)
+    assert np.max(np.abs(eri_mo - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref)))
+    ref_e = orc.mp2_energy(n, o, ref, e)
+    assert abs(e_mp2 - ref_e) < 1e-10 * max(1.0, abs(ref_e))
+    eng.set_eri(n, eri)
+    e2, again = eng.do_mp2_spatial(n, o, c, e, None)       # AO integrals already resident on the device
+    assert np.array_equal(again, eri_mo) and e2 == e_mp2
+
+
 def test_h2o_tz_shape_synthetic(eng):
     """BASELINE config 2 shape (o=5, v=53) on the SURVEY 8(d) synthetic integrals: CCSD path + (T) vs oracle."""
     o, v = 5, 53
