@@ -189,13 +189,13 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         AFESP_HIP(hipSetDevice(cx.device));
         const int64_t n = nbasis, o = nocc, v = n - o, ne = neri_of(n);
         if (n <= 0 || o <= 0 || v <= 0 || n > 1024) throw Error(1, "afesp_ao2mo_mp2: bad extents");
-        double* packed = cx.alloc(ne);
+        if (!eri_packed && (!ctx->eri_ao_dev || ctx->eri_ao_n != n))
+            throw Error(1, "afesp_ao2mo_mp2: eri_packed is NULL and no AO integrals were read onto the device for this basis size");
+        double* packed = cx.alloc_raw(ne);   // upload buffer, then the packed MO integrals
+        const double* ao = ctx->eri_ao_dev;  // NULL source: transformed where afesp_read_eri_text / afesp_set_eri left them
         if (eri_packed) {
             AFESP_HIP(hipMemcpyAsync(packed, eri_packed, sizeof(double) * ne, hipMemcpyHostToDevice, cx.stream));
-        } else {
-            if (!ctx->eri_ao_dev || ctx->eri_ao_n != n)
-                throw Error(1, "afesp_ao2mo_mp2: eri_packed is NULL and no AO integrals were read onto the device for this basis size");
-            AFESP_HIP(hipMemcpyAsync(packed, ctx->eri_ao_dev, sizeof(double) * ne, hipMemcpyDeviceToDevice, cx.stream));
+            ao = packed;
         }
         Tensor Cm = cx.tensor({n, n});
         AFESP_HIP(hipMemcpyAsync(Cm.d, canon_coeff, sizeof(double) * n * n, hipMemcpyHostToDevice, cx.stream));
@@ -203,7 +203,7 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         // p >= q only -- 4 n^5 flop and two buffers of n^2 x npair instead of 8 n^5 and two of n^4.
         const int64_t np = n * (n + 1) / 2;
         Tensor Ta = view(cx.alloc_raw(n * n * np), {n, n, np}), Tb = view(cx.alloc_raw(n * n * np), {n, n, np});
-        k_unpack_half(cx, Ta.d, packed, (int)n);                     // (ij|KL), ij squared up
+        k_unpack_half(cx, Ta.d, ao, (int)n);                         // (ij|KL), ij squared up
         contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
         contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348
         k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                    // (kl|PQ), kl squared up, p >= q

@@ -381,28 +381,55 @@ void k_lincomb(Context& cx, double* out, const double* xbase, int64_t xstride, c
     if (n > 0) LAUNCH(lincomb_kernel, dim3(grid_for(n)), out, xbase, xstride, coef_dev, nx, n);
 }
 // ---- pair-symmetric AO->MO (capi.hip, afesp_ao2mo_mp2): the three layout steps between the quarter transforms
-// u(i,j,KL) = (ij|kl) for every pair KL = tri(k,l): the packed array squared up along its first pair only
-__global__ void unpack_half_kernel(double* u, const double* packed, int n)
+// Both steps have the shape  out(x,y,C) = src(C, tri(x,y)):  a pair index is squared up into the two leading (fastest)
+// indices of the result while the other pair index C moves from fastest (in src) to slowest.  A workgroup stages a
+// 16 x 16 x 16 tile through LDS so that both the reads (16 consecutive C, or 16 consecutive members of the packed pair)
+// and the writes (16 consecutive x) are 128-byte runs.
+//   MODE 0  unpack_half:     out(i,j,KL) = packed[tri(tri(i,j), KL)]          (ij|kl) with ij squared up, for every pair KL
+//   MODE 1  pair_transpose:  out(k,l,PQ) = in(q,p,tri(k,l)), PQ = tri(p,q)    (pq|kl) -> (kl|PQ), kl squared up, p >= q
+template <int MODE>
+__global__ __launch_bounds__(256) void pair_square_kernel(double* out, const double* src, int n)
 {
-    const int64_t N = n, np = N * (N + 1) / 2, tot = N * N * np;
-    GRID_STRIDE(x, tot)
-    {
-        const int i = (int)(x % N), j = (int)((x / N) % N);
-        u[x] = packed[tri(tri(i, j), x / (N * N))];
+    constexpr int T = 16, SC = T * T + 4;
+    __shared__ double tile[T * SC];
+    const int64_t N = n, np = N * (N + 1) / 2;
+    const int nb = (n + T - 1) / T;
+    const int64_t cb = (int64_t)blockIdx.x / (nb * nb);
+    const int xy = (int)((int64_t)blockIdx.x % (nb * nb));
+    const int x0 = (xy % nb) * T, y0 = (xy / nb) * T;
+    const int64_t c0 = cb * T;
+    // which tile direction is contiguous in src: C (dir 0), y (1) or x (2)
+    int dir = 0;
+    if (MODE == 0) {
+        const int64_t lo = tri(x0, y0), hi = tri(min(x0 + T, n) - 1, min(y0 + T, n) - 1);
+        if (lo < c0 + T - 1 && hi <= c0) dir = x0 >= y0 ? 1 : 2;   // the whole tile lies in rows C of the packed triangle
     }
-}
-// out(k,l,PQ) = in(q,p,tri(k,l)) for PQ = tri(p,q), p >= q: the half-transformed integrals (pq|kl) turned so that the
-// untransformed pair is unpacked and leads (in is symmetric in its first two indices)
-__global__ void pair_transpose_kernel(double* out, const double* in, int n)
-{
-    const int64_t N = n, np = N * (N + 1) / 2, tot = N * N * np;
-    GRID_STRIDE(x, tot)
-    {
-        const int k = (int)(x % N), l = (int)((x / N) % N);
-        const int64_t pq = x / (N * N);
+    const int lane = threadIdx.x % T, row = threadIdx.x / T;
+    int64_t pq_off = 0;
+    if (MODE == 1 && c0 + lane < np) {
         int q, p;
-        unpair(pq, q, p);
-        out[x] = in[q + N * p + N * N * tri(k, l)];
+        unpair(c0 + lane, q, p);
+        pq_off = q + N * p;
+    }
+#pragma unroll 4
+    for (int it = 0; it < T; ++it) {
+        const int c = dir == 0 ? lane : row, yi = dir == 1 ? lane : it, xi = dir == 0 ? row : dir == 1 ? it : lane;
+        const int yy = dir == 2 ? row : yi, cc = dir == 2 ? it : c;   // dir 2: lanes along x, rows along y, loop over C
+        const int X = x0 + xi, Y = y0 + (dir == 2 ? yy : yi);
+        const int64_t Cg = c0 + (dir == 2 ? cc : c);
+        if (X < n && Y < n && Cg < np) {
+            const double val = MODE == 0 ? src[tri(tri(X, Y), Cg)] : src[pq_off + N * N * tri(X, Y)];
+            tile[(dir == 2 ? cc : c) * SC + (dir == 2 ? yy : yi) * T + xi] = val;
+        }
+    }
+    __syncthreads();
+    {
+        const int xi = lane, yi = row, X = x0 + xi, Y = y0 + yi;
+        if (X < n && Y < n) {
+#pragma unroll 4
+            for (int c = 0; c < T; ++c)
+                if (c0 + c < np) out[X + N * Y + N * N * (c0 + c)] = tile[c * SC + yi * T + xi];
+        }
     }
 }
 // packed[tri(PQ,RS)] = full(s,r,PQ) for RS = tri(r,s) <= PQ  (mp2.f90:388-410 on the pair-packed result)
@@ -418,13 +445,18 @@ __global__ void pack_pairs_kernel(double* packed, const double* full, int n)
         packed[pq * (pq + 1) / 2 + rs] = full[s_ + N * r_ + N * N * pq];
     }
 }
+static unsigned pair_square_grid(int n)
+{
+    const int64_t nb = (n + 15) / 16, np = (int64_t)n * (n + 1) / 2;
+    return (unsigned)(nb * nb * ((np + 15) / 16));
+}
 void k_unpack_half(Context& cx, double* u, const double* packed, int n)
 {
-    LAUNCH(unpack_half_kernel, dim3(grid_for((int64_t)n * n * ((int64_t)n * (n + 1) / 2), 65536)), u, packed, n);
+    LAUNCH(pair_square_kernel<0>, dim3(pair_square_grid(n)), u, packed, n);
 }
 void k_pair_transpose(Context& cx, double* out, const double* in, int n)
 {
-    LAUNCH(pair_transpose_kernel, dim3(grid_for((int64_t)n * n * ((int64_t)n * (n + 1) / 2), 65536)), out, in, n);
+    LAUNCH(pair_square_kernel<1>, dim3(pair_square_grid(n)), out, in, n);
 }
 void k_pack_pairs(Context& cx, double* packed, const double* full, int n)
 {
