@@ -411,6 +411,50 @@ __global__ __launch_bounds__(256) void permute_add_kernel(double* __restrict__ o
     }
 }
 
+// Transposing case: the unit-stride index of `in` (label fi) differs from that of `out` (label fo).  A workgroup moves a
+// 32 x 32 tile of the (fo, fi) plane through LDS, so reads run along fi and writes along fo; the other indices are
+// enumerated by the block index.
+struct PermTileArgs {
+    int nother;
+    int64_t dim[4], so[4], si[4];
+    int64_t d_o, d_i, in_stride_o, out_stride_i, tiles_o, tiles_i;
+    double alpha, beta;
+};
+
+__global__ __launch_bounds__(256) void permute_add_tiled_kernel(double* __restrict__ out, const double* __restrict__ in, PermTileArgs a)
+{
+    __shared__ double tile[32][33];
+    int64_t b = blockIdx.x;
+    const int64_t o0 = (b % a.tiles_o) * 32;
+    b /= a.tiles_o;
+    const int64_t i0 = (b % a.tiles_i) * 32;
+    b /= a.tiles_i;
+    int64_t bo = 0, bi = 0;
+    for (int q = 0; q < a.nother; ++q) {
+        const int64_t i = b % a.dim[q];
+        b /= a.dim[q];
+        bo += i * a.so[q];
+        bi += i * a.si[q];
+    }
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ro = ty + 8 * r;
+        if (o0 + ro < a.d_o && i0 + tx < a.d_i) tile[ro][tx] = in[bi + (o0 + ro) * a.in_stride_o + (i0 + tx)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ri = ty + 8 * r;
+        if (i0 + ri < a.d_i && o0 + tx < a.d_o) {
+            const int64_t addr = bo + (o0 + tx) + (i0 + ri) * a.out_stride_i;
+            double val = a.alpha * tile[tx][ri];
+            if (a.beta != 0.0) val += a.beta * out[addr];
+            out[addr] = val;
+        }
+    }
+}
+
 void permute_add(Context& cx, double alpha, const Tensor& in, const char* li, double beta, const Tensor& out, const char* lo)
 {
     if ((int)strlen(li) != in.rank || (int)strlen(lo) != out.rank || in.rank != out.rank || in.rank > 6)
@@ -436,6 +480,33 @@ void permute_add(Context& cx, double alpha, const Tensor& in, const char* li, do
     a.alpha = alpha;
     a.beta = beta;
     if (a.n == 0) return;
+    // q_o / q_i: positions (in the enumeration above) of the indices that are unit-stride in out / in
+    int q_o = -1, q_i = -1;
+    for (int q = 0; q < a.rank; ++q) {
+        if (a.so[q] == 1 && a.dim[q] > 1 && q_o < 0) q_o = q;
+        if (a.si[q] == 1 && a.dim[q] > 1 && q_i < 0) q_i = q;
+    }
+    if (q_o >= 0 && q_i >= 0 && q_o != q_i && a.rank <= 6 && a.dim[q_o] >= 8 && a.dim[q_i] >= 8 && a.n >= (1 << 16)) {
+        PermTileArgs t;
+        t.nother = 0;
+        int64_t blocks = 1;
+        for (int q = 0; q < a.rank; ++q) {
+            if (q == q_o || q == q_i) continue;
+            t.dim[t.nother] = a.dim[q]; t.so[t.nother] = a.so[q]; t.si[t.nother] = a.si[q];
+            blocks *= a.dim[q];
+            ++t.nother;
+        }
+        t.d_o = a.dim[q_o]; t.d_i = a.dim[q_i];
+        t.in_stride_o = a.si[q_o]; t.out_stride_i = a.so[q_i];
+        t.tiles_o = (t.d_o + 31) / 32; t.tiles_i = (t.d_i + 31) / 32;
+        t.alpha = alpha; t.beta = beta;
+        blocks *= t.tiles_o * t.tiles_i;
+        if (blocks < ((int64_t)1 << 31)) {
+            hipLaunchKernelGGL(permute_add_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, cx.stream, out.d, in.d, t);
+            AFESP_HIP(hipGetLastError());
+            return;
+        }
+    }
     unsigned grid = (unsigned)std::min<int64_t>((a.n + 255) / 256, 4096);
     hipLaunchKernelGGL(permute_add_kernel, dim3(grid), dim3(256), 0, cx.stream, out.d, in.d, a);
     AFESP_HIP(hipGetLastError());

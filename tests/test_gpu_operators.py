@@ -97,3 +97,22 @@ def test_omp_reshape_all_24_orders(eng, order):
     orc.lib().orc_permute4(dims, order.encode(), np.ascontiguousarray(x.ravel(order="F")), ref2, 1, 0.5)
     got2 = eng.omp_reshape(x, order, out_arr=y0, beta=0.5)
     assert np.array_equal(got2.ravel(order="F"), ref2)
+
+
+@pytest.mark.parametrize("order", ["".join(p) for p in itertools.permutations("1234")])
+def test_omp_reshape_transposing_orders_through_the_tiled_kernel(eng, order):
+    """Extents past the thresholds of the LDS-tiled permute (unit-stride index changes, both extents >= 8, >= 2^16 elements),
+    not multiples of the 32 x 32 tile; bit-exact, with and without beta."""
+    rng = np.random.default_rng(12)
+    x = _rand(rng, 9, 35, 41, 10)
+    dims = (orc.i64 * 4)(*x.shape)
+    oshape = tuple(x.shape[int(c) - 1] for c in order)
+    ref = np.zeros(x.size)
+    orc.lib().orc_permute4(dims, order.encode(), np.ascontiguousarray(x.ravel(order="F")), ref, 0, 0.0)
+    got = eng.omp_reshape(x, order)
+    assert np.array_equal(got.ravel(order="F"), ref)
+    y0 = _rand(rng, *oshape)
+    ref2 = np.ascontiguousarray(y0.ravel(order="F")).copy()
+    orc.lib().orc_permute4(dims, order.encode(), np.ascontiguousarray(x.ravel(order="F")), ref2, 1, 0.5)
+    got2 = eng.omp_reshape(x, order, out_arr=y0, beta=0.5)
+    assert np.array_equal(got2.ravel(order="F"), ref2)
