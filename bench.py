@@ -153,6 +153,44 @@ def time_ao2mo(eng, o, v, reps):
             "algorithmic_gbs": 8 * (n**4 + (n * (n + 1) // 2) ** 2) / sec / 1e9, "e_mp2": emp2}
 
 
+def real_molecule(name, rank, world, local, dist, cdev, torch):
+    """BASELINE configs 3 / 4: the bundled N2 / F2 cc-pVDZ inputs (tests/golden, copies of the reference's sample_data) through
+    the whole path -- RHF on the host, AO->MO + MP2, CCSD to convergence, (T) with the (i<=j<=k) triples sharded over the
+    ranks and one all-reduce -- with the energies checked against the reference's own outputs."""
+    import molecules
+    from afesp_amd.capi import Engine
+    si, ints, res, _ = molecules.load(name)
+    gold = molecules.SURVEY_GOLD[name]
+    n, o = ints.nbasis, ints.nel // 2
+    v = n - o
+    eng = Engine(local)
+    t0 = time.perf_counter()
+    e_mp2, _ = eng.do_mp2_spatial(n, o, res.canon_coeff, res.canon_levels, ints.eri, want_eri_mo=False)
+    t_ao = time.perf_counter() - t0
+    eng.ccsd_init(o, v, res.canon_levels, None, si.ccsd_diis_n_errmat)
+    t0 = time.perf_counter()
+    nit, en, _ = eng.do_ccsd_spatial(si.ccsd_maxiter, si.ccsd_e_tol, si.ccsd_t_tol)
+    t_cc = time.perf_counter() - t0
+    lo, hi = eng.shard_bounds(world)[rank:rank + 2]
+    eng.do_ccsd_t_spatial(lo, hi)                                        # first call builds the (T) plan
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    part = np.asarray(eng.do_ccsd_t_spatial(lo, hi), dtype=np.float64)
+    if dist is not None:
+        red = torch.from_numpy(part.copy()).to(cdev)
+        dist.all_reduce(red)
+        part = red.cpu().numpy()
+    t_t = time.perf_counter() - t0
+    eng.close()
+    ec = float(en[nit])
+    got = {"mp2_corr": e_mp2, "ccsd_corr": ec, "ccsd_bt_corr": ec + part[0], "ccsd_pt_corr": ec + part[1],
+           "d_bt": part[2], "d_pt": part[3]}
+    return {"nocc": o, "nvirt": v, "ao2mo_mp2_s": t_ao, "ccsd_iterations": int(nit), "ccsd_iter_s": t_cc / max(nit, 1),
+            "t_s": t_t, "energies": {k: float(x) for k, x in got.items()},
+            "max_abs_error_vs_reference_Eh": max(abs(float(got[k]) - gold[k]) for k in got)}
+
+
 DEFAULT_SCALE = {"cfg5": 0.005}     # magnitude of the hashed integrals: keeps the first iterates of every workload finite
 
 
@@ -270,7 +308,8 @@ def main():
     ap.add_argument("--workload", default="h2o_tz", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
     ap.add_argument("--no-extra", dest="extra", action="store_false",
-                    help="skip the additional config-5 (o=20, v=200) measurement appended to the line")
+                    help="skip the additional measurements appended to the line: config 5 (o=20, v=200) and the bundled "
+                         "N2 / F2 inputs (configs 3 / 4) with their energy check")
     ap.add_argument("--scale", type=float, default=None)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the multi-rank path on a one-GPU box")
@@ -300,6 +339,9 @@ def main():
     if args.extra and args.workload != "cfg5":
         # the only configuration where the fp64 MFMA roofline is meaningful: config 5, one step
         extra = measure(args, "cfg5", 1, 1, rank, world, local, dist, cdev, torch, with_roofline=True)
+    molecules_leg = None
+    if args.extra:
+        molecules_leg = {name: real_molecule(name, rank, world, local, dist, cdev, torch) for name in ("n2-cc-pvdz", "f2-cc-pvdz")}
     if rank == 0:
         line = {"metric": "CCSD iter wall-time (s) + (T) wall-time (s); fp64 TFLOP/s vs MFMA peak",
                 "value": res.pop("value"), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -309,6 +351,8 @@ def main():
         if extra is not None:
             extra.pop("cpu_baseline", None)
             line["config5_same_run"] = dict(extra, unit="TFLOP/s", steps=1, warmup=1)
+        if molecules_leg is not None:
+            line["real_molecules_same_run"] = molecules_leg
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
