@@ -377,8 +377,19 @@ int afesp_ccsd_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t
             {"v_oovv", &s.v_oovv}, {"v_ovov", &s.v_ovov}, {"v_vvov", &s.v_vvov}, {"v_oovo", &s.v_oovo}, {"v_oooo", &s.v_oooo},
             {"v_vvvv", &s.v_vvvv}, {"I_vo", &s.I_vo}, {"I_vv", &s.I_vv}, {"I_oo_p", &s.I_oo_p}, {"I_oo", &s.I_oo},
             {"c_oovv", &s.c}, {"asym_t2", &s.asym}, {"x_voov", &s.x_voov}, {"I_oooo", &s.I_oooo}, {"I_ovov", &s.I_ovov},
-            {"I_voov", &s.I_voov}, {"I_vovv_p", &s.I_vovv_p}, {"I_ooov_p", &s.I_ooov_p}, {"r1", &s.r1}, {"r2", &s.r2},
+            {"I_voov", &s.I_voov}, {"I_ooov_p", &s.I_ooov_p}, {"r1", &s.r1}, {"r2", &s.r2},
             {"D1", &s.D1}, {"D2", &s.D2}, {"t1", &s.t1}, {"t2", &s.t2}};
+        if (!strcmp(name, "I_vovv_p")) {   // not formed by the iteration (ccsd.hip): built from the current t1 on request
+            Context& cx = ctx->cx;
+            AFESP_HIP(hipSetDevice(cx.device));
+            const int64_t O = s.o, V = s.v;
+            if (V * O * V * V > capacity) throw Error(1, "afesp_ccsd_get_tensor: buffer too small for I_vovv_p");
+            Tensor t = view(cx.scratch("I_vovv_p", V * O * V * V), {V, O, V, V});
+            ccsd_build_I_vovv_p(cx, s, t);
+            AFESP_HIP(hipMemcpyAsync(out, t.d, sizeof(double) * t.size(), hipMemcpyDeviceToHost, cx.stream));
+            cx.sync();
+            return;
+        }
         for (auto& e : tab)
             if (!strcmp(e.n, name)) {
                 if (e.t->size() > capacity) throw Error(1, std::string("afesp_ccsd_get_tensor: buffer too small for ") + name);

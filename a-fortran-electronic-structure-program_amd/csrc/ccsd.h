@@ -32,7 +32,8 @@ struct CCState : DiisRing {
     bool pp_sym = false;
     double *pp_vs = nullptr, *pp_va = nullptr, *pp_cs = nullptr, *pp_ca = nullptr, *pp_ps = nullptr, *pp_pa = nullptr;
     int64_t pp_ks = 0, pp_ka = 0, pp_ns = 0, pp_na = 0, pp_kn = 0;   // even leading dimensions of those operands
-    Tensor I_vo, I_vv, I_oo_p, I_oo, c, asym, x_voov, I_oooo, I_ovov, I_voov, I_vovv_p, I_ooov_p;
+    Tensor I_vo, I_vv, I_oo_p, I_oo, c, asym, x_voov, I_oooo, I_ovov, I_voov, I_ooov_p;
+    Tensor y_ooov, y_oovo;         // t1-dressed pieces that stand in for I_vovv_p (ccsd_intermediates)
     double energy = 0.0, energy_old = 0.0, rms = 0.0;
     void* tplan = nullptr;      // cached (T) launch plan (triples.hip)
     Tensor I_vovv_pp, I_ooov_pp;   // completely renormalised moments (ccsd.f90:2338-2551), built on request
@@ -47,6 +48,7 @@ void ccsd_diis_save(Context& cx, CCState& s);
 void ccsd_intermediates(Context& cx, CCState& s);
 void ccsd_amplitudes(Context& cx, CCState& s);
 void ccsd_pp_ladder(Context& cx, CCState& s);
+void ccsd_build_I_vovv_p(Context& cx, CCState& s, const Tensor& out);   // out(c,i,a,b), dense v x o x v x v
 bool pp_sym_pays(int64_t o, int64_t v);   // whether ccsd_init chooses the split form (AFESP_PP_SYM=0/1 overrides)
 // updates s.energy / s.energy_old / s.rms (un-rooted, as ccsd.f90:1806); returns 1 if converged
 int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol);

@@ -50,7 +50,7 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     s.I_vo = cx.tensor({V, O}); s.I_vv = cx.tensor({V, V}); s.I_oo_p = cx.tensor({O, O}); s.I_oo = cx.tensor({O, O});
     s.c = cx.tensor({O, O, V, V}); s.asym = cx.tensor({O, O, V, V}); s.x_voov = cx.tensor({V, O, O, V});
     s.I_oooo = cx.tensor({O, O, O, O}); s.I_ovov = cx.tensor({O, V, O, V}); s.I_voov = cx.tensor({V, O, O, V});
-    s.I_vovv_p = cx.tensor({V, O, V, V}); s.I_ooov_p = cx.tensor({O, O, O, V});
+    s.I_ooov_p = cx.tensor({O, O, O, V}); s.y_ooov = cx.tensor({O, O, O, V}); s.y_oovo = cx.tensor({O, O, V, O});
     // pp-ladder (ccsd.f90:1669) over the symmetry-unique column pairs a <= b
     {
         const int64_t np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
@@ -103,7 +103,7 @@ void ccsd_free(Context& cx, CCState& s)
     if (!s.o) return;
     double* bufs[] = {s.e, s.v_oovv.d, s.v_ovov.d, s.v_vvov.d, s.v_oovo.d, s.v_oooo.d, s.v_vvvv.d, s.w_oovv.d, s.w_vvov.d,
                       s.w_oovo.d, s.D1.d, s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.I_vo.d, s.I_vv.d, s.I_oo_p.d, s.I_oo.d, s.c.d,
-                      s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_vovv_p.d, s.I_ooov_p.d, s.amp_s, s.hist_t,
+                      s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_ooov_p.d, s.y_ooov.d, s.y_oovo.d, s.amp_s, s.hist_t,
                       s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d, s.pp, (double*)s.pp_tab, s.pp_vs, s.pp_va, s.pp_cs,
                       s.pp_ca, s.pp_ps, s.pp_pa};
     for (double* b : bufs) cx.release(b);
@@ -191,10 +191,13 @@ void ccsd_intermediates(Context& cx, CCState& s)
     C(-0.5, s.v_oovv, "imbe", s.c, "mjae", 1.0, s.I_voov, "bjia");
     C(-1.0, s.v_oovo, "imbj", s.t1, "ma", 1.0, s.I_voov, "bjia");
     lane(4);
-    // I_vovv_p(c,i,a,b)                                                  ccsd.f90:1255-1272, :1296-1299
-    permute_add(cx, 1.0, s.v_vvov, "baic", 0.0, s.I_vovv_p, "ciab");
-    C(-1.0, s.v_oovv, "micb", s.t1, "ma", 1.0, s.I_vovv_p, "ciab");
-    C(-1.0, s.v_ovov, "maic", s.t1, "mb", 1.0, s.I_vovv_p, "ciab");
+    // I_vovv_p(c,i,a,b) = <ab|ci> - t(m,a) <mi|cb> - t(m,b) <ma|ic>          ccsd.f90:1255-1272, :1296-1299
+    // is only ever contracted with t(i,e) over its first index (:1700), so the o v^3 tensor is not formed: the first term
+    // is contracted from v_vvov directly (ccsd_amplitudes) and the two t1-dressed terms go through these o^3 v tensors,
+    //   y_ooov(i,m,j,b) = t(i,e) <mj|eb>,   y_oovo(i,m,a,j) = t(i,e) <ma|je>
+    // (three passes over o v^3 elements less per iteration; ccsd_build_I_vovv_p forms the tensor itself on request)
+    C(1.0, s.t1, "ie", s.v_oovv, "mjeb", 0.0, s.y_ooov, "imjb");
+    C(1.0, s.t1, "ie", s.v_ovov, "maje", 0.0, s.y_oovo, "imaj");
     lane(5);
     // I_ooov_p(j,k,i,a)                                                  ccsd.f90:1302-1308
     permute_add(cx, 1.0, s.v_oovo, "kjai", 0.0, s.I_ooov_p, "jkia");
@@ -267,10 +270,11 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     // in three groups; all but the first group of each go into partial buffers that are added after the join
     const bool par = lanes_pay(s);
     auto lane = [&](int i) { if (par) cx.use_lane(i); };
-    Tensor r2b = s.r2, r2c = s.r2, r1b = s.r1;
+    Tensor r2b = s.r2, r2c = s.r2, r2d = s.r2, r1b = s.r1;
     if (par) {
         r2b.d = cx.scratch("r2_lane2", s.r2.size());
         r2c.d = cx.scratch("r2_lane3", s.r2.size());
+        r2d.d = cx.scratch("r2_lane4", s.r2.size());
         r1b.d = cx.scratch("r1_lane5", s.r1.size());
         cx.fork(6);
     }
@@ -290,6 +294,8 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     C(-1.0, s.t2, "miba", s.I_oo, "jm", 1.0, s.r2, "ijab");                // :1654-1664
     lane(4);
     ccsd_pp_ladder(cx, s);                                                 // :1669  particle-particle ladder
+    C(-1.0, s.t1, "ma", s.y_ooov, "imjb", par ? 0.0 : 1.0, r2d, "ijab");   // :1700, t1-dressed parts of t(i,e) I_vovv_p(e,j,a,b)
+    C(-1.0, s.t1, "mb", s.y_oovo, "imaj", 1.0, r2d, "ijab");
     lane(1);
     C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");              // :1673  hole-hole ladder
     lane(2);
@@ -297,17 +303,26 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     C(-1.0, s.I_ovov, "iema", s.t2, "mjeb", 1.0, r2b, "ijab");
     lane(3);
     C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
-    C(1.0, s.t1, "ie", s.I_vovv_p, "ejab", 1.0, r2c, "ijab");              // :1700
+    C(1.0, s.t1, "ie", s.v_vvov, "baje", 1.0, r2c, "ijab");                // :1700, bare part: t(i,e) <ab|ej>
     C(-1.0, s.t1, "ma", s.I_ooov_p, "ijmb", 1.0, r2c, "ijab");             // :1705-1715
     if (par) {
         cx.join();
         k_axpby(cx, s.r1.d, 1.0, r1b.d, 1.0, s.r1.size());
         k_axpby(cx, s.r2.d, 1.0, r2b.d, 1.0, s.r2.size());
         k_axpby(cx, s.r2.d, 1.0, r2c.d, 1.0, s.r2.size());
+        k_axpby(cx, s.r2.d, 1.0, r2d.d, 1.0, s.r2.size());
     }
     // P(ia/jb), + v_oovv, Jacobi divide                                  ccsd.f90:1720-1728
     k_div(cx, s.t1.d, s.r1.d, s.D1.d, s.t1.size());
     k_t2_update(cx, s.t2.d, s.r2.d, s.v_oovv.d, s.D2.d, s.pp, s.o, s.v);
+}
+
+// The intermediate of ccsd.f90:1255-1272 as a tensor (tests / afesp_ccsd_get_tensor); the iteration never forms it.
+void ccsd_build_I_vovv_p(Context& cx, CCState& s, const Tensor& out)
+{
+    permute_add(cx, 1.0, s.v_vvov, "baic", 0.0, out, "ciab");
+    contract(cx, -1.0, s.v_oovv, "micb", s.t1, "ma", 1.0, out, "ciab");
+    contract(cx, -1.0, s.v_ovov, "maic", s.t1, "mb", 1.0, out, "ciab");
 }
 
 int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol)
