@@ -347,8 +347,21 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
         };
         p.wide = (p.a_kc ? (pairs(tAk) && evens(tAm)) : (pairs(tAm) && evens(tAk))) &&
                  (p.b_kc ? (pairs(tBk) && evens(tBn)) : (pairs(tBn) && evens(tBk)));
-        p.offAm = upload(cx, tAm); p.offAk = upload(cx, tAk); p.offBk = upload(cx, tBk);
-        p.offBn = upload(cx, tBn); p.offCm = upload(cx, tCm); p.offCn = upload(cx, tCn);
+        // the six tables in one allocation and one copy (a plan per contraction site: ~45 of them in a CCSD iteration),
+        // each starting on a 16-byte boundary
+        {
+            const std::vector<int64_t>* tabs[6] = {&tAm, &tAk, &tBk, &tBn, &tCm, &tCn};
+            int64_t** dst[6] = {&p.offAm, &p.offAk, &p.offBk, &p.offBn, &p.offCm, &p.offCn};
+            std::vector<int64_t> all;
+            size_t start[6];
+            for (int q = 0; q < 6; ++q) {
+                start[q] = all.size();
+                all.insert(all.end(), tabs[q]->begin(), tabs[q]->end());
+                if (all.size() % 2) all.push_back(0);
+            }
+            int64_t* base = upload(cx, all);
+            for (int q = 0; q < 6; ++q) *dst[q] = base + start[q];
+        }
         it = cx.plans.emplace(key, p).first;
         }
     }
