@@ -170,6 +170,19 @@ def test_ao2mo_pair_symmetric_transform(eng, n, o):
     assert np.array_equal(again, eri_mo) and e2 == e_mp2
 
 
+def test_pp_ladder_split_form_through_the_replayed_iteration(eng, monkeypatch):
+    """The pair form inside the laned, graph-replayed iteration of a small system: a whole solve against the oracle."""
+    monkeypatch.setenv("AFESP_PP_SYM", "1")
+    o, v = 5, 19
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.04)
+    cc = orc.OracleCC(o, v, eri, e, 8)
+    eng.ccsd_init(o, v, e, eri, 8)
+    nit, en, rm = eng.do_ccsd_spatial(60, 1e-8, 1e-9)
+    onit, oen, orm = cc.solve(60, 1e-8, 1e-9)
+    assert nit == onit and nit > 3
+    assert np.max(np.abs(en[:nit + 1] - oen[:nit + 1])) < 1e-10
+
+
 def test_h2o_tz_shape_synthetic(eng):
     """BASELINE config 2 shape (o=5, v=53) on the SURVEY 8(d) synthetic integrals: CCSD path + (T) vs oracle."""
     o, v = 5, 53
