@@ -70,3 +70,35 @@ def test_fortran_host_rhf_on_cpu(tmp_path):
     assert len(got["scf_iters"]) == len(gold["scf_iters"])
     for a, b in zip(got["scf_iters"], gold["scf_iters"]):
         assert abs(a[1] - b[1]) < 5e-9
+
+
+def test_bench_script_defines_everything_it_calls():
+    """bench.py only runs on a GPU box; here: it compiles and every plain name it loads resolves (a builtin, a module-level
+    definition or import, or a name bound inside the function that uses it)."""
+    import ast
+    import builtins
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    top = set(dir(builtins))
+    for node in tree.body:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)):
+            top.add(node.name)
+        elif isinstance(node, (ast.Import, ast.ImportFrom)):
+            top.update((a.asname or a.name).split(".")[0] for a in node.names)
+        elif isinstance(node, ast.Assign):
+            top.update(t.id for t in node.targets if isinstance(t, ast.Name))
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        bound = {a.arg for a in fn.args.args + fn.args.kwonlyargs}
+        for sub in ast.walk(fn):
+            if isinstance(sub, ast.Name) and isinstance(sub.ctx, (ast.Store, ast.Del)):
+                bound.add(sub.id)
+            elif isinstance(sub, (ast.FunctionDef, ast.Lambda)):
+                if isinstance(sub, ast.FunctionDef):
+                    bound.add(sub.name)
+                bound.update(a.arg for a in sub.args.args)
+            elif isinstance(sub, (ast.Import, ast.ImportFrom)):
+                bound.update((a.asname or a.name).split(".")[0] for a in sub.names)
+            elif isinstance(sub, ast.ExceptHandler) and sub.name:
+                bound.add(sub.name)
+        missing = {sub.id for sub in ast.walk(fn) if isinstance(sub, ast.Name) and isinstance(sub.ctx, ast.Load)} - bound - top
+        assert not missing, (fn.name, sorted(missing))
