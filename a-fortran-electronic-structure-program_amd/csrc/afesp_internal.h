@@ -86,6 +86,7 @@ struct Context {
     void release(void* p);                // early free of an `owned` buffer
     double* scratch(const std::string& name, int64_t ndoubles);   // cached, uninitialised, grows on demand
     void drop_scratch();
+    void drop_scratch(const std::string& prefix);   // only the cached buffers whose name starts with `prefix`
     int64_t scratch_epoch = 0;            // bumped whenever cached scratch buffers are freed (captured graphs go stale)
     Tensor tensor(std::initializer_list<int64_t> dims);
     void sync();

@@ -191,31 +191,39 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         if (n <= 0 || o <= 0 || v <= 0 || n > 1024) throw Error(1, "afesp_ao2mo_mp2: bad extents");
         if (!eri_packed && (!ctx->eri_ao_dev || ctx->eri_ao_n != n))
             throw Error(1, "afesp_ao2mo_mp2: eri_packed is NULL and no AO integrals were read onto the device for this basis size");
-        double* packed = cx.alloc_raw(ne);   // upload buffer, then the packed MO integrals
+        // upload buffer, then the packed MO integrals; a transform of the same basis size overwrites the previous result
+        double* packed = ctx->eri_mo_dev;
+        if (!packed || ctx->eri_mo_n != n) {
+            if (packed) cx.release(packed);
+            ctx->eri_mo_dev = nullptr;
+            packed = cx.alloc_raw(ne);
+        }
         const double* ao = ctx->eri_ao_dev;  // NULL source: transformed where afesp_read_eri_text / afesp_set_eri left them
         if (eri_packed) {
             AFESP_HIP(hipMemcpyAsync(packed, eri_packed, sizeof(double) * ne, hipMemcpyHostToDevice, cx.stream));
             ao = packed;
         }
-        Tensor Cm = cx.tensor({n, n});
+        Tensor Cm = view(cx.scratch("ao2mo_c", n * n), {n, n});
         AFESP_HIP(hipMemcpyAsync(Cm.d, canon_coeff, sizeof(double) * n * n, hipMemcpyHostToDevice, cx.stream));
         // Pair symmetry: (ij|kl) is transformed for the n(n+1)/2 pairs k >= l only, the half-transformed (pq|kl) kept for
         // p >= q only -- 4 n^5 flop and two buffers of n^2 x npair instead of 8 n^5 and two of n^4.
         const int64_t np = n * (n + 1) / 2;
-        Tensor Ta = view(cx.alloc_raw(n * n * np), {n, n, np}), Tb = view(cx.alloc_raw(n * n * np), {n, n, np});
+        // the two temporaries are cached scratch: a second transform in the same context reuses them, the next afesp_ccsd_init /
+        // afesp_ccsd_so_init gives them back (hipMalloc of several GB is not reliably cheap on this runtime)
+        Tensor Ta = view(cx.scratch("ao2mo_a", n * n * np), {n, n, np}), Tb = view(cx.scratch("ao2mo_b", n * n * np), {n, n, np});
         k_unpack_half(cx, Ta.d, ao, (int)n);                         // (ij|KL), ij squared up
         contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
         contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348
         k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                    // (kl|PQ), kl squared up, p >= q
         contract(cx, 1.0, Cm, "rk", Tb, "klP", 0.0, Ta, "rlP");      // mp2.f90:357-367
         contract(cx, 1.0, Cm, "sl", Ta, "rlP", 0.0, Tb, "rsP");      // mp2.f90:375-385
-        if (ctx->eri_mo_dev) cx.release(ctx->eri_mo_dev);
-        ctx->eri_mo_dev = packed;   // reuse the upload buffer for the packed MO integrals
+        ctx->eri_mo_dev = packed;
         ctx->eri_mo_n = n;
         k_pack_pairs(cx, packed, Tb.d, (int)n);                      // mp2.f90:388-410
         // MP2 energy on the <ij|ab> slice (mp2.f90:418-440)
-        Tensor voovv = cx.tensor({o, o, v, v}), D1 = cx.tensor({o, v}), D2 = cx.tensor({o, o, v, v});
-        double* e_dev = cx.alloc(n);
+        Tensor voovv = view(cx.scratch("ao2mo_v", o * o * v * v), {o, o, v, v}), D1 = view(cx.scratch("ao2mo_d1", o * v), {o, v}),
+               D2 = view(cx.scratch("ao2mo_d2", o * o * v * v), {o, o, v, v});
+        double* e_dev = cx.scratch("ao2mo_e", n);
         AFESP_HIP(hipMemcpyAsync(e_dev, canon_levels, sizeof(double) * n, hipMemcpyHostToDevice, cx.stream));
         k_slice_phys(cx, voovv.d, packed, (int)o, (int)o, (int)v, (int)v, 0, 0, (int)o, (int)o);
         k_denominators(cx, D1.d, D2.d, e_dev, (int)o, (int)v);
@@ -226,8 +234,6 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
             AFESP_HIP(hipMemcpyAsync(eri_mo_packed, packed, sizeof(double) * ne, hipMemcpyDeviceToHost, cx.stream));
             cx.sync();
         }
-        cx.release(Cm.d); cx.release(Ta.d); cx.release(Tb.d); cx.release(voovv.d); cx.release(D1.d); cx.release(D2.d);
-        cx.release(e_dev);
     });
 }
 
@@ -249,6 +255,7 @@ int afesp_ccsd_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, const double* e
             throw Error(1, "afesp_ccsd_init: no MO integrals resident for this basis size (call afesp_ao2mo_mp2 first)");
         }
         ctx->graph_cc.reset();
+        cx.drop_scratch("ao2mo_");   // the AO->MO temporaries
         ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, src, canon_levels, diis_n_errmat);
         if (tmp) cx.release(tmp);
     });
@@ -610,6 +617,7 @@ int afesp_ccsd_so_init(afesp_ctx* ctx, int64_t nbasis, int64_t nel, const double
         } else if (!src || ctx->eri_mo_n != nbasis) {
             throw Error(1, "afesp_ccsd_so_init: no MO integrals resident for this basis size (call afesp_ao2mo_mp2 first)");
         }
+        cx.drop_scratch("ao2mo_");   // the AO->MO temporaries
         so_init(cx, ctx->so, (int)nbasis, (int)nel, src, canon_levels, diis_n_errmat, (flags & AFESP_SO_FOO_AS_PUBLISHED) != 0);
         if (tmp) cx.release(tmp);
     });

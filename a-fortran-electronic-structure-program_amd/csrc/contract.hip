@@ -52,6 +52,21 @@ void Context::drop_scratch()
     for (auto& kv : cache) (void)hipFree(kv.second.first);
     cache.clear();
 }
+void Context::drop_scratch(const std::string& prefix)
+{
+    bool any = false;
+    for (auto it = cache.begin(); it != cache.end();) {
+        if (it->first.compare(0, prefix.size(), prefix) == 0) {
+            if (!any && stream) (void)hipStreamSynchronize(stream);
+            any = true;
+            (void)hipFree(it->second.first);
+            it = cache.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    if (any) ++scratch_epoch;
+}
 void Context::release(void* p)
 {
     if (!p) return;
