@@ -137,7 +137,9 @@ void k_pack_pairs(Context& cx, double* packed, const double* full, int n);
 // out(p,q,r,s) = packed[ index( (p+b0)(r+b2) | (q+b1)(s+b3) ) ]  physicist <pq|rs> from packed chemist (pr|qs)
 void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1, int d2, int d3, int b0, int b1, int b2,
                   int b3);
-void k_build_fock(Context& cx, double* fock, const double* hcore, const double* dens, const double* packed, int n);
+// Fock matrix from the half-unpacked integrals u(x,y,P) (k_unpack_half); work holds k_build_fock_work(n) doubles
+void k_build_fock(Context& cx, double* fock, const double* hcore, const double* dens, const double* u, double* work, int n);
+int64_t k_build_fock_work(int n);
 double* host_scalars(Context& cx, int n);   // copies cx.scal[0..n) to pinned host memory and synchronises
 
 }  // namespace afesp

@@ -36,6 +36,7 @@ struct afesp_ctx {
         }
     } graph_cc;
     int64_t eri_ao_n = 0;
+    int64_t half_n = 0, half_epoch = -1;   // scratch "ao2mo_a" holds the half-unpacked AO integrals of this basis size / epoch
 };
 
 namespace {
@@ -211,7 +212,9 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         // the two temporaries are cached scratch: a second transform in the same context reuses them, the next afesp_ccsd_init /
         // afesp_ccsd_so_init gives them back (hipMalloc of several GB is not reliably cheap on this runtime)
         Tensor Ta = view(cx.scratch("ao2mo_a", n * n * np), {n, n, np}), Tb = view(cx.scratch("ao2mo_b", n * n * np), {n, n, np});
-        k_unpack_half(cx, Ta.d, ao, (int)n);                         // (ij|KL), ij squared up
+        if (!(ao == ctx->eri_ao_dev && ctx->half_n == n && ctx->half_epoch == cx.scratch_epoch))
+            k_unpack_half(cx, Ta.d, ao, (int)n);                     // (ij|KL), ij squared up (afesp_build_fock may have left it)
+        ctx->half_n = 0;                                             // the transform overwrites it
         contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
         contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348
         k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                    // (kl|PQ), kl squared up, p >= q
@@ -526,6 +529,7 @@ int afesp_read_eri_text(afesp_ctx* ctx, const char* path, int64_t nbasis, double
         if (ctx->eri_ao_dev) cx.release(ctx->eri_ao_dev);
         ctx->eri_ao_dev = cx.alloc(ne);
         ctx->eri_ao_n = nbasis;
+        ctx->half_n = 0;
         AFESP_HIP(hipMemcpyAsync(ctx->eri_ao_dev, host.data(), sizeof(double) * ne, hipMemcpyHostToDevice, cx.stream));
         cx.sync();
         if (eri_packed) memcpy(eri_packed, host.data(), sizeof(double) * ne);
@@ -544,6 +548,7 @@ int afesp_set_eri(afesp_ctx* ctx, int64_t nbasis, const double* eri_packed)
         if (ctx->eri_ao_dev) cx.release(ctx->eri_ao_dev);
         ctx->eri_ao_dev = cx.alloc(ne);
         ctx->eri_ao_n = nbasis;
+        ctx->half_n = 0;
         AFESP_HIP(hipMemcpyAsync(ctx->eri_ao_dev, eri_packed, sizeof(double) * ne, hipMemcpyHostToDevice, cx.stream));
         cx.sync();
     });
@@ -561,7 +566,18 @@ int afesp_build_fock(afesp_ctx* ctx, int64_t nbasis, const double* density, cons
         double* buf = cx.scratch("fock_io", 3 * n2);
         AFESP_HIP(hipMemcpyAsync(buf, density, sizeof(double) * n2, hipMemcpyHostToDevice, cx.stream));
         AFESP_HIP(hipMemcpyAsync(buf + n2, core_hamil, sizeof(double) * n2, hipMemcpyHostToDevice, cx.stream));
-        k_build_fock(cx, buf + 2 * n2, buf + n2, buf, ctx->eri_ao_dev, (int)nbasis);
+        // the half-unpacked integrals (ij|KL) live in the scratch buffer the AO->MO transform starts from ("ao2mo_a"): built on
+        // the first Fock build of an SCF, reused by every later one and by afesp_ao2mo_mp2
+        const int64_t np = nbasis * (nbasis + 1) / 2;
+        double* u = cx.scratch("ao2mo_a", n2 * np);
+        if (ctx->half_n != nbasis || ctx->half_epoch != cx.scratch_epoch) {
+            k_unpack_half(cx, u, ctx->eri_ao_dev, (int)nbasis);
+            ctx->half_n = nbasis;
+            ctx->half_epoch = cx.scratch_epoch;
+        }
+        double* work = cx.scratch("fock_work", k_build_fock_work((int)nbasis));
+        ctx->half_epoch = cx.scratch_epoch;   // (growing fock_work moves the epoch, not u)
+        k_build_fock(cx, buf + 2 * n2, buf + n2, buf, u, work, (int)nbasis);
         AFESP_HIP(hipMemcpyAsync(fock, buf + 2 * n2, sizeof(double) * n2, hipMemcpyDeviceToHost, cx.stream));
         cx.sync();
     });
@@ -812,6 +828,7 @@ int afesp_synthetic_ao(afesp_ctx* ctx, int64_t nbasis, double scale, uint64_t se
         if (ctx->eri_ao_dev) cx.release(ctx->eri_ao_dev);
         ctx->eri_ao_dev = cx.alloc(ne);
         ctx->eri_ao_n = nbasis;
+        ctx->half_n = 0;
         hipLaunchKernelGGL(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, ctx->eri_ao_dev, ne, scale, seed);
         AFESP_HIP(hipGetLastError());
         cx.sync();

@@ -214,25 +214,71 @@ __global__ void slice_phys_kernel(double* out, const double* packed, int d0, int
         out[x] = packed[tri(tri(p + b0, r + b2), tri(q + b1, s + b3))];
     }
 }
-// build_fock (hf.f90:349-385): F(i,j) = H(i,j) + sum_kl D(k,l) [2 (ij|kl) - (ik|jl)] from the packed AO integrals.
-// One workgroup per (i,j); the n^2 terms are strided over the threads and summed in a fixed order (bit-reproducible).
-__global__ __launch_bounds__(256) void build_fock_kernel(double* fock, const double* hcore, const double* dens, const double* packed, int n)
+// build_fock (hf.f90:349-385): F(i,j) = H(i,j) + sum_kl D(k,l) [2 (ij|kl) - (ik|jl)].  Both sums run over the half-unpacked
+// integrals u(x,y,P) = (xy|ab), P = tri(a,b), a >= b -- the first stage of the AO->MO transform, built once per SCF -- so
+// every unique pair slab is read once per sum, in 8-byte-per-lane coalesced rows, and every partial sum is combined in a
+// fixed order (bit-reproducible run to run):
+//   J(x,y)  = sum_P u(x,y,P) dv(P),  dv(P) = D(a,b) + D(b,a)  (D(a,a) on a == b)           fock_j_kernel, FOCK_CHUNKS partial sums
+//   K(x,a) += sum_y u(x,y,P) D(y,b),   K(x,b) += sum_y u(x,y,P) D(y,a)  (a != b)              fock_k_kernel, one workgroup per slab
+constexpr int FOCK_CHUNKS = 64;
+__global__ void fock_dv_kernel(double* dv, const double* dens, int n)
 {
-    __shared__ double red[256];
-    const int i = blockIdx.x % n, j = blockIdx.x / n;
-    const int64_t ij = tri(i, j);
-    double s = 0.0;
-    for (int kl = threadIdx.x; kl < n * n; kl += 256) {
-        const int k = kl % n, l = kl / n;
-        s += dens[kl] * (2.0 * packed[tri(ij, tri(k, l))] - packed[tri(tri(i, k), tri(j, l))]);
+    const int64_t np = (int64_t)n * (n + 1) / 2;
+    GRID_STRIDE(p, np)
+    {
+        int b, a;
+        unpair(p, b, a);
+        dv[p] = a == b ? dens[a + (int64_t)n * a] : dens[a + (int64_t)n * b] + dens[b + (int64_t)n * a];
     }
-    red[threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void fock_j_kernel(double* jpart, const double* u, const double* dv, int n)
+{
+    const int64_t n2 = (int64_t)n * n, np = (int64_t)n * (n + 1) / 2;
+    const int64_t xy = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per = (np + FOCK_CHUNKS - 1) / FOCK_CHUNKS, p0 = blockIdx.y * per, p1 = p0 + per < np ? p0 + per : np;
+    if (xy >= n2) return;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int64_t p = p0; p < p1; ++p) acc += u[xy + n2 * p] * dv[p];
+    jpart[(int64_t)blockIdx.y * n2 + xy] = acc;
+}
+__global__ __launch_bounds__(256) void fock_k_kernel(double* kp1, double* kp2, const double* u, const double* dens, int n)
+{
+    extern __shared__ double dcol[];   // D(:,b) then D(:,a)
+    const int64_t n2 = (int64_t)n * n, p = blockIdx.x;
+    int b, a;
+    unpair(p, b, a);
+    for (int y = threadIdx.x; y < n; y += 256) {
+        dcol[y] = dens[y + (int64_t)n * b];
+        dcol[n + y] = dens[y + (int64_t)n * a];
+    }
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-        __syncthreads();
+    const double* m = u + n2 * p;
+    for (int x = threadIdx.x; x < n; x += 256) {
+        double w1 = 0.0, w2 = 0.0;
+#pragma unroll 8
+        for (int y = 0; y < n; ++y) {
+            const double v = m[x + (int64_t)n * y];
+            w1 += v * dcol[y];
+            w2 += v * dcol[n + y];
+        }
+        kp1[p * n + x] = w1;
+        kp2[p * n + x] = w2;
     }
-    if (threadIdx.x == 0) fock[blockIdx.x] = hcore[blockIdx.x] + red[0];
+}
+// F(x,a) = H(x,a) + 2 sum_c jpart[c](x,a) - sum_{b<=a} kp1[tri(a,b)](x) - sum_{b>a} kp2[tri(b,a)](x)
+__global__ void fock_reduce_kernel(double* fock, const double* hcore, const double* jpart, const double* kp1, const double* kp2, int n)
+{
+    const int64_t n2 = (int64_t)n * n;
+    GRID_STRIDE(xa, n2)
+    {
+        const int x = (int)(xa % n), a = (int)(xa / n);
+        double j = 0.0, k = 0.0;
+        for (int c = 0; c < FOCK_CHUNKS; ++c) j += jpart[(int64_t)c * n2 + xa];
+        for (int b = 0; b <= a; ++b) k += kp1[((int64_t)a * (a + 1) / 2 + b) * n + x];
+        for (int b = a + 1; b < n; ++b) k += kp2[((int64_t)b * (b + 1) / 2 + a) * n + x];
+        fock[xa] = hcore[xa] + 2.0 * j - k;
+    }
 }
 }  // namespace
 
@@ -469,10 +515,21 @@ void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1
     if (n > 0) LAUNCH(slice_phys_kernel, dim3(grid_for(n, 65536)), out, packed, d0, d1, d2, d3, b0, b1, b2, b3);
 }
 
-void k_build_fock(Context& cx, double* fock, const double* hcore, const double* dens, const double* packed, int n)
+void k_build_fock(Context& cx, double* fock, const double* hcore, const double* dens, const double* u, double* work, int n)
 {
-    hipLaunchKernelGGL(build_fock_kernel, dim3((unsigned)(n * n)), dim3(256), 0, cx.stream, fock, hcore, dens, packed, n);
+    // work: [ dv (npair) | jpart (FOCK_CHUNKS n^2) | kp1 (npair n) | kp2 (npair n) ]
+    const int64_t n2 = (int64_t)n * n, np = (int64_t)n * (n + 1) / 2;
+    double *dv = work, *jpart = dv + np, *kp1 = jpart + FOCK_CHUNKS * n2, *kp2 = kp1 + np * n;
+    LAUNCH(fock_dv_kernel, dim3(grid_for(np)), dv, dens, n);
+    LAUNCH(fock_j_kernel, dim3((unsigned)((n2 + 255) / 256), FOCK_CHUNKS), jpart, u, dv, n);
+    hipLaunchKernelGGL(fock_k_kernel, dim3((unsigned)np), dim3(256), 2 * n * sizeof(double), cx.stream, kp1, kp2, u, dens, n);
     AFESP_HIP(hipGetLastError());
+    LAUNCH(fock_reduce_kernel, dim3(grid_for(n2)), fock, hcore, jpart, kp1, kp2, n);
+}
+int64_t k_build_fock_work(int n)
+{
+    const int64_t n2 = (int64_t)n * n, np = (int64_t)n * (n + 1) / 2;
+    return np + FOCK_CHUNKS * n2 + 2 * np * n;
 }
 
 }  // namespace afesp
