@@ -130,6 +130,10 @@ void k_dots(Context& cx, double* out, const double* x, const double* ybase, int6
 void k_lincomb(Context& cx, double* out, const double* xbase, int64_t xstride, const double* coef_dev, int nx,
                int64_t n);      // out = sum_j coef[j] * x_j
 void k_sub(Context& cx, double* out, const double* a, const double* b, int64_t n);
+// DIIS extrapolation coefficients on the device: bmat (nerr x nerr) gets row/column `slot` from dots[0..n), coef[0..n) out
+void k_diis_solve(Context& cx, double* coef, double* bmat, const double* dots, double* flag, int n, int nerr, int slot);
+constexpr int DIIS_FLAG_SLOT = 48;   // cx.scal[48]: set by diis_solve_kernel when the solve fails, read with the energies
+void diis_check_flag(Context& cx, const double* host_scal);   // throws the reference's error (ccsd.f90:666) if it is set
 // pair-symmetric AO->MO: u(i,j,KL) from the packed array; out(k,l,PQ) = in(q,p,tri(k,l)); packed[tri(PQ,RS)] = full(s,r,PQ)
 void k_unpack_half(Context& cx, double* u, const double* packed, int n);
 void k_pair_transpose(Context& cx, double* out, const double* in, int n);

@@ -13,7 +13,7 @@ struct DiisRing {
     double *amp_s = nullptr;    // amplitudes saved at the top of the iteration (t1_s/t2_s)
     double *hist_t = nullptr, *hist_e = nullptr;   // nerr * nvec each
     double *coef = nullptr;     // device coefficients
-    std::vector<double> B;      // host copy of the error overlap matrix (nerr x nerr, full)
+    double *bmat = nullptr;     // error overlap matrix on the device (nerr x nerr, full)
 };
 void diis_alloc(Context& cx, DiisRing& r, int diis_nerr);   // r.nvec and r.amp set by the caller (init_diis_cc_t, :577-615)
 void diis_save(Context& cx, DiisRing& r);                   // ccsd.f90:342-343

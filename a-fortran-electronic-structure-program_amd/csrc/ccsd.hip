@@ -105,7 +105,7 @@ void ccsd_free(Context& cx, CCState& s)
                       s.w_oovo.d, s.D1.d, s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.I_vo.d, s.I_vv.d, s.I_oo_p.d, s.I_oo.d, s.c.d,
                       s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_ooov_p.d, s.y_ooov.d, s.y_oovo.d, s.amp_s, s.hist_t,
                       s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d, s.pp, (double*)s.pp_tab, s.pp_vs, s.pp_va, s.pp_cs,
-                      s.pp_ca, s.pp_ps, s.pp_pa};
+                      s.pp_ca, s.pp_ps, s.pp_pa, s.bmat};
     for (double* b : bufs) cx.release(b);
     cx.drop_scratch();
     triples_plan_free(s);
@@ -121,7 +121,7 @@ void diis_alloc(Context& cx, DiisRing& s, int diis_nerr)
         s.hist_t = cx.alloc(s.nvec * diis_nerr);
         s.hist_e = cx.alloc(s.nvec * diis_nerr);
         s.coef = cx.alloc(32);
-        s.B.assign((size_t)diis_nerr * diis_nerr, 0.0);
+        s.bmat = cx.alloc((int64_t)diis_nerr * diis_nerr);
     }
 }
 
@@ -328,7 +328,8 @@ void ccsd_build_I_vovv_p(Context& cx, CCState& s, const Tensor& out)
 int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol)
 {
     k_cc_energy(cx, cx.scal, s.v_oovv.d, s.t1.d, s.t2.d, s.t2_old.d, s.o, s.v);
-    double* h = host_scalars(cx, 2);
+    double* h = host_scalars(cx, DIIS_FLAG_SLOT + 1);
+    diis_check_flag(cx, h);
     s.energy_old = s.energy;        // ccsd.f90:1760
     s.energy = h[0];
     s.rms = h[1];                   // un-rooted, ccsd.f90:1806
@@ -400,35 +401,6 @@ void ccsd_cr_intermediates(Context& cx, CCState& s)
     C(-1.0, t2_e3, "mjae", xo_e, "kemi", 1.0, s.I_ooov_pp, "jkia");
 }
 
-// Symmetric solve of the (n+1)x(n+1) DIIS system on the host (the reference calls LAPACK dsysv, linalg.fpp:38-56;
-// the matrix is at most 16x16).  Gaussian elimination with partial pivoting.
-static int solve_dense(int n, std::vector<double>& A, std::vector<double>& b)
-{
-    for (int k = 0; k < n; ++k) {
-        int p = k;
-        double big = std::fabs(A[k + n * k]);
-        for (int i = k + 1; i < n; ++i)
-            if (std::fabs(A[i + n * k]) > big) { big = std::fabs(A[i + n * k]); p = i; }
-        if (big == 0.0) return 1;
-        if (p != k) {
-            for (int j = 0; j < n; ++j) std::swap(A[k + n * j], A[p + n * j]);
-            std::swap(b[k], b[p]);
-        }
-        for (int i = k + 1; i < n; ++i) {
-            double f = A[i + n * k] / A[k + n * k];
-            if (f == 0.0) continue;
-            for (int j = k; j < n; ++j) A[i + n * j] -= f * A[k + n * j];
-            b[i] -= f * b[k];
-        }
-    }
-    for (int k = n - 1; k >= 0; --k) {
-        double x = b[k];
-        for (int j = k + 1; j < n; ++j) x -= A[k + n * j] * b[j];
-        b[k] = x / A[k + n * k];
-    }
-    return 0;
-}
-
 void ccsd_diis_update(Context& cx, CCState& s) { diis_update(cx, s); }
 
 void diis_update(Context& cx, DiisRing& s)
@@ -443,20 +415,19 @@ void diis_update(Context& cx, DiisRing& s)
     double* he = s.hist_e + (int64_t)slot * s.nvec;
     k_copy(cx, ht, s.amp, s.nvec);
     k_sub(cx, he, s.amp, s.amp_s, s.nvec);
-    // ccsd.f90:653-663: only row/column `slot` of B changes; the other entries are sums over unchanged vectors
+    // ccsd.f90:653-673: only row/column `slot` of B changes; the solve and the extrapolation follow on the device with no
+    // host round trip (k_diis_solve), so the whole update is six launches queued behind the amplitude update
     k_dots(cx, cx.scal, he, s.hist_e, s.nvec, n, s.nvec, false);
-    double* h = host_scalars(cx, n);
-    for (int j = 0; j < n; ++j) s.B[slot + s.nerr * j] = s.B[j + s.nerr * slot] = h[j];
-    const int N = n + 1;
-    std::vector<double> A((size_t)N * N, 0.0), c((size_t)N, 0.0);
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) A[i + N * j] = s.B[i + s.nerr * j];
-    for (int j = 0; j < n; ++j) A[n + N * j] = A[j + N * n] = -1.0;
-    c[n] = -1.0;
-    if (solve_dense(N, A, c)) throw Error(4, "ccsd::update_diis_cc: Linear solve failed!");   // ccsd.f90:666
-    AFESP_HIP(hipMemcpyAsync(s.coef, c.data(), sizeof(double) * n, hipMemcpyHostToDevice, cx.stream));
-    cx.sync();   // c is a local
-    k_lincomb(cx, s.amp, s.hist_t, s.nvec, s.coef, n, s.nvec);   // ccsd.f90:668-673
+    k_diis_solve(cx, s.coef, s.bmat, cx.scal, cx.scal + DIIS_FLAG_SLOT, n, s.nerr, slot);
+    k_lincomb(cx, s.amp, s.hist_t, s.nvec, s.coef, n, s.nvec);
+}
+
+void diis_check_flag(Context& cx, const double* host_scal)
+{
+    if (host_scal[DIIS_FLAG_SLOT] != 0.0) {
+        AFESP_HIP(hipMemsetAsync(cx.scal + DIIS_FLAG_SLOT, 0, sizeof(double), cx.stream));
+        throw Error(4, "ccsd::update_diis_cc: Linear solve failed!");   // ccsd.f90:666
+    }
 }
 
 }  // namespace afesp

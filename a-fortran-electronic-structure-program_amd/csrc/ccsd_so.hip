@@ -205,7 +205,7 @@ void so_free(Context& cx, SOState& s)
     if (!s.o) return;
     double* bufs[] = {s.e, s.oooo.d, s.ooov.d, s.ovoo.d, s.oovo.d, s.oovv.d, s.ovvo.d, s.ovvv.d, s.vovv.d, s.vvvv.d, s.D1.d,
                       s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.F_vv.d, s.F_oo.d, s.F_ov.d, s.W_oooo.d, s.W_vvvv.d, s.W_ovvo.d,
-                      s.tau.d, s.tau_t.d, s.amp_s, s.hist_t, s.hist_e, s.coef};
+                      s.tau.d, s.tau_t.d, s.amp_s, s.hist_t, s.hist_e, s.coef, s.bmat};
     for (double* b : bufs) cx.release(b);
     cx.drop_scratch();
     so_triples_plan_free(s);
@@ -304,7 +304,8 @@ int so_energy(Context& cx, SOState& s, double e_tol, double t_tol)
     AFESP_HIP(hipGetLastError());
     hipLaunchKernelGGL(so_sum2_kernel, dim3(2), dim3(TB), 0, cx.stream, cx.scal, partial, nblk);
     AFESP_HIP(hipGetLastError());
-    double* h = host_scalars(cx, 2);
+    double* h = host_scalars(cx, DIIS_FLAG_SLOT + 1);
+    diis_check_flag(cx, h);
     s.energy_old = s.energy;
     s.energy = h[0];
     s.rms = h[1];

@@ -398,6 +398,79 @@ void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, in
 {
     LAUNCH(pp_expand_kernel, dim3(grid_for((int64_t)o * o * ((int64_t)v * (v + 1) / 2))), pp, ps, pa, o, v, ns, na);
 }
+// update_diis_cc (ccsd.f90:653-673) without leaving the device: the new row/column `slot` of the error overlap matrix comes
+// from `dots`, and the (n+1) x (n+1) system [B -1; -1 0] c = (0,...,0,-1) is solved by Gaussian elimination with partial
+// pivoting (the reference calls dsysv, linalg.fpp:38-56; the matrix is at most 16 x 16) by ONE WAVE: lane j holds column j of
+// the augmented matrix [A | rhs] in registers (all row indices are compile-time constants: the loops are fully unrolled), pivot
+// column and multipliers travel by lane broadcasts.  The coefficients stay in HBM for lincomb_kernel.  flag[0] is set to 1
+// when a pivot vanishes (reported by the next energy evaluation).
+constexpr int DIIS_MAXN = 17;
+__global__ __launch_bounds__(64) void diis_solve_kernel(double* coef, double* bmat, const double* dots, double* flag, int n, int nerr, int slot)
+{
+    const int lane = threadIdx.x, N = n + 1;   // columns 0..n of A, column N = right-hand side
+    double col[DIIS_MAXN];
+#pragma unroll
+    for (int i = 0; i < DIIS_MAXN; ++i) {
+        double v = 0.0;
+        if (lane < n && i < n) v = i == slot ? dots[lane] : lane == slot ? dots[i] : bmat[i + nerr * lane];
+        else if (lane < n && i == n) v = -1.0;
+        else if (lane == n && i < n) v = -1.0;
+        else if (lane == N && i == n) v = -1.0;
+        col[i] = v;
+    }
+    if (lane < n) bmat[slot + nerr * lane] = bmat[lane + nerr * slot] = dots[lane];
+    bool singular = false;
+#pragma unroll
+    for (int k = 0; k < DIIS_MAXN; ++k) {
+        if (k < N && !singular) {
+            double big = -1.0;
+            int p = k;
+#pragma unroll
+            for (int i = k; i < DIIS_MAXN; ++i) {
+                if (i < N) {   // (uniform: rows beyond the system cost nothing)
+                    const double v = fabs(__shfl(col[i], k, 64));
+                    if (v > big) { big = v; p = i; }
+                }
+            }
+            singular = big == 0.0;
+            if (p != k) {
+                const double t = col[k];
+#pragma unroll
+                for (int i = k + 1; i < DIIS_MAXN; ++i)
+                    if (i == p) { col[k] = col[i]; col[i] = t; }
+            }
+            const double rkk = singular ? 0.0 : 1.0 / __shfl(col[k], k, 64);
+#pragma unroll
+            for (int i = k + 1; i < DIIS_MAXN; ++i) {
+                if (i < N) {
+                    const double f = __shfl(col[i], k, 64) * rkk;
+                    col[i] -= f * col[k];
+                }
+            }
+        }
+    }
+    if (singular) {
+        if (lane == 0) flag[0] = 1.0;
+        return;
+    }
+    double xj = 0.0;
+#pragma unroll
+    for (int k = DIIS_MAXN - 1; k >= 0; --k) {
+        if (k < N) {
+            double term = (lane > k && lane < N) ? col[k] * xj : 0.0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) term += __shfl_xor(term, off, 64);
+            const double xk = (__shfl(col[k], N, 64) - term) / __shfl(col[k], k, 64);
+            if (lane == k) xj = xk;
+        }
+    }
+    if (lane < n) coef[lane] = xj;
+}
+void k_diis_solve(Context& cx, double* coef, double* bmat, const double* dots, double* flag, int n, int nerr, int slot)
+{
+    hipLaunchKernelGGL(diis_solve_kernel, dim3(1), dim3(64), 0, cx.stream, coef, bmat, dots, flag, n, nerr, slot);
+    AFESP_HIP(hipGetLastError());
+}
 void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v)
 {
     LAUNCH(denominators_kernel, dim3(grid_for((int64_t)o * o * v * v)), D1, D2, e, o, v);
