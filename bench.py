@@ -370,7 +370,7 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
                                 "tflops_reference_equivalent": 2 * o**2 * v**4 / (ms_lad * 1e-3) / 1e12,
                                 "algorithmic_gbs": 8 * (v**3 * (v + 1) / 2 + 2 * o**2 * v**2) / (ms_lad * 1e-3) / 1e9}
             res["ao2mo"] = time_ao2mo(eng, o, v, 21 if o * v < 2000 else 3)
-        if args.cpu_baseline and with_roofline:
+        if args.cpu_baseline and with_roofline and world == 1:   # rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(o, v, scale, seed, eng)
     barrier()
     eng.close()
