@@ -13,8 +13,9 @@ for it in range(2):
 for rep in range(2):
     t0 = time.perf_counter(); out = eng.do_ccsd_t_spatial(); t1 = time.perf_counter()
     print("(T)    %.3f s" % (t1 - t0), out[:2])
-t0 = time.perf_counter(); eng.build_cr_intermediates(); t1 = time.perf_counter()
-print("CR intermediates %.3f s" % (t1 - t0))
+for rep in range(3):
+    t0 = time.perf_counter(); eng.build_cr_intermediates(); t1 = time.perf_counter()
+    print("CR intermediates %.3f s" % (t1 - t0))
 for rep in range(2):
     t0 = time.perf_counter(); out = eng.do_ccsd_t_spatial_cr(); t1 = time.perf_counter()
     print("CR-(T) %.3f s" % (t1 - t0), out[:2], out[4:])
