@@ -61,3 +61,83 @@ def test_triples_shards_add_up_and_match_oracle_on_device_tensors(big):
         ref += out
     got = big.do_ccsd_t_spatial(0, 2)
     assert np.max(np.abs(got - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref)))
+
+
+def _hash_uniform(k, seed):
+    """numpy twin of the device generator (csrc/capi.hip, splitmix64) used by afesp_synthetic_ao / afesp_synthetic_init"""
+    with np.errstate(over="ignore"):
+        x = (k.astype(np.uint64) + np.uint64(seed)) + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return (x >> np.uint64(11)).astype(np.float64) / 9007199254740992.0
+
+
+def _tri(i, j):
+    hi, lo = np.maximum(i, j), np.minimum(i, j)
+    return hi * (hi + 1) // 2 + lo
+
+
+def _packed(i, j, k, l):
+    return _tri(_tri(i, j), _tri(k, l))          # integrals.f90:196-210, 0-based
+
+
+def test_ao2mo_full_size_with_a_signed_permutation():
+    """n = 220 (config 5): with C a signed permutation matrix every MO integral is one AO integral with a sign,
+    (pq|rs) = s_p s_q s_r s_s (P(p)P(q)|P(r)P(s)) -- exact in floating point, so the pair-squaring, the four quarter transforms over
+    unique pairs and the repack are checked element by element (200 000 sampled index quadruples) at the full size."""
+    from afesp_amd.capi import Engine
+    n, o, scale, seed = O + V, O, 0.02, 4242
+    rng = np.random.default_rng(17)
+    perm = rng.permutation(n)
+    sign = rng.choice([-1.0, 1.0], n)
+    c = np.zeros((n, n))
+    c[np.arange(n), perm] = sign                  # canon_coeff(MO, AO)
+    e = np.concatenate([-2.0 + np.arange(o) / (o - 1), 1.0 + 2.0 * np.arange(n - o) / (n - o - 1)])
+    with Engine(0) as eng:
+        eng.synthetic_ao(n, scale, seed)
+        e_mp2, mo = eng.do_mp2_spatial(n, o, c, e, None)
+    assert np.isfinite(e_mp2)
+    p, q, r, s = (rng.integers(0, n, 200_000) for _ in range(4))
+    ao_index = _packed(perm[p], perm[q], perm[r], perm[s]).astype(np.uint64)
+    expect = sign[p] * sign[q] * sign[r] * sign[s] * scale * (2.0 * _hash_uniform(ao_index, seed) - 1.0)
+    assert np.array_equal(mo[_packed(p, q, r, s)], expect)
+
+
+def test_fock_build_full_size_against_the_defining_sum():
+    """n = 220: sampled elements of F = H + sum_kl D(k,l) [2 (ij|kl) - (ik|jl)] (hf.f90:349-385) evaluated on the host from the
+    same hashed integrals, a non-symmetric density included; linearity in D."""
+    from afesp_amd.capi import Engine
+    n, scale, seed = O + V, 0.02, 99
+    rng = np.random.default_rng(23)
+    h = rng.standard_normal((n, n))
+    d1, d2 = rng.standard_normal((n, n)), rng.standard_normal((n, n))
+    d2 = d2 + d2.T
+    with Engine(0) as eng:
+        eng.synthetic_ao(n, scale, seed)
+        f1, f2, f12 = eng.build_fock(n, d1, h), eng.build_fock(n, d2, h), eng.build_fock(n, d1 + d2, h)
+    assert np.max(np.abs((f12 - h) - (f1 - h) - (f2 - h))) < 1e-11 * np.max(np.abs(f12))
+    g2 = f2 - h                                   # the two-electron part is symmetric for a symmetric density
+    assert np.max(np.abs(g2 - g2.T)) < 1e-11 * np.max(np.abs(g2))
+    k, l = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    val = lambda idx: scale * (2.0 * _hash_uniform(idx.astype(np.uint64), seed) - 1.0)
+    for (i, j) in [(0, 0), (3, 217), (219, 5), (111, 112), (219, 219)]:
+        ref = h[i, j] + np.sum(d1 * (2.0 * val(_packed(i, j, k, l)) - val(_packed(i, k, j, l))))
+        assert abs(f1[i, j] - ref) < 1e-11 * max(1.0, abs(ref)), (i, j)
+
+
+def test_pp_ladder_pair_form_equals_the_plain_form_at_full_size(monkeypatch):
+    """Config 5: one amplitude update with the particle-particle ladder in its symmetric/antisymmetric pair form (what this size
+    runs) and one with the a <= b form, from the same amplitudes: two different sets of GEMMs, the same t2."""
+    from afesp_amd.capi import Engine
+    res = []
+    for form in ("1", "0"):
+        monkeypatch.setenv("AFESP_PP_SYM", form)
+        with Engine(0) as eng:
+            eng.synthetic_init(O, V, 0.005, 12345, 2)
+            eng.ccsd_energy()
+            eng.ccsd_iterate()
+            en = eng.ccsd_iterate()[0]
+            res.append((en, eng.amplitudes()[1]))
+    assert abs(res[0][0] - res[1][0]) < 1e-10 * max(1.0, abs(res[0][0]))
+    assert np.max(np.abs(res[0][1] - res[1][1])) < 1e-12 * max(1.0, np.max(np.abs(res[1][1])))
