@@ -503,26 +503,27 @@ void k_lincomb(Context& cx, double* out, const double* xbase, int64_t xstride, c
 // Both steps have the shape  out(x,y,C) = src(C, tri(x,y)):  a pair index is squared up into the two leading (fastest)
 // indices of the result while the other pair index C moves from fastest (in src) to slowest.  A workgroup stages a
 // 16 x 16 x 16 tile through LDS so that both the reads (16 consecutive C, or 16 consecutive members of the packed pair)
-// and the writes (16 consecutive x) are 128-byte runs.
+// and the writes (16 consecutive x) are 128-byte runs; the tile and its mirror image (x and y exchanged) come from one read.
 //   MODE 0  unpack_half:     out(i,j,KL) = packed[tri(tri(i,j), KL)]          (ij|kl) with ij squared up, for every pair KL
 //   MODE 1  pair_transpose:  out(k,l,PQ) = in(q,p,tri(k,l)), PQ = tri(p,q)    (pq|kl) -> (kl|PQ), kl squared up, p >= q
 template <int MODE>
 __global__ __launch_bounds__(256) void pair_square_kernel(double* out, const double* src, int n)
 {
-    constexpr int T = 16, SC = T * T + 4;
+    constexpr int T = 16, TP = T + 1, SC = T * TP + 3;   // rows padded: the mirrored tile is read out of LDS along y
     __shared__ double tile[T * SC];
     const int64_t N = n, np = N * (N + 1) / 2;
-    const int nb = (n + T - 1) / T;
-    const int64_t cb = (int64_t)blockIdx.x / (nb * nb);
-    const int xy = (int)((int64_t)blockIdx.x % (nb * nb));
-    const int x0 = (xy % nb) * T, y0 = (xy / nb) * T;
+    const int nb = (n + T - 1) / T, nbp = nb * (nb + 1) / 2;
+    // a workgroup owns the tile pair (x-block xb >= y-block yb) of one C block: src(C, tri(x,y)) is read once and written
+    // to out(x,y,C) and to its mirror image out(y,x,C)
+    const int64_t cb = (int64_t)blockIdx.x / nbp;
+    int yb, xb;
+    unpair((int64_t)blockIdx.x % nbp, yb, xb);
+    const int x0 = xb * T, y0 = yb * T;
     const int64_t c0 = cb * T;
-    // which tile direction is contiguous in src: C (dir 0), y (1) or x (2)
+    // which tile direction is contiguous in src: C (dir 0) or y (dir 1: the whole tile lies in rows C of the packed triangle,
+    // where the members x >= y of a pair run along y)
     int dir = 0;
-    if (MODE == 0) {
-        const int64_t lo = tri(x0, y0), hi = tri(min(x0 + T, n) - 1, min(y0 + T, n) - 1);
-        if (lo < c0 + T - 1 && hi <= c0) dir = x0 >= y0 ? 1 : 2;   // the whole tile lies in rows C of the packed triangle
-    }
+    if (MODE == 0 && tri(min(x0 + T, n) - 1, min(y0 + T, n) - 1) <= c0) dir = 1;
     const int lane = threadIdx.x % T, row = threadIdx.x / T;
     int64_t pq_off = 0;
     if (MODE == 1 && c0 + lane < np) {
@@ -532,22 +533,26 @@ __global__ __launch_bounds__(256) void pair_square_kernel(double* out, const dou
     }
 #pragma unroll 4
     for (int it = 0; it < T; ++it) {
-        const int c = dir == 0 ? lane : row, yi = dir == 1 ? lane : it, xi = dir == 0 ? row : dir == 1 ? it : lane;
-        const int yy = dir == 2 ? row : yi, cc = dir == 2 ? it : c;   // dir 2: lanes along x, rows along y, loop over C
-        const int X = x0 + xi, Y = y0 + (dir == 2 ? yy : yi);
-        const int64_t Cg = c0 + (dir == 2 ? cc : c);
-        if (X < n && Y < n && Cg < np) {
-            const double val = MODE == 0 ? src[tri(tri(X, Y), Cg)] : src[pq_off + N * N * tri(X, Y)];
-            tile[(dir == 2 ? cc : c) * SC + (dir == 2 ? yy : yi) * T + xi] = val;
-        }
+        const int c = dir == 0 ? lane : row, yi = dir == 0 ? it : lane, xi = dir == 0 ? row : it;
+        const int X = x0 + xi, Y = y0 + yi;
+        if (X < n && Y < n && c0 + c < np)
+            tile[c * SC + yi * TP + xi] = MODE == 0 ? src[tri(tri(X, Y), c0 + c)] : src[pq_off + N * N * tri(X, Y)];
     }
     __syncthreads();
     {
-        const int xi = lane, yi = row, X = x0 + xi, Y = y0 + yi;
+        const int X = x0 + lane, Y = y0 + row;          // out(x,y,C): lanes along x
         if (X < n && Y < n) {
 #pragma unroll 4
             for (int c = 0; c < T; ++c)
-                if (c0 + c < np) out[X + N * Y + N * N * (c0 + c)] = tile[c * SC + yi * T + xi];
+                if (c0 + c < np) out[X + N * Y + N * N * (c0 + c)] = tile[c * SC + row * TP + lane];
+        }
+    }
+    if (xb != yb) {
+        const int X = y0 + lane, Y = x0 + row;          // the mirror image out(y,x,C): lanes along y
+        if (X < n && Y < n) {
+#pragma unroll 4
+            for (int c = 0; c < T; ++c)
+                if (c0 + c < np) out[X + N * Y + N * N * (c0 + c)] = tile[c * SC + lane * TP + row];
         }
     }
 }
@@ -567,7 +572,7 @@ __global__ void pack_pairs_kernel(double* packed, const double* full, int n)
 static unsigned pair_square_grid(int n)
 {
     const int64_t nb = (n + 15) / 16, np = (int64_t)n * (n + 1) / 2;
-    return (unsigned)(nb * nb * ((np + 15) / 16));
+    return (unsigned)(nb * (nb + 1) / 2 * ((np + 15) / 16));
 }
 void k_unpack_half(Context& cx, double* u, const double* packed, int n)
 {
