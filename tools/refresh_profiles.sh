@@ -19,5 +19,6 @@ python3 $R/tools/summarize_profile.py /tmp/kt_cfg5 > $O/${TAG}_bench_cfg5_kernel
 python3 $R/tools/small_system_gaps.py /tmp/kt_def 600 > $O/${TAG}_bench_default_gaps.txt
 echo "== PMC passes (one counter per pass)"; date
 bash $R/tools/refresh_traffic.sh $TAG || exit 1
+bash $R/tools/pmc_ao2mo_fock.sh $TAG || exit 1
 date
 echo done
