@@ -226,6 +226,27 @@ def test_ragged_and_degenerate_extents(eng, o, v):
     assert np.max(np.abs(outc - refc)) < 1e-10, (outc, refc)
 
 
+@pytest.mark.parametrize("o,v", [(1, 1), (2, 1), (9, 1), (1, 9)])
+@pytest.mark.parametrize("pp_sym", ["0", "1"])
+def test_single_orbital_extents(eng, o, v, pp_sym, monkeypatch):
+    """One occupied or one virtual orbital (no antisymmetric pairs, one-element cubes), both forms of the pp-ladder: three
+    iterations with DIIS and (T) against the oracle."""
+    monkeypatch.setenv("AFESP_PP_SYM", pp_sym)
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05, seed=7 * o + v)
+    cc = orc.OracleCC(o, v, eri, e, 3)
+    eng.ccsd_init(o, v, e, eri, 3)
+    L = cc.L
+    eng.ccsd_energy(1e-12, 1e-12)
+    L.orc_cc_energy(cc.h, 1e-12, 1e-12)
+    for it in range(3):
+        ge, gr, _ = eng.ccsd_iterate(1e-12, 1e-12)
+        eng.ccsd_diis()
+        L.orc_cc_diis_save(cc.h); L.orc_cc_intermediates(cc.h); L.orc_cc_amplitudes(cc.h); L.orc_cc_energy(cc.h, 1e-12, 1e-12)
+        assert abs(ge - cc.energy) < 1e-12, (it, ge, cc.energy)
+        L.orc_cc_diis_update(cc.h)
+    assert np.max(np.abs(eng.do_ccsd_t_spatial() - cc.triples(e))) < 1e-12
+
+
 def test_ccsd_without_diis_and_nonconvergence_is_silent(eng):
     o, v = 3, 6
     n, e, eri = molecules.synthetic_system(o, v, scale=0.05)
