@@ -102,3 +102,20 @@ def test_bench_script_defines_everything_it_calls():
                 bound.add(sub.name)
         missing = {sub.id for sub in ast.walk(fn) if isinstance(sub, ast.Name) and isinstance(sub.ctx, ast.Load)} - bound - top
         assert not missing, (fn.name, sorted(missing))
+
+
+def test_bench_flop_counts_match_the_survey_table():
+    """F_it (reference formulation, full pp-ladder dgemm) and F_T for the BASELINE configurations."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ref_iter = lambda o, v: bench.flops_iter(o, v, 2 * o**2 * v**4)
+    for (o, v), f_it, f_t in [((5, 19), 2.278e7, None), ((5, 53), 7.320e8, None), ((7, 21), 7.616e7, 1.067e9),
+                              ((9, 19), 1.099e8, 1.680e9), ((20, 200), 2.251e12, 1.690e14)]:
+        assert abs(ref_iter(o, v) - f_it) < 6e-4 * f_it, (o, v, ref_iter(o, v))
+        if f_t:
+            assert abs(bench.flops_t_ref(o, v) - f_t) < 6e-4 * f_t
+    assert abs(bench.flops_t_sym(20, 200) - 3.25e13) < 2e-3 * 3.25e13
+    # the two cheaper evaluations of the ladder are counted as what they execute
+    assert bench.flops_iter(20, 200) < ref_iter(20, 200)
