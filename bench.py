@@ -358,6 +358,8 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
                 if tr:
                     roof["traffic"] = tr["hbm_bytes_per_launch"]
                     roof["traffic_source"] = tr["command"]
+                    if "mfma_busy_frac" in tr:
+                        roof["mfma_busy"] = tr["mfma_busy_frac"]     # MFMA-pipe busy fraction (PMC), same passes
             second = {"kernel": "triples_orbit_kernel", "bound": "hbm",
                       "achieved": prof["orbit_bytes"] / max(prof["orbit_ms"], 1e-9) / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "ms_per_launch": prof["orbit_ms"] / max(prof["orbit_launches"], 1),

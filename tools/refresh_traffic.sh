@@ -14,4 +14,5 @@ for wl in cfg5 h2o_tz; do
   done
   python3 $R/tools/pmc_bench_traffic.py $wl /tmp/pmc_${wl}_FETCH_SIZE /tmp/pmc_${wl}_WRITE_SIZE $O/${TAG}_traffic.json > /dev/null
 done
+python3 $R/tools/pmc_mfma_busy.py $TAG $O
 echo done
