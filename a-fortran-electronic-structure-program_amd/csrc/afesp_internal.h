@@ -121,6 +121,8 @@ void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o,
 void k_vvvv_sympack(Context& cx, double* vs, double* va, const double* vvvv, int v, int64_t ks, int64_t ka);
 void k_c_sympack(Context& cx, double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na);
 void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na);
+void k_vvx_sympack(Context& cx, double* ws, double* wa, const double* x, int v, int64_t ncol, int64_t ks, int64_t ka);
+void k_pair_expand_add(Context& cx, double* out, const double* ps, const double* pa, int o, int64_t ncol, int64_t ns, int64_t na);
 // out[0] = sum (2 v(ijab) - v(ijba)) (t2 + t1 t1), out[1] = sum (t2 - t2_old)^2 ; then t2_old = t2
 void k_cc_energy(Context& cx, double* out2, const double* v_oovv, const double* t1, const double* t2, double* t2_old,
                  int o, int v);

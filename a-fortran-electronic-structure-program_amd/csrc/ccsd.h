@@ -32,6 +32,8 @@ struct CCState : DiisRing {
     bool pp_sym = false;
     double *pp_vs = nullptr, *pp_va = nullptr, *pp_cs = nullptr, *pp_ca = nullptr, *pp_ps = nullptr, *pp_pa = nullptr;
     int64_t pp_ks = 0, pp_ka = 0, pp_ns = 0, pp_na = 0, pp_kn = 0;   // even leading dimensions of those operands
+    int64_t pp_nm = 0;                                     // rows the row tables cover: max(v(v+1)/2, o v)
+    double *ov_ws = nullptr, *ov_wa = nullptr;             // the same split of <ef|ia> (v_vvov) for I_ooov_p, built at init
     Tensor I_vo, I_vv, I_oo_p, I_oo, c, asym, x_voov, I_oooo, I_ovov, I_voov, I_ooov_p;
     Tensor y_ooov, y_oovo;         // t1-dressed pieces that stand in for I_vovv_p (ccsd_intermediates)
     double energy = 0.0, energy_old = 0.0, rms = 0.0;
@@ -48,6 +50,7 @@ void ccsd_diis_save(Context& cx, CCState& s);
 void ccsd_intermediates(Context& cx, CCState& s);
 void ccsd_amplitudes(Context& cx, CCState& s);
 void ccsd_pp_ladder(Context& cx, CCState& s);
+void ccsd_ooov_pair_form(Context& cx, CCState& s);
 void ccsd_build_I_vovv_p(Context& cx, CCState& s, const Tensor& out);   // out(c,i,a,b), dense v x o x v x v
 bool pp_sym_pays(int64_t o, int64_t v);   // whether ccsd_init chooses the split form (AFESP_PP_SYM=0/1 overrides)
 // updates s.energy / s.energy_old / s.rms (un-rooted, as ccsd.f90:1806); returns 1 if converged

@@ -72,18 +72,26 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
             auto even = [](int64_t x) { return (x + 1) & ~(int64_t)1; };
             const int64_t npa = V * (V - 1) / 2, ks = even(np), ka = even(npa), ns = even(O * (O + 1) / 2), na = even(O * (O - 1) / 2);
             s.pp_ks = ks; s.pp_ka = ka; s.pp_ns = ns; s.pp_na = na;
-            s.pp_vs = cx.alloc(ks * np); s.pp_cs = cx.alloc(ns * ks); s.pp_ps = cx.alloc(ns * np);
-            if (npa > 0 && na > 0) { s.pp_va = cx.alloc(ka * npa); s.pp_ca = cx.alloc(na * ka); s.pp_pa = cx.alloc(na * npa); }
+            // (the products of t2 with <ef|ia> for I_ooov_p use the same tables and the same c+- / P+- buffers: rows m = (i,a))
+            const int64_t nm = std::max(np, O * V);
+            s.pp_nm = nm;
+            s.pp_vs = cx.alloc(ks * np); s.pp_cs = cx.alloc(ns * ks); s.pp_ps = cx.alloc(ns * nm);
+            s.ov_ws = cx.alloc(ks * O * V);
+            if (npa > 0 && na > 0) {
+                s.pp_va = cx.alloc(ka * npa); s.pp_ca = cx.alloc(na * ka); s.pp_pa = cx.alloc(na * nm);
+                s.ov_wa = cx.alloc(ka * O * V);
+            }
             k_vvvv_sympack(cx, s.pp_vs, s.pp_va, s.v_vvvv.d, v, ks, ka);
+            k_vvx_sympack(cx, s.ov_ws, s.ov_wa, s.v_vvov.d, v, O * V, ks, ka);
             // [ x (k or n) | ks*m | ka*m | ns*k | na*k | ns*m | na*m ]: entries beyond the antisymmetric extents unused
             s.pp_kn = std::max(ks, ns);
             for (int64_t k = 0; k < s.pp_kn; ++k) tab.push_back(k);
-            for (int64_t m = 0; m < np; ++m) tab.push_back(ks * m);
-            for (int64_t m = 0; m < np; ++m) tab.push_back(ka * m);
+            for (int64_t m = 0; m < nm; ++m) tab.push_back(ks * m);
+            for (int64_t m = 0; m < nm; ++m) tab.push_back(ka * m);
             for (int64_t k = 0; k < ks; ++k) tab.push_back(ns * k);
             for (int64_t k = 0; k < ks; ++k) tab.push_back(na * k);
-            for (int64_t m = 0; m < np; ++m) tab.push_back(ns * m);
-            for (int64_t m = 0; m < np; ++m) tab.push_back(na * m);
+            for (int64_t m = 0; m < nm; ++m) tab.push_back(ns * m);
+            for (int64_t m = 0; m < nm; ++m) tab.push_back(na * m);
         }
         s.pp_tab = cx.alloc_i64((int64_t)tab.size());
         AFESP_HIP(hipMemcpyAsync(s.pp_tab, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
@@ -105,7 +113,7 @@ void ccsd_free(Context& cx, CCState& s)
                       s.w_oovo.d, s.D1.d, s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.I_vo.d, s.I_vv.d, s.I_oo_p.d, s.I_oo.d, s.c.d,
                       s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_ooov_p.d, s.y_ooov.d, s.y_oovo.d, s.amp_s, s.hist_t,
                       s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d, s.pp, (double*)s.pp_tab, s.pp_vs, s.pp_va, s.pp_cs,
-                      s.pp_ca, s.pp_ps, s.pp_pa, s.bmat};
+                      s.pp_ca, s.pp_ps, s.pp_pa, s.bmat, s.ov_ws, s.ov_wa};
     for (double* b : bufs) cx.release(b);
     cx.drop_scratch();
     triples_plan_free(s);
@@ -201,7 +209,8 @@ void ccsd_intermediates(Context& cx, CCState& s)
     lane(5);
     // I_ooov_p(j,k,i,a)                                                  ccsd.f90:1302-1308
     permute_add(cx, 1.0, s.v_oovo, "kjai", 0.0, s.I_ooov_p, "jkia");
-    C(1.0, s.t2, "jkef", s.v_vvov, "efia", 1.0, s.I_ooov_p, "jkia");
+    if (s.pp_sym) ccsd_ooov_pair_form(cx, s);   // t2(jk,ef) <ef|ia> over pair indices, as the pp-ladder
+    else C(1.0, s.t2, "jkef", s.v_vvov, "efia", 1.0, s.I_ooov_p, "jkia");
     if (par) cx.wait(x_voov_ready);
     C(1.0, s.t1, "je", s.x_voov, "ekia", 1.0, s.I_ooov_p, "jkia");
     if (par) cx.join();
@@ -243,23 +252,61 @@ void ccsd_pp_ladder(Context& cx, CCState& s)
         AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
         return;
     }
-    const int64_t npa = V * (V - 1) / 2, ks = s.pp_ks, ka = s.pp_ka, ns = s.pp_ns, na = s.pp_na;
+    const int64_t npa = V * (V - 1) / 2, ks = s.pp_ks, ka = s.pp_ka, ns = s.pp_ns, na = s.pp_na, nm = s.pp_nm;
     const int64_t* t = s.pp_tab;
-    const int64_t* u = t + s.pp_kn;   // [ ks*m | ka*m | ns*k | na*k | ns*m | na*m ]
+    const int64_t* u = t + s.pp_kn;   // [ ks*m | ka*m | ns*k | na*k | ns*m | na*m ], nm rows each
     k_c_sympack(cx, s.pp_cs, s.pp_ca, s.c.d, s.o, s.v, ns, na);
     gp.wide = true;
     gp.offAk = t; gp.offBn = gp.offCn = t;
     gp.A = s.pp_vs; gp.B = s.pp_cs; gp.C = s.pp_ps;
-    gp.offAm = u; gp.offBk = u + 2 * np; gp.offCm = u + 2 * np + 2 * ks;
+    gp.offAm = u; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * ks;
     gp.M = (int)np; gp.N = (int)ns; gp.K = (int)ks;
     AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
     if (s.pp_pa) {
         gp.A = s.pp_va; gp.B = s.pp_ca; gp.C = s.pp_pa;
-        gp.offAm = u + np; gp.offBk = u + 2 * np + ks; gp.offCm = u + 3 * np + 2 * ks;
+        gp.offAm = u + nm; gp.offBk = u + 2 * nm + ks; gp.offCm = u + 3 * nm + 2 * ks;
         gp.M = (int)npa; gp.N = (int)na; gp.K = (int)ka;
         AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
     }
     k_pp_expand(cx, s.pp, s.pp_ps, s.pp_pa, s.o, s.v, ns, na);
+}
+
+// I_ooov_p(j,k,i,a) += sum_ef t2(jk,ef) <ef|ia>  (ccsd.f90:1302-1308) in the pair form of the pp-ladder: t2 has the (anti)symmetry
+// of c under j <-> k together with e <-> f, so with t+- = t2(jkef) +- t2(jkfe) and W+- = <ef|ia> +- <fe|ia> the product is
+// Ts + Ta for j <= k and Ts - Ta for k < j, two products over pair indices (half the work).  W+- are built at init, the c+- and
+// P+- buffers of the ladder hold t+- and the two results (the ladder runs later in the iteration).
+void ccsd_ooov_pair_form(Context& cx, CCState& s)
+{
+    const int64_t O = s.o, V = s.v, np = V * (V + 1) / 2, npa = V * (V - 1) / 2, ks = s.pp_ks, ka = s.pp_ka, ns = s.pp_ns, na = s.pp_na,
+                  nm = s.pp_nm, M = O * V;
+    const int64_t* t = s.pp_tab;
+    const int64_t* u = t + s.pp_kn;
+    k_c_sympack(cx, s.pp_cs, s.pp_ca, s.t2.d, s.o, s.v, ns, na);
+    GettProblem gp;
+    gp.alpha = 1.0; gp.beta = 0.0;
+    gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
+    gp.a_kcontig = true; gp.b_kcontig = false;
+    gp.wide = true;
+    gp.offAk = t; gp.offBn = gp.offCn = t;
+    // few tiles (o v rows x o-pair columns), long K: slice K until the device is full
+    auto slices = [&](int64_t n, int64_t k) {
+        const int64_t tiles = ((M + 255) / 256) * ((n + 127) / 128), ksteps = (k + 15) / 16;
+        int64_t sp = (256 + tiles - 1) / tiles;
+        while (sp > 1 && ksteps / sp < 32) --sp;
+        return (int)std::max<int64_t>(1, std::min<int64_t>(sp, 16));
+    };
+    gp.A = s.ov_ws; gp.B = s.pp_cs; gp.C = s.pp_ps;
+    gp.offAm = u; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * ks;
+    gp.M = (int)M; gp.N = (int)ns; gp.K = (int)ks;
+    AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, slices(ns, ks)));
+    if (s.ov_wa) {
+        gp.A = s.ov_wa; gp.B = s.pp_ca; gp.C = s.pp_pa;
+        gp.offAm = u + nm; gp.offBk = u + 2 * nm + ks; gp.offCm = u + 3 * nm + 2 * ks;
+        gp.M = (int)M; gp.N = (int)na; gp.K = (int)ka;
+        AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, slices(na, ka)));
+    }
+    (void)np; (void)npa;
+    k_pair_expand_add(cx, s.I_ooov_p.d, s.pp_ps, s.ov_wa ? s.pp_pa : nullptr, s.o, M, ns, na);
 }
 
 void ccsd_amplitudes(Context& cx, CCState& s)

@@ -386,6 +386,46 @@ __global__ void pp_expand_kernel(double* pp, const double* ps, const double* pa,
         pp[x] = val;
     }
 }
+// Same split of the leading pair (e,f) for a tensor x(e,f,col) whose columns carry no pair structure (v_vvov: col = (i,a)):
+// ws(ef,col) = 1/2 (x(e,f,col) + x(f,e,col)) (x 1/2 on e == f) over e <= f,  wa(ef,col) = 1/2 (x(e,f,col) - x(f,e,col)) over e < f
+__global__ void vvx_sympack_kernel(double* ws, double* wa, const double* x, int v, int64_t ncol, int64_t ks, int64_t ka)
+{
+    const int64_t V = v, n = V * V * ncol;
+    GRID_STRIDE(t, n)
+    {
+        const int e = (int)(t % V), f = (int)((t / V) % V);
+        if (e > f) continue;
+        const int64_t col = t / (V * V);
+        const double p = x[t], q = x[f + V * e + V * V * col];
+        ws[(int64_t)f * (f + 1) / 2 + e + ks * col] = (e == f ? 0.25 : 0.5) * (p + q);
+        if (wa && e < f) wa[(int64_t)f * (f - 1) / 2 + e + ka * col] = 0.5 * (p - q);
+    }
+}
+// out(j,k,col) += Ts(jk,col) +/- Ta(jk,col): + for j < k, - for j > k  (the pair-form product of t2 with v_vvov, ccsd.hip)
+__global__ void pair_expand_add_kernel(double* out, const double* ps, const double* pa, int o, int64_t ncol, int64_t ns, int64_t na)
+{
+    const int64_t O = o, n = O * O * ncol;
+    GRID_STRIDE(x, n)
+    {
+        const int j = (int)(x % O), k = (int)((x / O) % O);
+        const int64_t col = x / (O * O);
+        const int lo = j < k ? j : k, hi = j < k ? k : j;
+        double val = ps[(int64_t)hi * (hi + 1) / 2 + lo + ns * col];
+        if (j != k && pa) {
+            const double w = pa[(int64_t)hi * (hi - 1) / 2 + lo + na * col];
+            val += j < k ? w : -w;
+        }
+        out[x] += val;
+    }
+}
+void k_vvx_sympack(Context& cx, double* ws, double* wa, const double* x, int v, int64_t ncol, int64_t ks, int64_t ka)
+{
+    LAUNCH(vvx_sympack_kernel, dim3(grid_for((int64_t)v * v * ncol, 65536)), ws, wa, x, v, ncol, ks, ka);
+}
+void k_pair_expand_add(Context& cx, double* out, const double* ps, const double* pa, int o, int64_t ncol, int64_t ns, int64_t na)
+{
+    LAUNCH(pair_expand_add_kernel, dim3(grid_for((int64_t)o * o * ncol)), out, ps, pa, o, ncol, ns, na);
+}
 void k_vvvv_sympack(Context& cx, double* vs, double* va, const double* vvvv, int v, int64_t ks, int64_t ka)
 {
     LAUNCH(vvvv_sympack_kernel, dim3(grid_for((int64_t)v * v * ((int64_t)v * (v + 1) / 2), 65536)), vs, va, vvvv, v, ks, ka);
