@@ -80,6 +80,7 @@ def load_library():
     L.afesp_time_pp_ladder.argtypes = [C.c_void_p, C.c_int, C.POINTER(dbl)]
     L.afesp_synthetic_ao.argtypes = [C.c_void_p, i64, dbl, C.c_uint64]
     L.afesp_ccsd_pp_ladder_flop.argtypes = [C.c_void_p, C.POINTER(dbl)]
+    L.afesp_ccsd_iteration_flop.argtypes = [C.c_void_p, C.POINTER(dbl)]
     L.afesp_bench_contract.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(i64), C.c_char_p, C.POINTER(i64), C.c_char_p,
                                        C.POINTER(i64), C.c_int, C.POINTER(dbl)]
     L.afesp_set_tuning.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
@@ -386,6 +387,11 @@ class Engine:
     def pp_ladder_flop(self):
         f = dbl()
         self._chk(self.L.afesp_ccsd_pp_ladder_flop(self.h, C.byref(f)))
+        return f.value
+
+    def iteration_flop(self):
+        f = dbl()
+        self._chk(self.L.afesp_ccsd_iteration_flop(self.h, C.byref(f)))
         return f.value
 
     def time_pp_ladder(self, reps=10):

@@ -846,6 +846,23 @@ int afesp_ccsd_pp_ladder_flop(afesp_ctx* ctx, double* flop)
     });
 }
 
+// Floating-point operations of one CCSD iteration as this context evaluates it: SURVEY.md 8(d)'s sum over the contraction sites,
+// with the pp-ladder and the t2 x <ef|ia> product counted in the form they are executed (plain, a <= b, or over pair indices)
+int afesp_ccsd_iteration_flop(afesp_ctx* ctx, double* flop)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_iteration_flop: no CCSD state");
+        const double O = ctx->cc.o, V = ctx->cc.v, ps = V * (V + 1) / 2, pa = V * (V - 1) / 2, os = O * (O + 1) / 2, oa = O * (O - 1) / 2;
+        const bool sym = ctx->cc.pp_sym;
+        const double pp = sym ? 2.0 * (os * ps * ps + oa * pa * pa) : 2.0 * O * O * V * V * ps;
+        const double ooov = sym ? 2.0 * O * V * (os * ps + oa * pa) : 2.0 * O * O * O * V * V * V;
+        const double o3v3 = O * O * O * V * V * V;
+        if (flop)
+            *flop = pp + ooov + 12.0 * o3v3 + 2.0 * O * O * O * O * V * V + 2.0 * O * O * O * O * V + 18.0 * O * O * V * V * V +
+                    2.0 * O * V * V * V + 14.0 * O * O * O * V * V;
+    });
+}
+
 int afesp_bench_stream(afesp_ctx* ctx, int64_t n, int reps, double* ms_per_launch)
 {
     return guarded(ctx, [&] {

@@ -325,7 +325,7 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed, t_iter, t_trip = [float(x) for x in tt.cpu()]
     sec_per_step = elapsed / steps
-    flop_step = flops_iter(o, v, eng.pp_ladder_flop()) + flops_t_sym(o, v)
+    flop_step = int(eng.iteration_flop()) + flops_t_sym(o, v)     # the iteration as the engine evaluates it (pair forms counted as executed)
     res = None
     if rank == 0:
         res = {

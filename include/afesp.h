@@ -161,6 +161,8 @@ int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double sca
 int afesp_synthetic_ao(afesp_ctx* ctx, int64_t nbasis, double scale, uint64_t seed);
 /* Floating-point operations of one particle-particle ladder (src/ccsd.f90:1669) as this context evaluates it. */
 int afesp_ccsd_pp_ladder_flop(afesp_ctx* ctx, double* flop);
+/* ... and of one whole CCSD iteration (src/ccsd.f90:340-395; SURVEY.md 8(d) sum with the two pair-form products as executed). */
+int afesp_ccsd_iteration_flop(afesp_ctx* ctx, double* flop);
 /* Kernel-only timing helpers: average HIP-event milliseconds per launch over `reps` launches on the context stream. */
 int afesp_time_pp_ladder(afesp_ctx* ctx, int reps, double* ms_per_launch);
 /* y = a x + b y on n doubles (8 B per lane, 24 n bytes of HBM traffic per launch): PMC calibration / achievable-bandwidth probe. */
