@@ -304,8 +304,9 @@ int afesp_ccsd_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* energ
             ccsd_diis_save(ctx->cx, ctx->cc);
             ccsd_intermediates(ctx->cx, ctx->cc);
             ccsd_amplitudes(ctx->cx, ctx->cc);
+            ccsd_energy_launch(ctx->cx, ctx->cc);
         });
-        int conv = ccsd_energy(ctx->cx, ctx->cc, e_tol, t_tol);
+        int conv = ccsd_energy_read(ctx->cx, ctx->cc, e_tol, t_tol);
         if (energy) *energy = ctx->cc.energy;
         if (rms_sq) *rms_sq = ctx->cc.rms;
         if (converged) *converged = conv;
@@ -340,8 +341,9 @@ int afesp_ccsd_solve(afesp_ctx* ctx, int maxiter, double e_tol, double t_tol, do
                 ccsd_diis_save(cx, s);
                 ccsd_intermediates(cx, s);
                 ccsd_amplitudes(cx, s);
+                ccsd_energy_launch(cx, s);
             });
-            int conv = ccsd_energy(cx, s, e_tol, t_tol);
+            int conv = ccsd_energy_read(cx, s, e_tol, t_tol);
             if (iter_energy) iter_energy[it] = s.energy;
             if (iter_rms_sq) iter_rms_sq[it] = s.rms;
             if (conv) {

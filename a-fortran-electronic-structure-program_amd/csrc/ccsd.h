@@ -55,6 +55,8 @@ void ccsd_build_I_vovv_p(Context& cx, CCState& s, const Tensor& out);   // out(c
 bool pp_sym_pays(int64_t o, int64_t v);   // whether ccsd_init chooses the split form (AFESP_PP_SYM=0/1 overrides)
 // updates s.energy / s.energy_old / s.rms (un-rooted, as ccsd.f90:1806); returns 1 if converged
 int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol);
+void ccsd_energy_launch(Context& cx, CCState& s);                               // the two kernels only
+int ccsd_energy_read(Context& cx, CCState& s, double e_tol, double t_tol);        // host read of what they left
 void ccsd_diis_update(Context& cx, CCState& s);
 void ccsd_free(Context& cx, CCState& s);
 

@@ -372,9 +372,18 @@ void ccsd_build_I_vovv_p(Context& cx, CCState& s, const Tensor& out)
     contract(cx, -1.0, s.v_ovov, "maic", s.t1, "mb", 1.0, out, "ciab");
 }
 
-int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol)
+// The energy evaluation in two halves: the launches (part of the replayed iteration, capi.hip) and the host read.
+void ccsd_energy_launch(Context& cx, CCState& s)
 {
     k_cc_energy(cx, cx.scal, s.v_oovv.d, s.t1.d, s.t2.d, s.t2_old.d, s.o, s.v);
+}
+int ccsd_energy(Context& cx, CCState& s, double e_tol, double t_tol)
+{
+    ccsd_energy_launch(cx, s);
+    return ccsd_energy_read(cx, s, e_tol, t_tol);
+}
+int ccsd_energy_read(Context& cx, CCState& s, double e_tol, double t_tol)
+{
     double* h = host_scalars(cx, DIIS_FLAG_SLOT + 1);
     diis_check_flag(cx, h);
     s.energy_old = s.energy;        // ccsd.f90:1760
