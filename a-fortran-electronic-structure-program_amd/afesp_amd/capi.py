@@ -28,7 +28,11 @@ EXPORTS = [
     "afesp_ccsd_so_init", "afesp_ccsd_so_energy", "afesp_ccsd_so_iterate", "afesp_ccsd_so_diis", "afesp_ccsd_so_get_amplitudes",
     "afesp_ccsd_so_set_amplitudes", "afesp_ccsd_so_get_tensor", "afesp_ccsd_so_t_ntriples", "afesp_ccsd_so_t",
     "afesp_read_eri_text", "afesp_write_fcidump", "afesp_set_eri", "afesp_build_fock", "afesp_ccsd_t_plain",
+    "afesp_synthetic_ao", "afesp_ccsd_pp_ladder_flop", "afesp_ccsd_iteration_flop",
+    "afesp_device_count", "afesp_comm_unique_id", "afesp_comm_init", "afesp_comm_destroy", "afesp_allreduce_sum",
+    "afesp_ccsd_t_block_size", "afesp_test_inject",
 ]
+COMM_RCCL, COMM_HOST = 0, 1
 
 
 class AfespError(RuntimeError):
@@ -100,6 +104,13 @@ def load_library():
     L.afesp_write_fcidump.argtypes = [C.c_void_p, C.c_char_p, i64, C.POINTER(i64)]
     L.afesp_set_eri.argtypes = [C.c_void_p, i64, _dp]
     L.afesp_build_fock.argtypes = [C.c_void_p, i64, _dp, _dp, _dp]
+    L.afesp_device_count.argtypes = []
+    L.afesp_comm_unique_id.argtypes = [C.c_char_p]
+    L.afesp_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    L.afesp_comm_destroy.argtypes = [C.c_void_p]
+    L.afesp_allreduce_sum.argtypes = [C.c_void_p, _dp, i64]
+    L.afesp_ccsd_t_block_size.argtypes = [C.c_void_p, i64, i64, C.c_int, C.POINTER(C.c_int)]
+    L.afesp_test_inject.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L
 
@@ -231,6 +242,34 @@ class Engine:
             t_end = self.ntriples()
         self._chk(self.L.afesp_ccsd_t(self.h, t_begin, t_end, out))
         return out
+
+    # ---- multi-GPU: the OpenMP reduction of src/ccsd.f90:2091 as a sum over ranks (include/afesp.h)
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = self.L.afesp_comm_unique_id(buf)
+        if rc != 0:
+            raise AfespError(f"afesp_comm_unique_id failed with status {rc} (is librccl.so.1 loadable?)")
+        return buf.raw
+
+    def comm_init(self, rank, world, transport=COMM_RCCL, bootstrap_path=None, unique_id=None):
+        self._chk(self.L.afesp_comm_init(self.h, rank, world, transport,
+                                         None if bootstrap_path is None else str(bootstrap_path).encode(), unique_id))
+
+    def comm_destroy(self):
+        self._chk(self.L.afesp_comm_destroy(self.h))
+
+    def allreduce_sum(self, values):
+        buf = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._chk(self.L.afesp_allreduce_sum(self.h, buf, buf.size))
+        return buf
+
+    def t_block_size(self, cr=False):
+        sb = C.c_int()
+        self._chk(self.L.afesp_ccsd_t_block_size(self.h, self.o, self.v, 1 if cr else 0, C.byref(sb)))
+        return sb.value
+
+    def test_inject(self, what):
+        self._chk(self.L.afesp_test_inject(self.h, what))
 
     # ---- input / output side: src/integrals.f90:146-161, src/mp2.f90:451-487
     def read_eri_text(self, path, nbasis, want_host_copy=True):

@@ -47,8 +47,12 @@ struct Plan {
     int64_t repack_stride[6] = {0, 0, 0, 0, 0, 0};
 };
 
+struct Comm;
+
 struct Context {
     int device = 0;
+    Comm* comm = nullptr;                 // rank-to-rank sums (comm.h); null = single rank
+    int test_throw = 0;                   // test hook (afesp_test_inject): the next laned amplitude update throws
     hipStream_t stream = nullptr;
     std::vector<void*> owned;             // everything freed at destroy
     GettWorkspace ws{nullptr, 0};

@@ -8,6 +8,7 @@
 #include "../../include/afesp.h"
 #include "ccsd.h"
 #include "ccsd_so.h"
+#include "comm.h"
 
 using namespace afesp;
 
@@ -108,8 +109,13 @@ static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body 
         g.epoch = cx.scratch_epoch;
         return;
     }
+    // The capture is opened on the origin stream (lane 0).  A body that throws half-way leaves another lane selected and
+    // events outstanding: both are put back BEFORE the capture is ended, and the capture is ended on the origin stream --
+    // ending it on a lane's stream would leave lane 0 capturing for ever, and the direct run below would execute nothing.
+    cx.use_lane(0);
+    hipStream_t origin = cx.stream;
     hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(cx.stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    if (hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         g.disabled = true;
         body();
@@ -121,7 +127,9 @@ static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body 
     } catch (...) {
         ok = false;
     }
-    const hipError_t e = hipStreamEndCapture(cx.stream, &graph);
+    cx.use_lane(0);
+    cx.marks_used = 0;
+    const hipError_t e = hipStreamEndCapture(origin, &graph);
     if (ok && e == hipSuccess && graph && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess) {
         (void)hipGraphDestroy(graph);
         g.epoch = cx.scratch_epoch;
@@ -133,7 +141,19 @@ static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body 
     if (graph) (void)hipGraphDestroy(graph);
     g.exec = nullptr;
     g.disabled = true;
-    cx.use_lane(0);
+    // a failed capture (e.g. lanes left unjoined by the throw) has been invalidated by EndCapture; make sure of it
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(origin, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        throw Error(2, "afesp: the stream is still capturing after a failed graph capture");
+    }
+    for (size_t i = 1; i < cx.lanes.size(); ++i) {   // lanes that were pulled into the capture are out of it as well
+        hipStreamCaptureStatus ls = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(cx.lanes[i].stream, &ls) != hipSuccess || ls != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            throw Error(2, "afesp: a lane is still capturing after a failed graph capture");
+        }
+    }
     body();
 }
 
@@ -173,6 +193,8 @@ void afesp_ctx_destroy(afesp_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->cx.device);
     ctx->graph_cc.reset();
+    comm_destroy(ctx->cx.comm);
+    ctx->cx.comm = nullptr;
     triples_plan_free(ctx->cc);
     so_triples_plan_free(ctx->so);
     delete ctx;
@@ -352,6 +374,7 @@ int afesp_ccsd_solve(afesp_ctx* ctx, int maxiter, double e_tol, double t_tol, do
             }
             ccsd_diis_update(cx, s);
         }
+        if (result < 0 && maxiter > 0) diis_check_flag(cx, host_scalars(cx, DIIS_FLAG_SLOT + 1));   // a solve that failed after the last energy read
         if (niter) *niter = result;
     });
 }
@@ -364,7 +387,7 @@ int afesp_ccsd_get_amplitudes(afesp_ctx* ctx, double* t1, double* t2)
         AFESP_HIP(hipSetDevice(cx.device));
         if (t1) AFESP_HIP(hipMemcpyAsync(t1, ctx->cc.t1.d, sizeof(double) * ctx->cc.t1.size(), hipMemcpyDeviceToHost, cx.stream));
         if (t2) AFESP_HIP(hipMemcpyAsync(t2, ctx->cc.t2.d, sizeof(double) * ctx->cc.t2.size(), hipMemcpyDeviceToHost, cx.stream));
-        cx.sync();
+        diis_check_flag(cx, host_scalars(cx, DIIS_FLAG_SLOT + 1));   // afesp_ccsd_diis does not wait for its solve: a failure surfaces here at the latest
     });
 }
 
@@ -502,18 +525,43 @@ int afesp_read_eri_text(afesp_ctx* ctx, const char* path, int64_t nbasis, double
             while (p < lim) {
                 while (p < lim && (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n')) ++p;
                 if (p >= lim) break;
+                // list-directed input (src/integrals.f90:150 `read (ir, *) i, j, a, b, val`): fields are separated by blanks
+                // and/or one comma, a real may carry a Fortran D exponent ("1.0D-05"); whatever follows the fifth field on
+                // the record is ignored, as the reference's read does
+                auto sep = [&](char*& c) {
+                    while (c < lim && (*c == ' ' || *c == '\t' || *c == '\r')) ++c;
+                    if (c < lim && *c == ',') ++c;
+                    while (c < lim && (*c == ' ' || *c == '\t' || *c == '\r')) ++c;
+                };
                 char* q;
                 long idx[4];
                 bool ok = true;
                 for (int k = 0; k < 4 && ok; ++k) {
+                    if (*p == '\n') { ok = false; break; }
                     idx[k] = strtol(p, &q, 10);
-                    ok = (q != p);
+                    ok = (q != p) && (q >= lim || *q == ' ' || *q == '\t' || *q == ',' || *q == '\r');
                     p = q;
+                    if (ok) sep(p);
                 }
-                const double val = ok ? strtod(p, &q) : 0.0;
-                ok = ok && (q != p);
+                double val = 0.0;
+                if (ok && *p != '\n') {
+                    char tok[64];
+                    size_t len = 0;
+                    while (p + len < lim && len < sizeof(tok) - 1 && p[len] != ' ' && p[len] != '\t' && p[len] != ',' && p[len] != '\r' &&
+                           p[len] != '\n') {
+                        const char ch = p[len];
+                        tok[len] = (ch == 'D' || ch == 'd') ? 'E' : ch;
+                        ++len;
+                    }
+                    tok[len] = 0;
+                    char* tq = nullptr;
+                    val = strtod(tok, &tq);
+                    ok = len > 0 && tq == tok + len;   // the whole token is the number
+                    p += len;
+                } else {
+                    ok = false;
+                }
                 if (!ok) { bad = true; break; }
-                p = q;
                 for (int k = 0; k < 4; ++k)
                     if (idx[k] < 1 || idx[k] > nbasis) ok = false;
                 if (!ok) { bad = true; break; }
@@ -966,6 +1014,73 @@ int afesp_time_pp_ladder(afesp_ctx* ctx, int reps, double* ms_per_launch)
         (void)hipEventDestroy(a);
         (void)hipEventDestroy(b);
     });
+}
+
+// ---------------------------------------------------------------- multi-GPU: the sum over ranks (comm.h)
+int afesp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int afesp_comm_unique_id(char id_out[128])
+{
+    if (!id_out) return 1;
+    try {
+        comm_unique_id(id_out);
+        return 0;
+    } catch (const Error& e) {
+        return e.code ? e.code : 1;
+    } catch (...) {
+        return 1;
+    }
+}
+
+int afesp_comm_init(afesp_ctx* ctx, int rank, int world, int transport, const char* bootstrap_path, const char* unique_id)
+{
+    return guarded(ctx, [&] {
+        Context& cx = ctx->cx;
+        AFESP_HIP(hipSetDevice(cx.device));
+        if (cx.comm) throw Error(1, "afesp_comm_init: this context already has a communicator");
+        cx.comm = comm_create(cx, rank, world, transport, bootstrap_path, unique_id);
+        ctx->graph_cc.reset();   // a captured iteration does not contain the rank split
+    });
+}
+
+int afesp_comm_destroy(afesp_ctx* ctx)
+{
+    return guarded(ctx, [&] {
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        ctx->cx.sync();
+        comm_destroy(ctx->cx.comm);
+        ctx->cx.comm = nullptr;
+        ctx->graph_cc.reset();
+    });
+}
+
+int afesp_allreduce_sum(afesp_ctx* ctx, double* inout, int64_t n)
+{
+    return guarded(ctx, [&] {
+        if (n < 0 || (n > 0 && !inout)) throw Error(1, "afesp_allreduce_sum: bad arguments");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        if (!ctx->cx.comm) return;   // single rank: the sum over one rank
+        comm_allreduce_host(ctx->cx, ctx->cx.comm, inout, n);
+    });
+}
+
+int afesp_ccsd_t_block_size(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr, int* block_size)
+{
+    return guarded(ctx, [&] {
+        if (nocc < 1 || nvirt < 1 || !block_size) throw Error(1, "afesp_ccsd_t_block_size: bad arguments");
+        AFESP_HIP(hipSetDevice(ctx->cx.device));
+        *block_size = triples_block_size((int)nocc, (int)nvirt, cr != 0);
+    });
+}
+
+int afesp_test_inject(afesp_ctx* ctx, int what)
+{
+    return guarded(ctx, [&] { ctx->cx.test_throw = what; });
 }
 
 }  // extern "C"

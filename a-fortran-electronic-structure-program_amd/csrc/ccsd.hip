@@ -115,6 +115,10 @@ void ccsd_free(Context& cx, CCState& s)
                       s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d, s.pp, (double*)s.pp_tab, s.pp_vs, s.pp_va, s.pp_cs,
                       s.pp_ca, s.pp_ps, s.pp_pa, s.bmat, s.ov_ws, s.ov_wa};
     for (double* b : bufs) cx.release(b);
+    // contraction plans of the previous system: their offset tables are device memory too
+    for (auto& kv : cx.plans)
+        if (!kv.second.repack) cx.release(kv.second.offAm);
+    cx.plans.clear();
     cx.drop_scratch();
     triples_plan_free(s);
     s = CCState();
@@ -332,6 +336,10 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     C(1.0, s.asym, "miea", s.I_vo, "em", 1.0, s.r1, "ia");
     C(2.0, s.v_oovv, "miea", s.t1, "me", 1.0, s.r1, "ia");
     lane(5);
+    if (par && cx.test_throw == 1) {   // test hook (afesp_test_inject): a failure in the middle of the laned update
+        cx.test_throw = 0;
+        throw Error(99, "injected failure (afesp_test_inject)");
+    }
     C(-1.0, s.v_ovov, "maie", s.t1, "me", par ? 0.0 : 1.0, r1b, "ia");
     C(-1.0, s.v_oovo, "mien", s.asym, "mnea", 1.0, r1b, "ia");
     C(1.0, s.asym, "mief", s.v_vvov, "efma", 1.0, r1b, "ia");

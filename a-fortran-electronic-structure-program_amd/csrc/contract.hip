@@ -264,6 +264,9 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
         key += ";";
     };
     sig(A0); sig(B0); sig(C);
+    // the re-layout decision below depends on these as well: a shape first seen unbatched must not hand its plan to a batched call
+    key += (nbatch > 1 || bA0 || bB0) ? "|b" : "|u";
+    key += cx.in_repack ? "r" : "-";
     auto it = cx.plans.find(key);
     if (it == cx.plans.end()) {
         // orientation: the kernel's column index n runs along lanes in the epilogue -> put C's fastest label in N

@@ -465,7 +465,7 @@ static void launch_one(const GettKernelArgs& a, dim3 grid, hipStream_t st)
     int per = cap / (int)(grid.y * grid.z);
     if (per < 1) per = 1;
     if (g_dbg & 2) per = 1 << 30;   // measurement only: one tile per workgroup
-    if (g_dbg & 4) per = per / 4 > 0 ? per / 4 : 1;   // measurement only: a quarter of the device (tools/burst_test.py)
+    if (g_dbg & 4) per = per / 4 > 0 ? per / 4 : 1;   // measurement only: a quarter of the device (tools/burst_probe.py)
     if ((int)grid.x > per) grid.x = (unsigned)per;
     hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG>), grid, dim3(64 * WM * WN), 0, st, a);
 }

@@ -577,6 +577,8 @@ void triples_shard_bounds(int o, int v, bool cr, int world, int64_t* bounds)
     }
 }
 
+int triples_block_size(int o, int v, bool cr) { return fused_block_size(o, v, cr, device_pool_budget()); }
+
 void triples_plan_free(CCState& s)
 {
     delete (TriplesPlan*)s.tplan;

@@ -8,7 +8,11 @@ module afesp_capi
              afesp_ccsd_iterate, afesp_ccsd_diis, afesp_ccsd_get_amplitudes, afesp_ccsd_t, afesp_ccsd_t_ntriples, &
              afesp_neri, afesp_error_text, afesp_ccsd_cr_intermediates, afesp_ccsd_t_cr, afesp_ccsd_so_init, &
              afesp_ccsd_so_energy, afesp_ccsd_so_iterate, afesp_ccsd_so_diis, afesp_ccsd_so_t, afesp_ccsd_so_t_ntriples, &
-             afesp_read_eri_text, afesp_write_fcidump, afesp_build_fock, afesp_ccsd_t_plain
+             afesp_read_eri_text, afesp_write_fcidump, afesp_build_fock, afesp_ccsd_t_plain, afesp_device_count, &
+             afesp_comm_init, afesp_comm_destroy, afesp_allreduce_sum, afesp_ccsd_t_shard_bounds, afesp_ccsd_t_block_size, &
+             AFESP_COMM_RCCL, AFESP_COMM_HOST
+
+   integer(c_int), parameter :: AFESP_COMM_RCCL = 0, AFESP_COMM_HOST = 1
 
    interface
       function afesp_ctx_create(device, ctx) bind(C, name='afesp_ctx_create') result(rc)
@@ -194,6 +198,48 @@ module afesp_capi
          type(c_ptr), value :: ctx
          integer(c_int64_t), value :: t_begin, t_end
          real(c_double), intent(out) :: e_t
+         integer(c_int) :: rc
+      end function
+      !> ---- multi-GPU: one process per GPU; the OpenMP reduction of the reference's (T) loop (src/ccsd.f90:2091) becomes a
+      !> sum over ranks
+      function afesp_device_count() bind(C, name='afesp_device_count') result(n)
+         import :: c_int
+         integer(c_int) :: n
+      end function
+      function afesp_comm_init(ctx, rank, world, transport, bootstrap_path, unique_id) bind(C, name='afesp_comm_init') result(rc)
+         import :: c_int, c_ptr, c_char
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: rank, world, transport
+         character(kind=c_char), intent(in) :: bootstrap_path(*)
+         type(c_ptr), value :: unique_id              ! c_null_ptr: the id travels through bootstrap_path
+         integer(c_int) :: rc
+      end function
+      function afesp_comm_destroy(ctx) bind(C, name='afesp_comm_destroy') result(rc)
+         import :: c_int, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int) :: rc
+      end function
+      function afesp_allreduce_sum(ctx, inout, n) bind(C, name='afesp_allreduce_sum') result(rc)
+         import :: c_int, c_int64_t, c_double, c_ptr
+         type(c_ptr), value :: ctx
+         real(c_double), intent(inout) :: inout(*)
+         integer(c_int64_t), value :: n
+         integer(c_int) :: rc
+      end function
+      function afesp_ccsd_t_shard_bounds(ctx, nocc, nvirt, cr, world, bounds) bind(C, name='afesp_ccsd_t_shard_bounds') result(rc)
+         import :: c_int, c_int64_t, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int64_t), value :: nocc, nvirt
+         integer(c_int), value :: cr, world
+         integer(c_int64_t), intent(out) :: bounds(*)
+         integer(c_int) :: rc
+      end function
+      function afesp_ccsd_t_block_size(ctx, nocc, nvirt, cr, block_size) bind(C, name='afesp_ccsd_t_block_size') result(rc)
+         import :: c_int, c_int64_t, c_ptr
+         type(c_ptr), value :: ctx
+         integer(c_int64_t), value :: nocc, nvirt
+         integer(c_int), value :: cr
+         integer(c_int), intent(out) :: block_size
          integer(c_int) :: rc
       end function
    end interface

@@ -396,13 +396,34 @@ program els_amd
    real(dp) :: e_hf, e_mp2, e_ccsd, energy, eold, rms, tq(6), t0, t1s, tstart, t1diag, e_highest
    real(dp) :: e_bt, e_pt, e_rbt, e_rpt, e_crbt, e_crpt
    integer(c_int) :: rc, conv
-   integer :: iter, device
+   integer :: iter, device, rank, world, transport, sb
+   integer(c_int64_t), allocatable :: bounds(:)
+   integer(c_int64_t) :: t_lo, t_hi
+   real(dp) :: red(8)
+   character(len=512) :: comm_file
    logical :: scf_ok, cc_ok, compat, have_ctx
    integer(c_int64_t) :: nlines
    character(len=32) :: envval
    character(len=80) :: calcname
 
    tstart = seconds()
+   ! Rank mode (one process per GPU, started by host/els_mgpu.sh or any launcher that sets these): AFESP_RANK / AFESP_WORLD,
+   ! AFESP_COMM = rccl (default) | host, AFESP_COMM_FILE = bootstrap file unique to the job.  Every rank runs the calculation
+   ! (RHF, AO->MO and the CCSD iterations as replicas); the (T) triples are split over the ranks and summed with one
+   ! all-reduce, where the reference's OpenMP reduction sits (src/ccsd.f90:2091).  Only rank 0 prints.
+   rank = 0; world = 1; transport = AFESP_COMM_RCCL; comm_file = ''
+   call get_environment_variable('AFESP_WORLD', envval)
+   if (len_trim(envval) > 0) read (envval, *) world
+   call get_environment_variable('AFESP_RANK', envval)
+   if (len_trim(envval) > 0) read (envval, *) rank
+   if (world < 1 .or. rank < 0 .or. rank >= world) call fail('main', 'AFESP_RANK / AFESP_WORLD are inconsistent')
+   if (world > 1) then
+      call get_environment_variable('AFESP_COMM', envval)
+      if (trim(envval) == 'host') transport = AFESP_COMM_HOST
+      call get_environment_variable('AFESP_COMM_FILE', comm_file)
+      if (len_trim(comm_file) == 0) call fail('main', 'AFESP_WORLD > 1 needs AFESP_COMM_FILE (a bootstrap file unique to the job)')
+      if (rank > 0) open (unit=out, file='/dev/null', action='write')     ! rank 0 owns stdout
+   end if
    write (out, '(1X, 64("="))')
    write (out, '(1X, A)') 'A Fortran Electronic Structure Programme (AFESP) -- MI355X engine host'
    write (out, '(1X, 64("="))')
@@ -413,10 +434,16 @@ program els_amd
    call read_molecule(mol, have_ctx)
    if (have_ctx) then
       device = 0
+      if (world > 1 .and. afesp_device_count() > 0) device = mod(rank, int(afesp_device_count()))   ! one GPU per rank
       call get_environment_variable('AFESP_DEVICE', envval)
       if (len_trim(envval) > 0) read (envval, *) device
       rc = afesp_ctx_create(int(device, c_int), ctx)
       if (rc /= 0) call fail('main', 'no usable MI355X device: afesp_ctx_create failed (the engine has no CPU fallback)')
+      if (world > 1) then
+         rc = afesp_comm_init(ctx, int(rank, c_int), int(world, c_int), int(transport, c_int), trim(comm_file)//c_null_char, c_null_ptr)
+         if (rc /= 0) call fail('main', afesp_error_text(ctx))
+         write (out, '(1X, A, I0, A, A)') 'Ranks: ', world, ', transport ', merge('host', 'rccl', transport == AFESP_COMM_HOST)
+      end if
       rc = afesp_read_eri_text(ctx, 'eri.dat'//c_null_char, int(mol%nbasis, c_int64_t), mol%eri, nlines)
       if (rc /= 0) call fail('integrals::read_integrals_in', afesp_error_text(ctx))
       write (out, *) 'Done reading integrals!'
@@ -507,7 +534,10 @@ program els_amd
             ! ---------------- spin-orbital (T) (reference do_ccsd_t_spinorb, src/ccsd.f90:1812-1922)
             t0 = seconds()
             write (out, '(1X, 10("-"))'); write (out, '(1X, A)') 'CCSD(T)'; write (out, '(1X, 10("-"))')
-            rc = afesp_ccsd_so_t(ctx, 0_c_int64_t, afesp_ccsd_so_t_ntriples(int(mol%nel, c_int64_t)), tq(1))
+            t_hi = afesp_ccsd_so_t_ntriples(int(mol%nel, c_int64_t))     ! i<j<k triples, an even split over the ranks
+            t_lo = (int(rank, c_int64_t)*t_hi)/world; t_hi = (int(rank + 1, c_int64_t)*t_hi)/world
+            rc = afesp_ccsd_so_t(ctx, t_lo, t_hi, tq(1))
+            if (rc == 0 .and. world > 1) rc = afesp_allreduce_sum(ctx, tq, 1_c_int64_t)
             if (rc /= 0) call fail('ccsd::do_ccsd_t_spinorb', afesp_error_text(ctx))
             e_pt = e_ccsd + tq(1)
             e_highest = e_pt
@@ -567,15 +597,31 @@ program els_amd
          write (out, '(1X, A, 1X, F16.8, A)') 'Time taken for restricted CCSD:', seconds() - t0, 's'
 
          if (cfg%level == LEVEL_CCSD_T .and. cc_ok) then
-            ! ---------------- (T) (reference do_ccsd_t_spatial): whole (i<=j<=k) range on this GPU
+            ! ---------------- (T) (reference do_ccsd_t_spatial): this rank's shard of the (i<=j<=k) list, then one sum over ranks
             t0 = seconds()
             write (out, '(1X, 10("-"))'); write (out, '(1X, A)') 'CCSD(T)'; write (out, '(1X, 10("-"))')
+            ! this rank's shard of the (i<=j<=k) list (the whole list for one rank); the ranks must enumerate the triples in
+            ! the same order, i.e. agree on the occupied block size: it rides along in the all-reduce
+            allocate (bounds(world + 1))
+            rc = afesp_ccsd_t_shard_bounds(ctx, int(mol%nocc, c_int64_t), int(mol%nvirt, c_int64_t), &
+                                           merge(1_c_int, 0_c_int, cfg%comp_renorm), int(world, c_int), bounds)
+            if (rc /= 0) call fail('ccsd::do_ccsd_t_spatial', afesp_error_text(ctx))
+            t_lo = bounds(rank + 1); t_hi = bounds(rank + 2)
             if (cfg%comp_renorm) then
-               rc = afesp_ccsd_t_cr(ctx, 0_c_int64_t, afesp_ccsd_t_ntriples(int(mol%nocc, c_int64_t)), tq)
+               rc = afesp_ccsd_t_cr(ctx, t_lo, t_hi, tq)
             else if (cfg%renorm) then
-               rc = afesp_ccsd_t(ctx, 0_c_int64_t, afesp_ccsd_t_ntriples(int(mol%nocc, c_int64_t)), tq(1:4))
+               rc = afesp_ccsd_t(ctx, t_lo, t_hi, tq(1:4))
             else                               ! plain types: no y, no D sums (reference src/ccsd.f90:2181-2185)
-               rc = afesp_ccsd_t_plain(ctx, 0_c_int64_t, afesp_ccsd_t_ntriples(int(mol%nocc, c_int64_t)), tq(1:2))
+               rc = afesp_ccsd_t_plain(ctx, t_lo, t_hi, tq(1:2))
+            end if
+            if (rc == 0 .and. world > 1) then  ! the reference's reduction(+: ...) over threads, src/ccsd.f90:2091
+               rc = afesp_ccsd_t_block_size(ctx, int(mol%nocc, c_int64_t), int(mol%nvirt, c_int64_t), &
+                                            merge(1_c_int, 0_c_int, cfg%comp_renorm), sb)
+               red(1:6) = tq; red(7) = real(sb, dp); red(8) = real(sb, dp)**2
+               if (rc == 0) rc = afesp_allreduce_sum(ctx, red, 8_c_int64_t)
+               if (rc == 0 .and. abs(red(8)*world - red(7)**2) > 0.5_dp) &
+                  call fail('ccsd::do_ccsd_t_spatial', 'the ranks enumerate the triples in different block sizes (unequal devices or AFESP_T_* settings)')
+               tq = red(1:6)
             end if
             if (rc /= 0) call fail('ccsd::do_ccsd_t_spatial', afesp_error_text(ctx))
             ! The reference's plain CCSD(T)_spatial never fills z3_bar (src/ccsd.f90:2211-2215) and therefore prints
@@ -607,7 +653,10 @@ program els_amd
    else if (scf_ok) then
       e_highest = 0.0_dp
    end if
-   if (have_ctx) call afesp_ctx_destroy(ctx)
+   if (have_ctx) then
+      if (world > 1) rc = afesp_comm_destroy(ctx)
+      call afesp_ctx_destroy(ctx)
+   end if
 
    ! ---------------- final table: same labels and formats as the reference (src/main.F90:123-175)
    write (out, '(1X, 64("="))')

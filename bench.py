@@ -8,16 +8,24 @@ One "step" = one pass of the hot path over one system held in HBM:
 Inputs are generated on the device (afesp_synthetic_init); nothing crosses PCIe inside the timed region.
 
 Workloads (BASELINE.json configs):
+  cfg5    config 5: synthetic o=20, v=200 -- the largest single-GPU configuration and the only one where the fp64 MFMA roofline
+          means anything: the default, and what `value` is quoted on
   h2o_tz  config 2 shape: H2O/cc-pVTZ extents o=5, v=53 (its eri.dat is not bundled -> synthetic integrals)
-  cfg5    config 5: synthetic o=20, v=200
-  n2      config 3 extents o=7, v=21 (synthetic integrals; the real N2 inputs are exercised by tests/)
-value = algorithmic fp64 FLOP of the step / step time, summed over the job (strong scaling: total work fixed).
+  n2      config 3 extents o=7, v=21 (synthetic integrals; the real N2 / F2 inputs run in the `real_molecules_same_run` leg)
+value = algorithmic fp64 FLOP of the step (SURVEY.md 8(d), (T) counted over i<=j<=k as it is evaluated) / step time, summed over
+the job (strong scaling: total work fixed); `value_executed` counts only the multiply-adds the kernels issue.
+
+`--gpus N` without a launcher (WORLD_SIZE unset): this process starts N ranks of itself -- before anything touches the GPU -- and
+waits for them; under torchrun (WORLD_SIZE set) it must equal the world size.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -271,7 +279,64 @@ def real_molecule(name, rank, world, local, dist, cdev, torch):
 DEFAULT_SCALE = {"cfg5": 0.005}     # magnitude of the hashed integrals: keeps the first iterates of every workload finite
 
 
-def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch, with_roofline=True):
+class Reducer:
+    """The one collective of the path: the sum over ranks of the (T) partial scalars.  It goes through the product's own
+    C-ABI (afesp_comm_init / afesp_allreduce_sum: ncclAllReduce on the engine's stream, or the host segment when the ranks of a
+    rehearsal share one GPU); the RCCL unique id travels by a torch.distributed broadcast.  If the C-ABI communicator cannot be
+    set up the sum falls back to torch.distributed -- the line says which one ran (`t_allreduce`)."""
+
+    def __init__(self, eng, rank, world, dist, cdev, torch, backend, jobdir):
+        self.eng, self.world, self.dist, self.cdev, self.torch = eng, world, dist, cdev, torch
+        self.kind = "none (one rank)"
+        if world == 1:
+            return
+        from afesp_amd import capi
+        try:
+            if backend == "gloo":
+                eng.comm_init(rank, world, capi.COMM_HOST, os.path.join(jobdir, f"afesp_seg_{Reducer.count}"))
+                self.kind = "afesp_allreduce_sum (host segment: ranks share a GPU)"
+            else:
+                box = [eng.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                eng.comm_init(rank, world, capi.COMM_RCCL, None, box[0])
+                self.kind = "afesp_allreduce_sum (ncclAllReduce on the engine stream)"
+            self.own = True
+        except Exception as exc:   # noqa: BLE001 -- any failure here must not lose the measurement
+            self.own = False
+            self.kind = f"torch.distributed.all_reduce (afesp_comm_init failed: {exc})"
+        Reducer.count += 1
+        # every rank must have taken the same branch
+        flag = torch.tensor([1.0 if self.own else 0.0], dtype=torch.float64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if self.own and float(flag.cpu()[0]) == 0.0:
+            eng.comm_destroy()
+            self.own = False
+            self.kind = "torch.distributed.all_reduce (afesp_comm_init failed on another rank)"
+
+    count = 0
+
+    def sum(self, values):
+        if self.world == 1:
+            return np.asarray(values, dtype=np.float64)
+        if self.own:
+            return self.eng.allreduce_sum(values)
+        t = self.torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64)).to(self.cdev)
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    def close(self):
+        if self.world > 1 and getattr(self, "own", False):
+            self.eng.comm_destroy()
+
+
+def latest_profile(pattern):
+    """Newest profiles/rNN_<pattern> file (the PMC passes are separate rocprofv3 runs of this same command, tools/refresh_profiles.sh)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + pattern)))
+    return files[-1] if files else None
+
+
+def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch, jobdir, with_roofline=True, with_cpu=True):
     """Run `warmup` untimed + `steps` timed steps of one workload; returns the result dictionary (rank 0) or None."""
     from afesp_amd.capi import Engine
     o, v = WORKLOADS[workload]
@@ -282,7 +347,12 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
     eng.ccsd_energy()                                   # the "MP1" line: primes t2_old
     nt = eng.ntriples()
     lo, hi = eng.shard_bounds(world)[rank:rank + 2]     # contiguous shard of the i<=j<=k list, balanced by cost
-    red = torch.zeros(4, dtype=torch.float64, device=cdev)
+    red = Reducer(eng, rank, world, dist, cdev, torch, args.backend, jobdir)
+    sb = float(eng.t_block_size())                      # the ranks must enumerate the triples in the same block order
+    chk = red.sum([1.0, sb, sb * sb])
+    rccl_ranks = int(round(chk[0]))
+    if abs(chk[2] * world - chk[1] ** 2) > 0.5 or rccl_ranks != world:
+        raise SystemExit(f"bench.py: ranks disagree (ranks summed {chk[0]}, (T) block sizes sum {chk[1]}, squares {chk[2]})")
 
     def barrier():
         if dist is not None:
@@ -297,14 +367,8 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
         eng.ccsd_diis()
         t1 = time.perf_counter()
         # the benchmark configurations are CCSD(T)_spatial: E[T] and E(T) (the renormalised types' y / D sums are extra)
-        part = np.zeros(4)
-        part[:2] = eng.do_ccsd_t_spatial_plain(lo, hi)
-        if dist is not None:
-            red.copy_(torch.from_numpy(part))
-            dist.all_reduce(red)                        # the only collective of the path: 4 doubles over xGMI
-            acc["last"] = red.cpu().numpy()
-        else:
-            acc["last"] = part                          # one rank: nothing to reduce, no device round trip
+        part = eng.do_ccsd_t_spatial_plain(lo, hi)
+        acc["last"] = red.sum(part)                     # the only collective of the path: 2 doubles over xGMI
         t2 = time.perf_counter()
         if timed:
             acc["iter"] += t1 - t0
@@ -321,11 +385,17 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
     elapsed = time.perf_counter() - t0
     prof = eng.profile(False)
     tt = torch.tensor([elapsed, acc["iter"], acc["trip"]], dtype=torch.float64, device=cdev)
+    ex = torch.tensor([prof["gemm_flop"]], dtype=torch.float64, device=cdev)   # executed (T) multiply-adds of this rank's shard
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ex)
     elapsed, t_iter, t_trip = [float(x) for x in tt.cpu()]
     sec_per_step = elapsed / steps
-    flop_step = int(eng.iteration_flop()) + flops_t_sym(o, v)     # the iteration as the engine evaluates it (pair forms counted as executed)
+    it_flop = int(eng.iteration_flop())     # the iteration as the engine evaluates it (pair forms counted as executed)
+    flop_step = it_flop + flops_t_sym(o, v)
+    # executed: the (T) GEMMs evaluate o x o(o+1)/2 distinct blocks of 4 v^3 (v+o) flop (half of that where the occupied pair
+    # coincides) instead of the symmetric count's 12 v^3 (v+o) per i<=j<=k triple; the CCSD iteration is replicated per rank
+    flop_exec = it_flop * world + float(ex.cpu()[0]) / steps
     res = None
     if rank == 0:
         res = {
@@ -335,11 +405,17 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
                        "nocc": o, "nvirt": v, "triples": int(nt), "parallelism": f"(T) ijk-shard x{world}, CCSD replicas"},
             "ccsd_iter_s": t_iter / steps, "t_s": t_trip / steps, "flop_per_step": flop_step,
             "fraction_of_mfma_peak": flop_step / sec_per_step / 1e12 / (MFMA_F64_PEAK_TFLOPS * world),
-            "e_t": [float(x) for x in acc["last"]],
+            "flop_per_step_executed": flop_exec,
+            "value_executed": flop_exec / sec_per_step / 1e12,
+            "fraction_of_mfma_peak_executed": flop_exec / sec_per_step / 1e12 / (MFMA_F64_PEAK_TFLOPS * world),
+            "rates_note": "value / fraction_of_mfma_peak: SURVEY 8(d) algorithmic count ((T) = [o(o+1)(o+2)/6] 12 v^3 (v+o)); "
+                          "value_executed / fraction_of_mfma_peak_executed: multiply-adds the kernels issue, all ranks",
+            "e_t": [float(x) for x in acc["last"]], "rccl_ranks": rccl_ranks, "t_allreduce": red.kind,
         }
         if with_roofline:
             # Dominant kernel: the (T) GEMM (gett_kernel, X = tt^T vt over kappa = d + l, K = v+o), timed over the timed
-            # region with HIP events on the engine's stream (csrc/triples.hip).  Algorithmic flop per launch = 2 M N K.
+            # region with HIP events on the engine's stream (csrc/triples.hip).  achieved = EXECUTED flop per launch
+            # (2 M N K of the products it runs) / its average duration.
             nl = max(prof["gemm_launches"], 1)
             roof = {"bound": "mfma", "achieved": prof["gemm_flop"] / max(prof["gemm_ms"], 1e-9) / 1e9,
                     "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s"}
@@ -352,12 +428,13 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             roof["ms_per_launch"] = prof["gemm_ms"] / nl
             roof["flop_per_launch"] = prof["gemm_flop"] / nl
             roof["share_of_step_time"] = prof["gemm_ms"] * 1e-3 / elapsed
-            tfile = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tfile):
+            tfile = latest_profile("traffic.json")
+            if tfile:
                 tr = json.load(open(tfile)).get(workload + "_t_gemm")
                 if tr:
                     roof["traffic"] = tr["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = tr["command"]
+                    roof["traffic_source"] = (os.path.relpath(tfile, ROOT) + ": separate rocprofv3 --pmc passes of this command (FETCH_SIZE x2 "
+                                              "per the gfx950 correction, WRITE_SIZE); " + tr["command"])
                     if "mfma_busy_frac" in tr:
                         roof["mfma_busy"] = tr["mfma_busy_frac"]     # MFMA-pipe busy fraction (PMC), same passes
             second = {"kernel": "triples_orbit_kernel", "bound": "hbm",
@@ -371,32 +448,68 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             res["pp_ladder"] = {"ms_per_launch": ms_lad, "tflops_executed": eng.pp_ladder_flop() / (ms_lad * 1e-3) / 1e12,
                                 "tflops_reference_equivalent": 2 * o**2 * v**4 / (ms_lad * 1e-3) / 1e12,
                                 "algorithmic_gbs": 8 * (v**3 * (v + 1) / 2 + 2 * o**2 * v**2) / (ms_lad * 1e-3) / 1e9}
-            res["ao2mo"] = time_ao2mo(eng, o, v, 21 if o * v < 2000 else 3)
-        if args.cpu_baseline and with_roofline and world == 1:   # rank 0 at N = 1 only
+            res["ao2mo"] = time_ao2mo(eng, o, v, 21 if o * v < 2000 else 5)
+        if args.cpu_baseline and with_cpu and world == 1:   # rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(o, v, scale, seed, eng)
+            res["cpu_baseline"]["vs_gpu_step"] = res["cpu_baseline"]["value"] / sec_per_step
     barrier()
+    red.close()
     eng.close()
     return res
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """`--gpus N` with no launcher: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torchrun would)
+    and wait for them.  Runs before this process has imported torch or touched the GPU; nothing is exec'ed."""
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    jobdir = tempfile.mkdtemp(prefix="afesp_bench_")
+    env["AFESP_BENCH_JOBDIR"] = jobdir
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + sys.argv[1:],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(n)]
+    codes = [p.wait() for p in procs]
+    try:
+        for f in os.listdir(jobdir):
+            os.unlink(os.path.join(jobdir, f))
+        os.rmdir(jobdir)
+    except OSError:
+        pass
+    return next((c for c in codes if c != 0), 0)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)     # a step of the default workload is < 1 ms: 5 steps are noise
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="h2o_tz", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=5)      # a config-5 step is ~0.5 s
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg5", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", dest="cpu_baseline", action="store_false")
     ap.add_argument("--no-extra", dest="extra", action="store_false",
-                    help="skip the additional measurements appended to the line: config 5 (o=20, v=200) and the bundled "
-                         "N2 / F2 inputs (configs 3 / 4) with their energy check")
+                    help="skip the additional measurements appended to the line: the H2O/cc-pVTZ shape (config 2), the bundled "
+                         "N2 / F2 inputs (configs 3 / 4) with their energy check, the spin-orbital H2O/cc-pVTZ shape")
     ap.add_argument("--scale", type=float, default=None)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the multi-rank path on a one-GPU box")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); refusing to "
+                         "report a line for a different number of GPUs than asked for")
+    jobdir = os.environ.get("AFESP_BENCH_JOBDIR") or os.path.join(tempfile.gettempdir(), "afesp_bench_" + os.environ.get("MASTER_PORT", "0"))
+    os.makedirs(jobdir, exist_ok=True)
     import torch
     dist = None
     if world > 1:
@@ -411,29 +524,28 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(local)
-    cdev = "cpu" if (world > 1 and args.backend == "gloo") else f"cuda:{local}"   # where the collectives run
+    cdev = "cpu" if (world > 1 and args.backend == "gloo") else f"cuda:{local}"   # where torch's collectives run
 
-    res = measure(args, args.workload, args.steps, args.warmup, rank, world, local, dist, cdev, torch)
-    extra = None
-    if args.extra and args.workload != "cfg5":
-        # the only configuration where the fp64 MFMA roofline is meaningful: config 5, one step
-        extra = measure(args, "cfg5", 1, 1, rank, world, local, dist, cdev, torch, with_roofline=True)
-    molecules_leg = None
+    res = measure(args, args.workload, args.steps, args.warmup, rank, world, local, dist, cdev, torch, jobdir)
+    others = {}
     if args.extra:
-        molecules_leg = {name: real_molecule(name, rank, world, local, dist, cdev, torch) for name in ("n2-cc-pvdz", "f2-cc-pvdz")}
-        spinorb_leg = spinorb_h2o_tz(rank, world, local, dist, cdev, torch)
+        if args.workload != "h2o_tz":
+            # BASELINE config 2 shape: a step is ~0.6 ms, latency-bound (no roofline meaning): 50 steps
+            others["h2o_tz_same_run"] = measure(args, "h2o_tz", 50, 5, rank, world, local, dist, cdev, torch, jobdir,
+                                                with_roofline=True, with_cpu=True)
+        others["real_molecules_same_run"] = {name: real_molecule(name, rank, world, local, dist, cdev, torch)
+                                             for name in ("n2-cc-pvdz", "f2-cc-pvdz")}
+        others["spinorb_h2o_tz_same_run"] = spinorb_h2o_tz(rank, world, local, dist, cdev, torch)
     if rank == 0:
         line = {"metric": "CCSD iter wall-time (s) + (T) wall-time (s); fp64 TFLOP/s vs MFMA peak",
                 "value": res.pop("value"), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "f64", "data": "synthetic"}
         line.update(res)
-        if extra is not None:
-            extra.pop("cpu_baseline", None)
-            line["config5_same_run"] = dict(extra, unit="TFLOP/s", steps=1, warmup=1)
-        if molecules_leg is not None:
-            line["real_molecules_same_run"] = molecules_leg
-            line["spinorb_h2o_tz_same_run"] = spinorb_leg
+        for key, val in others.items():
+            if key == "h2o_tz_same_run" and val is not None:
+                val = dict(val, unit="TFLOP/s", steps=50, warmup=5)
+            line[key] = val
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

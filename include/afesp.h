@@ -140,6 +140,38 @@ int afesp_ccsd_so_get_tensor(afesp_ctx* ctx, const char* name, double* out, int6
 int64_t afesp_ccsd_so_t_ntriples(int64_t nocc);
 int afesp_ccsd_so_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double* e_t);
 
+/* ---- Multi-GPU: one process per GPU, each with its own context.  The reference has no distributed layer;
+ * its (T) loop ends in an OpenMP `reduction(+: ...)` over threads (src/ccsd.f90:2091, entered from src/main.F90:112).  Here
+ * every rank evaluates its shard [bounds[r], bounds[r+1]) of the triple list (afesp_ccsd_t_shard_bounds) and that
+ * reduction becomes ONE sum over the ranks of the 2...6 partial scalars: afesp_allreduce_sum.
+ *   transport AFESP_COMM_RCCL: ncclAllReduce(sum, fp64) on the context's stream (xGMI between the GPUs of a node); librccl is
+ *             opened on the first call, a single-rank run never needs it.
+ *   transport AFESP_COMM_HOST: ranks of one node add through a file-backed shared segment in a fixed rank order.  For
+ *             rehearsing the rank logic where ranks SHARE a GPU (RCCL refuses two ranks on one device); host memory only.
+ *   bootstrap_path: a file name in a directory every rank sees, unique to this job (the launcher makes it): rank 0 publishes
+ *             the RCCL unique id there / it backs the shared segment; removed once every rank has joined.  With
+ *             unique_id != NULL (128 bytes from afesp_comm_unique_id on rank 0, distributed by the caller -- bench.py
+ *             broadcasts it through torch.distributed) no file is used.
+ * After afesp_comm_init with world > 1 the CCSD iteration of this context also splits its large products over the ranks
+ * (column panels of the o^3 v^3 ring terms and of the pair-form ladder) and sums the T2 residual with one all-reduce per
+ * iteration; every rank must then make the same sequence of afesp_ccsd_* calls. */
+#define AFESP_COMM_RCCL 0
+#define AFESP_COMM_HOST 1
+int afesp_device_count(void);
+int afesp_comm_unique_id(char id_out[128]);
+int afesp_comm_init(afesp_ctx* ctx, int rank, int world, int transport, const char* bootstrap_path, const char* unique_id);
+int afesp_comm_destroy(afesp_ctx* ctx);
+/* in-place sum over the ranks of n host doubles (every rank passes the same n) */
+int afesp_allreduce_sum(afesp_ctx* ctx, double* inout, int64_t n);
+/* Occupied block size of the (T) triple enumeration on this rank's device (it depends on the device memory size and on the
+ * AFESP_T_POOL_GIB / AFESP_T_SPLIT_TILES environment): ranks whose values differ would enumerate different flat orders, so
+ * callers compare it across ranks before sharding (bench.py and els_amd put it into their first all-reduce). */
+int afesp_ccsd_t_block_size(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr, int* block_size);
+
+/* Test hook: what = 1 makes the next laned (small-system) amplitude update throw once, from a lane other than the main one
+ * -- the failure mode of a capture that dies half-way (tests/test_gpu_cc.py). */
+int afesp_test_inject(afesp_ctx* ctx, int what);
+
 /* Operator layer (src/linalg.fpp), exported for parity tests against the oracle.
  * afesp_gemm    = dgemm_wrapper (src/linalg.fpp:58-89): C(m x n) = alpha op(A) op(B) + beta C, host arrays.
  * afesp_permute4 = omp_reshape (src/linalg.fpp:99-156): out(perm) = beta*out + in; has_beta=0 zeroes `out` first. */

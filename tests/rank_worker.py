@@ -1,0 +1,48 @@
+"""One rank of a multi-process run of the Engine (started by tests/test_gpu_ranks.py, one process per rank).
+
+argv: rank world transport(host|rccl) bootstrap_path molecule result_path
+Every rank runs the replica part (AO->MO, CCSD to convergence); the (T) triples are split by Engine.shard_bounds and summed with
+the product's own all-reduce (afesp_allreduce_sum).  The rank writes what it saw as JSON."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "a-fortran-electronic-structure-program_amd"))
+
+
+def main():
+    rank, world = int(sys.argv[1]), int(sys.argv[2])
+    transport, boot, name, out_path = sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6]
+    import molecules
+    from afesp_amd import capi
+    si, ints, res, gold = molecules.load(name)
+    n, o = ints.nbasis, ints.nel // 2
+    v = n - o
+    eng = capi.Engine(0)
+    eng.comm_init(rank, world, capi.COMM_HOST if transport == "host" else capi.COMM_RCCL, boot)
+    ones = eng.allreduce_sum([1.0, float(rank)])
+    e_mp2, _ = eng.do_mp2_spatial(n, o, res.canon_coeff, res.canon_levels, ints.eri, want_eri_mo=False)
+    eng.ccsd_init(o, v, res.canon_levels, None, si.ccsd_diis_n_errmat)
+    nit, en, rm = eng.do_ccsd_spatial(si.ccsd_maxiter, si.ccsd_e_tol, si.ccsd_t_tol)
+    bounds = eng.shard_bounds(world)
+    part = eng.do_ccsd_t_spatial(bounds[rank], bounds[rank + 1])
+    total = eng.allreduce_sum(part)
+    sb = eng.t_block_size()
+    sbs = eng.allreduce_sum([sb, sb * sb])
+    # completely renormalised variant: shards of its own cost model, six sums
+    eng.build_cr_intermediates()
+    cb = eng.shard_bounds(world, cr=True)
+    cr_total = eng.allreduce_sum(eng.do_ccsd_t_spatial_cr(cb[rank], cb[rank + 1]))
+    eng.comm_destroy()
+    eng.close()
+    json.dump({"rank": rank, "ones": list(ones), "e_mp2": e_mp2, "nit": int(nit), "e_ccsd": float(en[nit]), "bounds": bounds,
+               "part": list(part), "total": list(total), "sb": sb, "sbs": list(sbs), "cr_total": list(cr_total)},
+              open(out_path, "w"))
+
+
+if __name__ == "__main__":
+    main()

@@ -151,7 +151,7 @@ def test_pp_ladder_split_form_on_ragged_extents(eng, o, v, monkeypatch):
     assert np.max(np.abs(h2 - g2)) < 1e-13
 
 
-@pytest.mark.parametrize("n,o", [(2, 1), (3, 2), (7, 3), (13, 4), (24, 5), (33, 16)])
+@pytest.mark.parametrize("n,o", [(2, 1), (3, 2), (7, 3), (13, 4), (24, 5), (33, 16), (58, 5)])
 def test_ao2mo_pair_symmetric_transform(eng, n, o):
     """AO->MO over the unique pairs (kl), then (pq): every packed MO integral and E(MP2) against the restatement of the four
     quarter transforms (src/mp2.f90:321-410), with a general (non-orthogonal) coefficient matrix and odd extents."""
@@ -168,6 +168,31 @@ def test_ao2mo_pair_symmetric_transform(eng, n, o):
     eng.set_eri(n, eri)
     e2, again = eng.do_mp2_spatial(n, o, c, e, None)       # AO integrals already resident on the device
     assert np.array_equal(again, eri_mo) and e2 == e_mp2
+
+
+def test_failed_graph_capture_leaves_a_working_context():
+    """The iteration of a small system is captured into a hipGraph on its second call.  A failure in the middle of the captured
+    body -- thrown while a lane other than the main one is selected (afesp_test_inject) -- must end the capture on the origin
+    stream and fall back to plain launches: that iteration and every later one still follow the oracle."""
+    from afesp_amd.capi import Engine
+    o, v = 4, 9
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05)
+    cc = orc.OracleCC(o, v, eri, e, 8)
+    onit, oen, _ = cc.solve(40, 1e-8, 1e-9)
+    with Engine(0) as eng2:
+        eng2.ccsd_init(o, v, e, eri, 8)
+        en = [eng2.ccsd_energy(1e-8, 1e-9)[0]]
+        for it in range(1, onit + 1):
+            if it == 2:
+                eng2.test_inject(1)                  # the capturing call
+            e_it, _, conv = eng2.ccsd_iterate(1e-8, 1e-9)
+            en.append(e_it)
+            if not conv:
+                eng2.ccsd_diis()
+        assert conv
+        assert np.max(np.abs(np.array(en) - oen[:onit + 1])) < 1e-10
+        out = eng2.do_ccsd_t_spatial()
+        assert np.max(np.abs(out - cc.triples(e))) < 1e-10
 
 
 def test_pp_ladder_split_form_through_the_replayed_iteration(eng, monkeypatch):
@@ -296,6 +321,29 @@ def test_eri_text_reader_and_fcidump_writer(eng, tmp_path):
         assert len(line) == 29
         assert (int(line[0:3]), int(line[3:6]), int(line[6:9]), int(line[9:12])) == (p, q, r, s)
         assert line[12:] == "%17.9E" % x and abs(float(line[12:]) - x) <= 5e-10 * abs(x)
+    # list-directed input (src/integrals.f90:150): Fortran D exponents, comma separators and trailing items are what the
+    # reference's `read (ir, *)` accepts -- the same lines through the engine's reader
+    lines_in = open(path).read().splitlines()
+    alt = tmp_path / "alt.dat"
+    rewritten = []
+    for li, ln in enumerate(lines_in):
+        i, j, a, b, x = ln.split()
+        if li % 3 == 0:
+            mant, ex = ("%.16E" % float(x)).split("E")      # 17 significant digits: the value survives
+            rewritten.append(f"{i} {j} {a} {b} {mant}D{ex}")
+        elif li % 3 == 1:
+            rewritten.append(f"{i}, {j},{a} ,{b},   {x}  ignored tail")
+        else:
+            rewritten.append(f"\t{i}\t{j}\t{a}\t{b}\t{x}\r")
+    alt.write_text("\n".join(rewritten) + "\n")
+    packed_alt, nalt = eng.read_eri_text(alt, n)
+    assert nalt == nlines
+    assert np.array_equal(packed_alt, ints.eri)
+    glued = tmp_path / "glued.dat"
+    glued.write_text("1 1 1 1 0.5D-01x\n")
+    from afesp_amd.capi import AfespError
+    with pytest.raises(AfespError):
+        eng.read_eri_text(glued, n)
     # malformed input is an error, not a silent zero
     bad = tmp_path / "bad.dat"
     bad.write_text("1 1 1 1 0.5\n1 1 99 1 0.25\n")
