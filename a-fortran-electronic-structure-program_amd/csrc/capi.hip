@@ -1078,6 +1078,12 @@ int afesp_ccsd_t_block_size(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr,
     });
 }
 
+// diagnostic builds of the GEMM kernel (AFESP_GETT_VARIANT bit 64): the per-wave cycle stamps of the last launch
+int afesp_debug_stamps(unsigned long long* out, int n)
+{
+    return gett_read_stamps(out, n) == hipSuccess ? 0 : 1;
+}
+
 int afesp_test_inject(afesp_ctx* ctx, int what)
 {
     return guarded(ctx, [&] { ctx->cx.test_throw = what; });

@@ -66,6 +66,8 @@ struct GettWorkspace {
 hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_t stream, int force_split = 0,
                        int force_tm = 0, int force_tn = 0);
 
+hipError_t gett_read_stamps(unsigned long long* out, int n);   // diagnostic builds (gett.hip)
+
 extern int g_group_m, g_force_tm, g_force_tn, g_force_split, g_allow_wide, g_dbg;
 
 }  // namespace afesp

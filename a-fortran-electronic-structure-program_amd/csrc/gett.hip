@@ -19,7 +19,17 @@ namespace afesp {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// Diagnostic builds only (AFESP_GETT_VARIANT bit 64): per (workgroup, wave) cycle sums -- [0] whole stream, [1] parked at the
+// step barrier (incl. the LDS-write drain in front of it), [2] the LDS-write block (incl. its wait for the gathered data),
+// [3] number of steps.  Read with gett_read_stamps; never part of a timed or shipped build.
+__device__ unsigned long long g_gett_stamp[256 * 8 * 4];
+
 constexpr int BK = 16;
+
+#ifndef AFESP_GETT_VARIANT
+#define AFESP_GETT_VARIANT 0
+#endif
+#define AFESP_GETT_VARIANT_ (AFESP_GETT_VARIANT)
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -357,9 +367,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
     // one at equal priority (MI355X_MICROARCH.md, two waves per SIMD): one static raise, no per-cluster flips
     // (A/B in one session, o=20 v=200: ring 61.3 -> 62.0 TF, pp-ladder 49.5 -> 50.0 TF; flips around every MFMA
     // cluster instead: -1 %).
-    if (NT == 512 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (AFESP_GETT_VARIANT_ & 4) {   // (a real raise for waves 4-7 only: the guard must be provably wave-uniform)
+        if (NT == 512 && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
+    } else if (NT == 512 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     int kt = 0, ctile = 0;
-#define AFESP_GETT_STEP(qa, qb, pa, pb)                                                         \
+// Schedule variants of one stream step (compile-time, A/B-measured in one GPU session: tools/ab_gemm.py):
+//   EARLY   the data of step g+1 is written to LDS right after the barrier that freed its buffer, so the whole step's
+//           MFMAs cover the ds_write completion the next barrier waits for; otherwise ("late") just before sub-step 2
+//   PIN     keep sub-step 2's MFMAs in front of the barrier (hipcc otherwise sinks them behind it, and the matrix pipe
+//           then idles from the first ds_write until the last wave has passed the barrier)
+#ifndef AFESP_GETT_VARIANT
+#define AFESP_GETT_VARIANT 0
+#endif
+    constexpr int VARIANT = AFESP_GETT_VARIANT;
+    constexpr bool PIN = (VARIANT & 1) != 0;
+    constexpr bool STAGGER = (VARIANT & 8) ? true : (VARIANT & 512) ? false : GRP;   // default: the grouped kernels only (A/B below)
+    unsigned long long stamp_bar = 0, stamp_stash = 0, stamp_n = 0, stamp_n2 = 0;
+    const unsigned long long stamp_t0 = (VARIANT & 64) ? __builtin_amdgcn_s_memtime() : 0;
+#define AFESP_GETT_STASH(pa, pb)                                                                \
+        if (st) {                                                                               \
+            unsigned long long s0_ = 0;                                                         \
+            if (VARIANT & 64) { __builtin_amdgcn_sched_barrier(0); s0_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } \
+            if (VARIANT & 128) { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_sched_barrier(0); stamp_n2 += __builtin_amdgcn_s_memtime() - s0_; __builtin_amdgcn_sched_barrier(0); } \
+            stA.stash(lds + (cur ^ 1) * STAGE, pa, t, kbeg + ktn * BK, kend, tail);             \
+            stB.stash(lds + (cur ^ 1) * STAGE + TA::SIZE, pb, t, kbeg + ktn * BK, kend, tail);  \
+            if (VARIANT & 64) { __builtin_amdgcn_sched_barrier(0); stamp_stash += __builtin_amdgcn_s_memtime() - s0_; __builtin_amdgcn_sched_barrier(0); } \
+        }
+#define AFESP_GETT_STEP(qa, qb, pa, pb, EARLY)                                                  \
     {                                                                                           \
         const int cur = g & 1;                                                                  \
         const double* cA = lds + cur * STAGE;                                                   \
@@ -367,6 +401,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
         const bool ld = g + 2 < G, st = g + 1 < G;                                              \
         const int ktn = (kt + 1 == nk) ? 0 : kt + 1;                                            \
         const bool tail = ragged && (ktn == nk - 1);                                            \
+        if (EARLY) { AFESP_GETT_STASH(pa, pb) }                                                 \
         frag(af1, bf1, cA, cB, 1);                                                              \
         if (ld) stA.fetch(qa);                                                                  \
         mfma(af0, bf0);                                                                         \
@@ -378,11 +413,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
         mfma(af1, bf1);                                                                         \
         frag(af1, bf1, cA, cB, 3);                                                              \
         if (ld) next_ko();                                                                      \
-        if (st) {                                                                               \
-            stA.stash(lds + (cur ^ 1) * STAGE, pa, t, kbeg + ktn * BK, kend, tail);             \
-            stB.stash(lds + (cur ^ 1) * STAGE + TA::SIZE, pb, t, kbeg + ktn * BK, kend, tail);  \
-        }                                                                                       \
+        if (!(EARLY)) { AFESP_GETT_STASH(pa, pb) }                                              \
         mfma(af0, bf0);                                                                         \
+        if (PIN) __builtin_amdgcn_sched_barrier(0);                                             \
+        if (VARIANT & 64) {                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+            const unsigned long long b0_ = __builtin_amdgcn_s_memtime();                        \
+            __syncthreads();                                                                    \
+            stamp_bar += __builtin_amdgcn_s_memtime() - b0_;                                    \
+            ++stamp_n;                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+        } else                                                                                  \
         __syncthreads();                                                                        \
         if (st) frag(af0, bf0, lds + (cur ^ 1) * STAGE, lds + (cur ^ 1) * STAGE + TA::SIZE, 0); \
         mfma(af1, bf1);                                                                         \
@@ -396,14 +437,39 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
         }                                                                                       \
         kt = ktn;                                                                               \
     }
-    int g = 0;
-    for (; g + 1 < G; g += 2) {
-        AFESP_GETT_STEP(ra0, rb0, ra1, rb1)
-        ++g;
-        AFESP_GETT_STEP(ra1, rb1, ra0, rb0)
-        --g;
+#define AFESP_GETT_LOOP(EARLY)                                                                  \
+    {                                                                                           \
+        int g = 0;                                                                              \
+        for (; g + 1 < G; g += 2) {                                                             \
+            AFESP_GETT_STEP(ra0, rb0, ra1, rb1, EARLY)                                          \
+            ++g;                                                                                \
+            AFESP_GETT_STEP(ra1, rb1, ra0, rb0, EARLY)                                          \
+            --g;                                                                                \
+        }                                                                                       \
+        if (g < G) AFESP_GETT_STEP(ra0, rb0, ra1, rb1, EARLY)                                   \
     }
-    if (g < G) AFESP_GETT_STEP(ra0, rb0, ra1, rb1)
+    // Stagger (8-wave tiles): the two waves of a SIMD run the same program between the same barriers, so left alone they
+    // reach their LDS writes, their waits and the barrier together and the matrix pipe has nothing to do meanwhile.
+    // Waves 4-7 therefore write early and waves 0-3 late: one half's non-matrix phase lies under the other half's MFMAs.
+    if (STAGGER && NT == 512) {
+        // one loop body, the position of the LDS writes chosen by a wave-uniform flag (two copies of the whole loop made
+        // hipcc spill 150-200 registers)
+        const bool early_half = (VARIANT & 16) ? __builtin_amdgcn_readfirstlane(wave) < 4 : __builtin_amdgcn_readfirstlane(wave) >= 4;
+        AFESP_GETT_LOOP(early_half)
+    } else if (VARIANT & 2) {
+        AFESP_GETT_LOOP(true)
+    } else {
+        AFESP_GETT_LOOP(false)
+    }
+#undef AFESP_GETT_LOOP
+#undef AFESP_GETT_STASH
+    if ((VARIANT & 64) && lane == 0 && blockIdx.x < 256 && wave < 8 && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned long long* d = g_gett_stamp + ((int)blockIdx.x * 8 + wave) * 4;
+        d[0] = __builtin_amdgcn_s_memtime() - stamp_t0;
+        d[1] = stamp_bar;
+        d[2] = stamp_stash;
+        d[3] = (VARIANT & 128) ? (stamp_n | (stamp_n2 << 20)) : stamp_n;
+    }
 #undef AFESP_GETT_STEP
 }
 
@@ -445,6 +511,11 @@ __global__ __launch_bounds__(256) void gett_reduce_kernel(GettKernelArgs a)
 }
 
 int g_dbg = 0;
+
+hipError_t gett_read_stamps(unsigned long long* out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gett_stamp), sizeof(unsigned long long) * (size_t)(n < 256 * 8 * 4 ? n : 256 * 8 * 4));
+}
 
 // Resident workgroups the device holds for one kernel instantiation (CUs x occupancy), found once per instantiation.
 template <typename Kern>

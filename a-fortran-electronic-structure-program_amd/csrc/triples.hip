@@ -563,6 +563,13 @@ void triples_shard_bounds(int o, int v, bool cr, int world, int64_t* bounds)
     const int64_t split_min_tiles = split_env ? atoll(split_env) : 1024;
     auto cost = [&](int64_t b, int64_t e) { return fused_range_cost(o, v, sb, b, e, BM, BN, split_min_tiles); };
     bounds[0] = 0;
+    // A small system is launch-bound: a single triple already costs about as much as the whole list (the estimate's floor of
+    // one round of tiles per launch), so there is nothing for the cost to balance -- equal counts then (F2/cc-pVDZ on two
+    // ranks would otherwise give rank 0 the one triple (0,0,0)).
+    if (cost(0, nt) < (double)world * cost(0, 1)) {
+        for (int r = 1; r <= world; ++r) bounds[r] = nt * r / world;
+        return;
+    }
     for (int r = 0; r < world; ++r) {
         const int64_t b = bounds[r];
         if (r == world - 1 || b >= nt) { bounds[r + 1] = nt; continue; }

@@ -171,6 +171,8 @@ int afesp_ccsd_t_block_size(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr,
 /* Test hook: what = 1 makes the next laned (small-system) amplitude update throw once, from a lane other than the main one
  * -- the failure mode of a capture that dies half-way (tests/test_gpu_cc.py). */
 int afesp_test_inject(afesp_ctx* ctx, int what);
+/* Diagnostic builds of the GEMM kernel only (tools/stamp_probe.py): per (workgroup, wave) cycle sums of the last launch. */
+int afesp_debug_stamps(unsigned long long* out, int n);
 
 /* Operator layer (src/linalg.fpp), exported for parity tests against the oracle.
  * afesp_gemm    = dgemm_wrapper (src/linalg.fpp:58-89): C(m x n) = alpha op(A) op(B) + beta C, host arrays.
