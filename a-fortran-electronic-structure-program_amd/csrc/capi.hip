@@ -322,6 +322,7 @@ int afesp_ccsd_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* energ
     return guarded(ctx, [&] {
         if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_iterate: call afesp_ccsd_init first");
         AFESP_HIP(hipSetDevice(ctx->cx.device));
+        ccsd_refresh_sharding(ctx->cx, ctx->cc);
         replay(ctx, ctx->graph_cc, ccsd_uses_lanes(ctx->cc), [&] {
             ccsd_diis_save(ctx->cx, ctx->cc);
             ccsd_intermediates(ctx->cx, ctx->cc);
@@ -358,6 +359,7 @@ int afesp_ccsd_solve(afesp_ctx* ctx, int maxiter, double e_tol, double t_tol, do
         if (iter_energy) iter_energy[0] = s.energy;
         if (iter_rms_sq) iter_rms_sq[0] = s.rms;
         int result = -1;
+        ccsd_refresh_sharding(cx, s);
         for (int it = 1; it <= maxiter; ++it) {
             replay(ctx, ctx->graph_cc, ccsd_uses_lanes(s), [&] {
                 ccsd_diis_save(cx, s);
@@ -1066,6 +1068,15 @@ int afesp_allreduce_sum(afesp_ctx* ctx, double* inout, int64_t n)
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         if (!ctx->cx.comm) return;   // single rank: the sum over one rank
         comm_allreduce_host(ctx->cx, ctx->cx.comm, inout, n);
+    });
+}
+
+int afesp_ccsd_is_split(afesp_ctx* ctx, int* split)
+{
+    return guarded(ctx, [&] {
+        if (!ctx->cc.ready || !split) throw Error(1, "afesp_ccsd_is_split: no CCSD state");
+        ccsd_refresh_sharding(ctx->cx, ctx->cc);
+        *split = ctx->cc.sharded ? 1 : 0;
     });
 }
 

@@ -26,7 +26,12 @@ struct CCState : DiisRing {
     // integral slices (ccsd.f90:507-512) and their immutable "2x - x^T" companions
     Tensor v_oovv, v_ovov, v_vvov, v_oovo, v_oooo, v_vvvv, w_oovv, w_vvov, w_oovo;
     Tensor D1, D2, t1, t2, t2_old, r1, r2;
-    double* pp = nullptr;          // packed particle-particle ladder PP(i,j,p), p over a <= b
+    double* pp = nullptr;          // packed particle-particle ladder PP(i,j,p), p over a <= b; the sharded ring terms' partial
+                                   // residual r2_sh (o^2 v^2) sits right behind it: one all-reduce covers both
+    double* r2_sh = nullptr;
+    // rank split of the iteration's large products (afesp_comm_init with world > 1; ccsd_refresh_sharding)
+    bool sharded = false;
+    int sh_rank = 0, sh_world = 1;
     int64_t* pp_tab = nullptr;     // offset tables of the pp-ladder GEMM: [Am | k | Bk | n]
     // symmetric / antisymmetric form (large systems): V+-(ef,ab) built at init, c+-(ij,ef) and the two products per iteration
     bool pp_sym = false;
@@ -45,6 +50,7 @@ void triples_plan_free(CCState& s);
 
 // eri_mo_dev: packed chemist MO integrals ON DEVICE (length neri(o+v)); e_host: orbital energies (host)
 void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, const double* e_host, int diis_nerr);
+void ccsd_refresh_sharding(Context& cx, CCState& s);   // call before an iteration: picks up the context's communicator
 bool ccsd_uses_lanes(const CCState& s);   // small systems: the iteration's chains run on parallel lanes (ccsd.hip)
 void ccsd_diis_save(Context& cx, CCState& s);
 void ccsd_intermediates(Context& cx, CCState& s);

@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "ccsd.h"
+#include "comm.h"
 
 namespace afesp {
 
@@ -54,7 +55,8 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     // pp-ladder (ccsd.f90:1669) over the symmetry-unique column pairs a <= b
     {
         const int64_t np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
-        s.pp = cx.alloc(N2 * np);
+        s.pp = cx.alloc(N2 * np + O * O * V * V);
+        s.r2_sh = s.pp + N2 * np;
         s.pp_sym = pp_sym_pays(O, V);
         std::vector<int64_t> tab;
         if (!s.pp_sym) {
@@ -151,13 +153,40 @@ bool ccsd_uses_lanes(const CCState& s) { return lanes_pay(s); }
 static bool lanes_pay(const CCState& s)
 {
     static const bool off = [] { const char* e = getenv("AFESP_NO_LANES"); return e && e[0] == '1'; }();
-    return !off && s.t2.size() <= ((int64_t)1 << 20);
+    return !off && !s.sharded && s.t2.size() <= ((int64_t)1 << 20);
+}
+
+// Rank split of one iteration ("next"): with a communicator of more than one rank the o^3 v^3 ring products and
+// the pp-ladder -- 20 of the 28 ms of an iteration at o = 20, v = 200 -- are evaluated for this rank's slice of a virtual
+// index only, into buffers that start from zero; ONE all-reduce of [PP | r2_sh] then gives every rank the same residual
+// and every rank applies the same update: amplitudes, DIIS history and energies stay replicated and identical.  The slice
+// index is external to both the intermediate and the product that consumes it, so a rank builds exactly the part of
+// I_ovov / I_voov it needs itself.  Everything else of the iteration (8 ms) is replicated.  Small systems stay
+// replicated (their iteration is launch-bound); AFESP_CC_SHARD=1 / 0 forces the split on / off.
+void ccsd_refresh_sharding(Context& cx, CCState& s)
+{
+    static const int force = [] { const char* e = getenv("AFESP_CC_SHARD"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const int world = cx.comm ? cx.comm->world : 1;
+    s.sh_world = world;
+    s.sh_rank = cx.comm ? cx.comm->rank : 0;
+    s.sharded = world > 1 && (force == 1 || (force != 0 && s.t2.size() > ((int64_t)1 << 20)));
+}
+
+static Tensor slice_axis(Tensor t, int axis, int64_t lo, int64_t hi)
+{
+    t.d += lo * t.stride[axis];
+    t.dim[axis] = hi - lo;
+    return t;
 }
 
 void ccsd_intermediates(Context& cx, CCState& s)
 {
     auto C = [&](double al, const Tensor& A, const char* la, const Tensor& B, const char* lb, double be, const Tensor& Cc,
                  const char* lc) { contract(cx, al, A, la, B, lb, be, Cc, lc); };
+    ccsd_refresh_sharding(cx, s);
+    // this rank's slice [v0, v1) of the last (virtual) index of I_ovov / I_voov: the whole range unless the iteration is split
+    const int64_t v0 = s.sharded ? (int64_t)s.v * s.sh_rank / s.sh_world : 0, v1 = s.sharded ? (int64_t)s.v * (s.sh_rank + 1) / s.sh_world : s.v;
+    auto sl = [&](const Tensor& t, int axis) { return slice_axis(t, axis, v0, v1); };
     // asym_t2, c_oovv                                                    ccsd.f90:1063-1079
     k_asym_c(cx, s.asym.d, s.c.d, s.t1.d, s.t2.d, s.o, s.v);
     // Small systems are bound by the latency of ~100 dependent launches: the independent chains below then run on four
@@ -189,7 +218,7 @@ void ccsd_intermediates(Context& cx, CCState& s)
     lane(2);
     // I_ovov(j,b,i,a)                                                    ccsd.f90:1158-1191
     k_copy(cx, s.I_ovov.d, s.v_ovov.d, s.I_ovov.size());
-    C(-0.5, s.v_oovv, "mibe", s.c, "mjae", 1.0, s.I_ovov, "jbia");
+    if (v1 > v0) C(-0.5, s.v_oovv, "mibe", sl(s.c, 2), "mjae", 1.0, sl(s.I_ovov, 3), "jbia");   // (o^3 v^3: sliced over a)
     C(-1.0, s.v_oovo, "mibj", s.t1, "ma", 1.0, s.I_ovov, "jbia");
     C(1.0, s.t1, "je", s.v_vvov, "ebia", 1.0, s.I_ovov, "jbia");
     lane(3);
@@ -199,8 +228,10 @@ void ccsd_intermediates(Context& cx, CCState& s)
     // I_voov(b,j,i,a)                                                    ccsd.f90:1193-1252
     permute_add(cx, 1.0, s.v_oovv, "jiab", 0.0, s.I_voov, "bjia");
     k_axpby(cx, s.I_voov.d, 1.0, s.x_voov.d, 1.0, s.I_voov.size());
-    C(0.5, s.w_oovv, "imbe", s.t2, "mjea", 1.0, s.I_voov, "bjia");
-    C(-0.5, s.v_oovv, "imbe", s.c, "mjae", 1.0, s.I_voov, "bjia");
+    if (v1 > v0) {                                                                             // (o^3 v^3 each: sliced over a)
+        C(0.5, s.w_oovv, "imbe", sl(s.t2, 3), "mjea", 1.0, sl(s.I_voov, 3), "bjia");
+        C(-0.5, s.v_oovv, "imbe", sl(s.c, 2), "mjae", 1.0, sl(s.I_voov, 3), "bjia");
+    }
     C(-1.0, s.v_oovo, "imbj", s.t1, "ma", 1.0, s.I_voov, "bjia");
     lane(4);
     // I_vovv_p(c,i,a,b) = <ab|ci> - t(m,a) <mi|cb> - t(m,b) <ma|ic>          ccsd.f90:1255-1272, :1296-1299
@@ -240,9 +271,24 @@ bool pp_sym_pays(int64_t O, int64_t V)
     return plain > 1.5 * split;
 }
 
+// Sharded iteration: a rank evaluates the rows (a <= b) of its range of b only -- contiguous row ranges of both pair
+// products, [b0 (b0+1)/2, b1 (b1+1)/2) and [b0 (b0-1)/2, b1 (b1-1)/2), the boundaries chosen for equal row counts -- and
+// leaves the rest of PP zero for the all-reduce (ccsd_amplitudes).
+static void pp_b_range(const CCState& s, int64_t* b0, int64_t* b1)
+{
+    const int64_t V = s.v;
+    if (!s.sharded) { *b0 = 0; *b1 = V; return; }
+    auto cut = [&](int r) { return (int64_t)std::llround(std::sqrt((double)r / (double)s.sh_world) * (double)V); };
+    *b0 = s.sh_rank == 0 ? 0 : std::min(V, cut(s.sh_rank));
+    *b1 = s.sh_rank + 1 == s.sh_world ? V : std::min(V, cut(s.sh_rank + 1));
+}
+
 void ccsd_pp_ladder(Context& cx, CCState& s)
 {
     const int64_t O = s.o, V = s.v, np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
+    int64_t b0, b1;
+    pp_b_range(s, &b0, &b1);
+    const int64_t p0 = b0 * (b0 + 1) / 2, p1 = b1 * (b1 + 1) / 2, q0 = b0 * (b0 - 1) / 2, q1 = b1 * (b1 - 1) / 2;
     GettProblem gp;
     gp.alpha = 1.0; gp.beta = 0.0;
     gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
@@ -251,9 +297,10 @@ void ccsd_pp_ladder(Context& cx, CCState& s)
         gp.A = s.v_vvvv.d; gp.B = s.c.d; gp.C = s.pp;
         gp.offAm = s.pp_tab; gp.offAk = s.pp_tab + np; gp.offBk = s.pp_tab + np + K2; gp.offBn = s.pp_tab + np + 2 * K2;
         gp.offCm = s.pp_tab + np + 2 * K2 + N2; gp.offCn = gp.offBn;
-        gp.M = (int)np; gp.N = (int)N2; gp.K = (int)K2;
+        gp.offAm += p0; gp.offCm += p0;
+        gp.M = (int)(p1 - p0); gp.N = (int)N2; gp.K = (int)K2;
         gp.wide = (O % 2 == 0) && (V % 2 == 0) && (np % 2 == 0);
-        AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+        if (p1 > p0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
         return;
     }
     const int64_t npa = V * (V - 1) / 2, ks = s.pp_ks, ka = s.pp_ka, ns = s.pp_ns, na = s.pp_na, nm = s.pp_nm;
@@ -263,16 +310,17 @@ void ccsd_pp_ladder(Context& cx, CCState& s)
     gp.wide = true;
     gp.offAk = t; gp.offBn = gp.offCn = t;
     gp.A = s.pp_vs; gp.B = s.pp_cs; gp.C = s.pp_ps;
-    gp.offAm = u; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * ks;
-    gp.M = (int)np; gp.N = (int)ns; gp.K = (int)ks;
-    AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+    gp.offAm = u + p0; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * ks + p0;
+    gp.M = (int)(p1 - p0); gp.N = (int)ns; gp.K = (int)ks;
+    if (p1 > p0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
     if (s.pp_pa) {
         gp.A = s.pp_va; gp.B = s.pp_ca; gp.C = s.pp_pa;
-        gp.offAm = u + nm; gp.offBk = u + 2 * nm + ks; gp.offCm = u + 3 * nm + 2 * ks;
-        gp.M = (int)npa; gp.N = (int)na; gp.K = (int)ka;
-        AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+        gp.offAm = u + nm + q0; gp.offBk = u + 2 * nm + ks; gp.offCm = u + 3 * nm + 2 * ks + q0;
+        gp.M = (int)(q1 - q0); gp.N = (int)na; gp.K = (int)ka;
+        if (q1 > q0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
     }
-    k_pp_expand(cx, s.pp, s.pp_ps, s.pp_pa, s.o, s.v, ns, na);
+    (void)npa;
+    k_pp_expand(cx, s.pp, s.pp_ps, s.pp_pa, s.o, s.v, ns, na, p0, p1);
 }
 
 // I_ooov_p(j,k,i,a) += sum_ef t2(jk,ef) <ef|ia>  (ccsd.f90:1302-1308) in the pair form of the pp-ladder: t2 has the (anti)symmetry
@@ -319,9 +367,18 @@ void ccsd_amplitudes(Context& cx, CCState& s)
                  const char* lc) { contract(cx, al, A, la, B, lb, be, Cc, lc); };
     // lanes (small systems only, see ccsd_intermediates): T1 in two groups, the pp-ladder on its own lane, the other T2 terms
     // in three groups; all but the first group of each go into partial buffers that are added after the join
-    const bool par = lanes_pay(s);
+    ccsd_refresh_sharding(cx, s);
+    const bool par = lanes_pay(s), sh = s.sharded;
+    const int64_t v0 = sh ? (int64_t)s.v * s.sh_rank / s.sh_world : 0, v1 = sh ? (int64_t)s.v * (s.sh_rank + 1) / s.sh_world : s.v;
+    auto sl = [&](const Tensor& t, int axis) { return slice_axis(t, axis, v0, v1); };
     auto lane = [&](int i) { if (par) cx.use_lane(i); };
     Tensor r2b = s.r2, r2c = s.r2, r2d = s.r2, r1b = s.r1;
+    Tensor r2s = s.r2;              // receives the three ring products: the rank-partial buffer when the iteration is split
+    if (sh) {
+        r2s.d = s.r2_sh;
+        const int64_t np = (int64_t)s.v * (s.v + 1) / 2;
+        AFESP_HIP(hipMemsetAsync(s.pp, 0, sizeof(double) * ((int64_t)s.o * s.o * np + s.r2.size()), cx.stream));   // [PP | r2_sh]
+    }
     if (par) {
         r2b.d = cx.scratch("r2_lane2", s.r2.size());
         r2c.d = cx.scratch("r2_lane3", s.r2.size());
@@ -354,10 +411,16 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     lane(1);
     C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");              // :1673  hole-hole ladder
     lane(2);
-    C(-1.0, s.t2, "mjae", s.I_ovov, "iemb", par ? 0.0 : 1.0, r2b, "ijab");   // :1680-1695 ring terms
-    C(-1.0, s.I_ovov, "iema", s.t2, "mjeb", 1.0, r2b, "ijab");
+    if (!sh) {
+        C(-1.0, s.t2, "mjae", s.I_ovov, "iemb", par ? 0.0 : 1.0, r2b, "ijab");   // :1680-1695 ring terms
+        C(-1.0, s.I_ovov, "iema", s.t2, "mjeb", 1.0, r2b, "ijab");
+    } else if (v1 > v0) {           // the slice of I_ovov / I_voov this rank built, into the zeroed partial residual
+        C(-1.0, s.t2, "mjae", sl(s.I_ovov, 3), "iemb", 1.0, sl(r2s, 3), "ijab");
+        C(-1.0, sl(s.I_ovov, 3), "iema", s.t2, "mjeb", 1.0, sl(r2s, 2), "ijab");
+        C(1.0, s.asym, "miea", sl(s.I_voov, 3), "ejmb", 1.0, sl(r2s, 3), "ijab");
+    }
     lane(3);
-    C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
+    if (!sh) C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
     C(1.0, s.t1, "ie", s.v_vvov, "baje", 1.0, r2c, "ijab");                // :1700, bare part: t(i,e) <ab|ej>
     C(-1.0, s.t1, "ma", s.I_ooov_p, "ijmb", 1.0, r2c, "ijab");             // :1705-1715
     if (par) {
@@ -366,6 +429,12 @@ void ccsd_amplitudes(Context& cx, CCState& s)
         k_axpby(cx, s.r2.d, 1.0, r2b.d, 1.0, s.r2.size());
         k_axpby(cx, s.r2.d, 1.0, r2c.d, 1.0, s.r2.size());
         k_axpby(cx, s.r2.d, 1.0, r2d.d, 1.0, s.r2.size());
+    }
+    if (sh) {
+        // the one exchange of a split iteration: sum over ranks of [PP | r2_sh] (64 + 128 MB at o = 20, v = 200), in place
+        const int64_t np = (int64_t)s.v * (s.v + 1) / 2;
+        comm_allreduce_dev(cx, cx.comm, s.pp, (int64_t)s.o * s.o * np + s.r2.size());
+        k_axpby(cx, s.r2.d, 1.0, s.r2_sh, 1.0, s.r2.size());
     }
     // P(ia/jb), + v_oovv, Jacobi divide                                  ccsd.f90:1720-1728
     k_div(cx, s.t1.d, s.r1.d, s.D1.d, s.t1.size());

@@ -366,11 +366,12 @@ __global__ void c_sympack_kernel(double* cs, double* ca, const double* c, int o,
     }
 }
 // PP(i,j,p) = Ps(ij,p) +/- Pa(ij,p): + for i < j, - for i > j (p over a <= b; Pa vanishes on i == j and on a == b)
-__global__ void pp_expand_kernel(double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na)
+__global__ void pp_expand_kernel(double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na, int64_t p0, int64_t p1)
 {
-    const int64_t O = o, V = v, n = O * O * (V * (V + 1) / 2);
-    GRID_STRIDE(x, n)
+    const int64_t O = o, n = O * O * (p1 - p0), x0 = O * O * p0;
+    GRID_STRIDE(xr, n)
     {
+        const int64_t x = x0 + xr;
         const int i = (int)(x % O), j = (int)((x / O) % O);
         const int64_t p = x / (O * O);
         const int lo = i < j ? i : j, hi = i < j ? j : i;
@@ -434,9 +435,11 @@ void k_c_sympack(Context& cx, double* cs, double* ca, const double* c, int o, in
 {
     LAUNCH(c_sympack_kernel, dim3(grid_for((int64_t)o * o * v * v)), cs, ca, c, o, v, ns, na);
 }
-void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na)
+void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na, int64_t p0, int64_t p1)
 {
-    LAUNCH(pp_expand_kernel, dim3(grid_for((int64_t)o * o * ((int64_t)v * (v + 1) / 2))), pp, ps, pa, o, v, ns, na);
+    if (p1 < 0) p1 = (int64_t)v * (v + 1) / 2;
+    if (p1 <= p0) return;
+    LAUNCH(pp_expand_kernel, dim3(grid_for((int64_t)o * o * (p1 - p0))), pp, ps, pa, o, v, ns, na, p0, p1);
 }
 // update_diis_cc (ccsd.f90:653-673) without leaving the device: the new row/column `slot` of the error overlap matrix comes
 // from `dots`, and the (n+1) x (n+1) system [B -1; -1 0] c = (0,...,0,-1) is solved by Gaussian elimination with partial

@@ -288,6 +288,7 @@ class Reducer:
     def __init__(self, eng, rank, world, dist, cdev, torch, backend, jobdir):
         self.eng, self.world, self.dist, self.cdev, self.torch = eng, world, dist, cdev, torch
         self.kind = "none (one rank)"
+        self.own = False
         if world == 1:
             return
         from afesp_amd import capi
@@ -395,14 +396,17 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
     flop_step = it_flop + flops_t_sym(o, v)
     # executed: the (T) GEMMs evaluate o x o(o+1)/2 distinct blocks of 4 v^3 (v+o) flop (half of that where the occupied pair
     # coincides) instead of the symmetric count's 12 v^3 (v+o) per i<=j<=k triple; the CCSD iteration is replicated per rank
-    flop_exec = it_flop * world + float(ex.cpu()[0]) / steps
+    split = world > 1 and red.own and eng.ccsd_is_split()   # the iteration's ring products and ladder run slice by slice on the ranks
+    rep_flop = it_flop - (eng.pp_ladder_flop() + 12 * o**3 * v**3) if split else it_flop
+    flop_exec = (it_flop - rep_flop) + rep_flop * world + float(ex.cpu()[0]) / steps
     res = None
     if rank == 0:
         res = {
             "value": flop_step / sec_per_step / 1e12, "ms_per_step": sec_per_step * 1e3,
             "config": {"workload": f"{workload}: nocc={o} nvirt={v}, synthetic hashed ERIs scale {scale}; "
                                    "step = 1 CCSD iteration (replicated) + full (T) over i<=j<=k sharded across ranks",
-                       "nocc": o, "nvirt": v, "triples": int(nt), "parallelism": f"(T) ijk-shard x{world}, CCSD replicas"},
+                       "nocc": o, "nvirt": v, "triples": int(nt), "parallelism": (f"(T) ijk-shard x{world}; CCSD iteration: ring o^3v^3 products + pp-ladder split x{world} with one "
+                                       f"all-reduce of [PP | residual], rest replicated" if split else f"(T) ijk-shard x{world}, CCSD replicas")},
             "ccsd_iter_s": t_iter / steps, "t_s": t_trip / steps, "flop_per_step": flop_step,
             "fraction_of_mfma_peak": flop_step / sec_per_step / 1e12 / (MFMA_F64_PEAK_TFLOPS * world),
             "flop_per_step_executed": flop_exec,

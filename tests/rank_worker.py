@@ -28,6 +28,7 @@ def main():
     e_mp2, _ = eng.do_mp2_spatial(n, o, res.canon_coeff, res.canon_levels, ints.eri, want_eri_mo=False)
     eng.ccsd_init(o, v, res.canon_levels, None, si.ccsd_diis_n_errmat)
     nit, en, rm = eng.do_ccsd_spatial(si.ccsd_maxiter, si.ccsd_e_tol, si.ccsd_t_tol)
+    split = eng.ccsd_is_split()
     bounds = eng.shard_bounds(world)
     part = eng.do_ccsd_t_spatial(bounds[rank], bounds[rank + 1])
     total = eng.allreduce_sum(part)
@@ -39,7 +40,7 @@ def main():
     cr_total = eng.allreduce_sum(eng.do_ccsd_t_spatial_cr(cb[rank], cb[rank + 1]))
     eng.comm_destroy()
     eng.close()
-    json.dump({"rank": rank, "ones": list(ones), "e_mp2": e_mp2, "nit": int(nit), "e_ccsd": float(en[nit]), "bounds": bounds,
+    json.dump({"rank": rank, "ones": list(ones), "e_mp2": e_mp2, "nit": int(nit), "e_ccsd": float(en[nit]), "en": [float(x) for x in en[:nit + 1]], "split": split, "bounds": bounds,
                "part": list(part), "total": list(total), "sb": sb, "sbs": list(sbs), "cr_total": list(cr_total)},
               open(out_path, "w"))
 

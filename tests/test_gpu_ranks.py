@@ -19,13 +19,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST_DIR = os.path.join(ROOT, "a-fortran-electronic-structure-program_amd", "host")
 
 
-def _run_ranks(tmp_path, world, name, transport="host"):
+def _run_ranks(tmp_path, world, name, transport="host", env=None):
     boot = str(tmp_path / "bootstrap")
     procs = []
     for r in range(world):
         out = tmp_path / f"rank{r}.json"
         procs.append((subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rank_worker.py"), str(r), str(world), transport,
-                                        boot, name, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True), out))
+                                        boot, name, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                                       env=dict(os.environ, **(env or {}))), out))
     res = []
     for p, out in procs:
         log, _ = p.communicate(timeout=600)
@@ -56,6 +57,27 @@ def test_engine_ranks_shard_triples_and_reduce(tmp_path, name, world):
     assert all(b1 > b0 for b0, b1 in zip(res[0]["bounds"][:-1], res[0]["bounds"][1:]))
     assert np.max(np.abs(parts.sum(axis=0) - np.array(res[0]["total"]))) < 1e-13
     assert np.all(np.abs(parts[:, 0]) < abs(res[0]["total"][0]))
+
+
+@pytest.mark.parametrize("name,world,pp_sym", [("f2-cc-pvdz", 2, "0"), ("n2-cc-pvdz", 3, "1")])
+def test_ccsd_iteration_split_over_ranks(tmp_path, name, world, pp_sym):
+    """the iteration's o^3 v^3 ring products and the pp-ladder (both of its forms) evaluated slice by
+    slice on the ranks, one all-reduce of [PP | partial residual] per iteration -- every rank must walk the reference's own
+    iteration table (els.out, 12 decimals) and land on the replica path's energies."""
+    res = _run_ranks(tmp_path, world, name, env={"AFESP_CC_SHARD": "1", "AFESP_PP_SYM": pp_sym})
+    g = molecules.SURVEY_GOLD[name]
+    _, _, _, gold = molecules.load(name)
+    for r in res:
+        assert r["split"] is True
+        assert r["nit"] == gold["cc_iters"][-1][0]
+        for (git, ge, gde, grms) in gold["cc_iters"]:
+            assert abs(r["en"][git] - ge) < 1e-10, (git, r["en"][git], ge)
+        assert r["en"] == res[0]["en"]                                          # replicated state: bit-identical on every rank
+        assert abs(r["e_ccsd"] - g["ccsd_corr"]) < 1e-8
+        assert abs(r["e_ccsd"] + r["total"][1] - g["ccsd_pt_corr"]) < 1e-8
+    plain = _run_ranks(tmp_path, world, name, env={"AFESP_CC_SHARD": "0", "AFESP_PP_SYM": pp_sym})
+    assert plain[0]["split"] is False
+    assert np.max(np.abs(np.array(plain[0]["en"]) - np.array(res[0]["en"]))) < 1e-11   # split == replicas
 
 
 def test_rccl_transport_with_one_rank():
