@@ -30,7 +30,7 @@ EXPORTS = [
     "afesp_read_eri_text", "afesp_write_fcidump", "afesp_set_eri", "afesp_build_fock", "afesp_ccsd_t_plain",
     "afesp_synthetic_ao", "afesp_ccsd_pp_ladder_flop", "afesp_ccsd_iteration_flop",
     "afesp_device_count", "afesp_comm_unique_id", "afesp_comm_init", "afesp_comm_destroy", "afesp_allreduce_sum",
-    "afesp_ccsd_t_block_size", "afesp_test_inject", "afesp_ccsd_is_split", "afesp_debug_stamps",
+    "afesp_ccsd_t_block_size", "afesp_test_inject", "afesp_ccsd_is_split", "afesp_debug_stamps", "afesp_arena_stats",
 ]
 COMM_RCCL, COMM_HOST = 0, 1
 
@@ -111,6 +111,7 @@ def load_library():
     L.afesp_allreduce_sum.argtypes = [C.c_void_p, _dp, i64]
     L.afesp_ccsd_t_block_size.argtypes = [C.c_void_p, i64, i64, C.c_int, C.POINTER(C.c_int)]
     L.afesp_test_inject.argtypes = [C.c_void_p, C.c_int]
+    L.afesp_arena_stats.argtypes = [C.c_void_p, _dp]
     L.afesp_ccsd_is_split.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.afesp_debug_stamps.argtypes = [C.c_void_p, C.c_int]
     _lib = L
@@ -269,6 +270,11 @@ class Engine:
         sb = C.c_int()
         self._chk(self.L.afesp_ccsd_t_block_size(self.h, self.o, self.v, 1 if cr else 0, C.byref(sb)))
         return sb.value
+
+    def arena_stats(self):
+        out = np.zeros(4)
+        self._chk(self.L.afesp_arena_stats(self.h, out))
+        return dict(driver_calls=int(out[0]), reuse_hits=int(out[1]), idle_gb=out[2] / 1e9, live_gb=out[3] / 1e9)
 
     def ccsd_is_split(self):
         f = C.c_int()

@@ -49,11 +49,27 @@ struct Plan {
 
 struct Comm;
 
+// Device arena owned by the context.  On this runtime a hipMalloc of a GB or more is normally 0.3 ms but now and then takes
+// 0.1-5 s, and a calculation frees and re-allocates tens of GB between its stages (AO->MO temporaries,
+// the CCSD tensors, the (T) pool).  Blocks given back therefore stay with the context and are handed out again -- best fit,
+// at most a quarter larger than asked for -- so that only the first use of a size ever reaches the driver; when the driver
+// is out of memory the idle blocks are returned to it and the request is retried.
+struct Arena {
+    std::map<void*, size_t> live;            // blocks handed out
+    std::multimap<size_t, void*> idle;       // blocks given back, by size
+    size_t idle_bytes = 0, driver_calls = 0, reuse_hits = 0;
+    void* get(size_t bytes);
+    void put(void* p);
+    void trim();                             // hipFree every idle block
+    void destroy();                          // ... and every live one
+};
+
 struct Context {
     int device = 0;
     Comm* comm = nullptr;                 // rank-to-rank sums (comm.h); null = single rank
     int test_throw = 0;                   // test hook (afesp_test_inject): the next laned amplitude update throws
     hipStream_t stream = nullptr;
+    Arena arena;                          // every device allocation of the context goes through it
     std::vector<void*> owned;             // everything freed at destroy
     GettWorkspace ws{nullptr, 0};
     bool in_repack = false;               // set while contract() runs on a re-laid-out operand
@@ -77,6 +93,7 @@ struct Context {
     double* scal = nullptr;               // small device scratch for reductions (64 doubles)
     double* scal_host = nullptr;          // pinned mirror
     std::map<std::string, Plan> plans;
+    size_t plan_bytes = 0;                // device bytes of their offset tables
     std::map<std::string, std::pair<void*, size_t>> cache;   // named scratch buffers kept across calls (not zeroed)
     std::string last_error;
     // optional HIP-event timing of the (T) launches (bench.py roofline): enabled by afesp_profile

@@ -1095,6 +1095,17 @@ int afesp_debug_stamps(unsigned long long* out, int n)
     return gett_read_stamps(out, n) == hipSuccess ? 0 : 1;
 }
 
+// device arena of the context: {driver allocations so far, requests served from idle blocks, idle bytes, live bytes}
+int afesp_arena_stats(afesp_ctx* ctx, double out[4])
+{
+    return guarded(ctx, [&] {
+        const Arena& a = ctx->cx.arena;
+        size_t live = 0;
+        for (auto& kv : a.live) live += kv.second;
+        out[0] = (double)a.driver_calls; out[1] = (double)a.reuse_hits; out[2] = (double)a.idle_bytes; out[3] = (double)live;
+    });
+}
+
 int afesp_test_inject(afesp_ctx* ctx, int what)
 {
     return guarded(ctx, [&] { ctx->cx.test_throw = what; });

@@ -117,10 +117,16 @@ void ccsd_free(Context& cx, CCState& s)
                       s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d, s.pp, (double*)s.pp_tab, s.pp_vs, s.pp_va, s.pp_cs,
                       s.pp_ca, s.pp_ps, s.pp_pa, s.bmat, s.ov_ws, s.ov_wa};
     for (double* b : bufs) cx.release(b);
-    // contraction plans of the previous system: their offset tables are device memory too
-    for (auto& kv : cx.plans)
-        if (!kv.second.repack) cx.release(kv.second.offAm);
-    cx.plans.clear();
+    // Contraction plans are keyed by shape and stay valid for the life of the context (the AO->MO plans carry tables of
+    // n^2 npair entries: rebuilding them costs a quarter of a second at n = 220), so a new system of the same extents finds
+    // them again.  Their offset tables are device memory, though: a context that has seen many different systems drops them
+    // here, where no captured iteration refers to them.
+    if (cx.plans.size() > 1024 || cx.plan_bytes > ((size_t)4 << 30)) {
+        for (auto& kv : cx.plans)
+            if (!kv.second.repack) cx.release(kv.second.offAm);
+        cx.plans.clear();
+        cx.plan_bytes = 0;
+    }
     cx.drop_scratch();
     triples_plan_free(s);
     s = CCState();

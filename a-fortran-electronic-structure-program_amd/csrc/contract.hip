@@ -11,20 +11,71 @@
 
 namespace afesp {
 
+// ------------------------------------------------------------------ arena
+static size_t arena_round(size_t bytes)
+{
+    if (bytes < 256) bytes = 256;
+    const size_t g = bytes >= ((size_t)1 << 20) ? ((size_t)2 << 20) : 256;   // 2 MiB steps for large blocks: sizes that recur, recur exactly
+    return (bytes + g - 1) / g * g;
+}
+void* Arena::get(size_t bytes)
+{
+    bytes = arena_round(bytes);
+    auto it = idle.lower_bound(bytes);
+    if (it != idle.end() && it->first <= bytes + std::max(bytes / 4, (size_t)1 << 20)) {
+        void* p = it->second;
+        live[p] = it->first;
+        idle_bytes -= it->first;
+        idle.erase(it);
+        ++reuse_hits;
+        return p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    ++driver_calls;
+    if (e != hipSuccess) {   // out of device memory: give the idle blocks back and try once more
+        (void)hipGetLastError();
+        trim();
+        e = hipMalloc(&p, bytes);
+        ++driver_calls;
+    }
+    if (e != hipSuccess) throw Error(2, std::string("device allocation of ") + std::to_string(bytes >> 20) + " MiB failed: " + hipGetErrorString(e));
+    live[p] = bytes;
+    return p;
+}
+void Arena::put(void* p)
+{
+    auto it = live.find(p);
+    if (it == live.end()) return;
+    idle.emplace(it->second, p);
+    idle_bytes += it->second;
+    live.erase(it);
+}
+void Arena::trim()
+{
+    for (auto& kv : idle) (void)hipFree(kv.second);
+    idle.clear();
+    idle_bytes = 0;
+}
+void Arena::destroy()
+{
+    trim();
+    for (auto& kv : live) (void)hipFree(kv.first);
+    live.clear();
+}
+
 // ------------------------------------------------------------------ context
 double* Context::alloc(int64_t n)
 {
-    void* p = nullptr;
-    size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(double);
-    AFESP_HIP(hipMalloc(&p, bytes));
+    const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(double);
+    void* p = arena.get(bytes);
     AFESP_HIP(hipMemsetAsync(p, 0, bytes, stream));
     owned.push_back(p);
     return (double*)p;
 }
 double* Context::alloc_raw(int64_t n)
 {
-    void* p = nullptr;
-    AFESP_HIP(hipMalloc(&p, (size_t)(n > 0 ? n : 1) * sizeof(double)));
+    void* p = arena.get((size_t)(n > 0 ? n : 1) * sizeof(double));
     owned.push_back(p);
     return (double*)p;
 }
@@ -37,11 +88,10 @@ double* Context::scratch(const std::string& name, int64_t n)
     if (it != cache.end()) {
         ++scratch_epoch;
         AFESP_HIP(hipStreamSynchronize(stream));
-        (void)hipFree(it->second.first);
+        arena.put(it->second.first);
         cache.erase(it);
     }
-    void* p = nullptr;
-    AFESP_HIP(hipMalloc(&p, bytes));
+    void* p = arena.get(bytes);
     cache[name] = {p, bytes};
     return (double*)p;
 }
@@ -49,7 +99,7 @@ void Context::drop_scratch()
 {
     ++scratch_epoch;
     if (stream) (void)hipStreamSynchronize(stream);
-    for (auto& kv : cache) (void)hipFree(kv.second.first);
+    for (auto& kv : cache) arena.put(kv.second.first);
     cache.clear();
 }
 void Context::drop_scratch(const std::string& prefix)
@@ -59,7 +109,7 @@ void Context::drop_scratch(const std::string& prefix)
         if (it->first.compare(0, prefix.size(), prefix) == 0) {
             if (!any && stream) (void)hipStreamSynchronize(stream);
             any = true;
-            (void)hipFree(it->second.first);
+            arena.put(it->second.first);
             it = cache.erase(it);
         } else {
             ++it;
@@ -74,7 +124,7 @@ void Context::release(void* p)
     if (it != owned.end()) {
         owned.erase(it);
         (void)hipStreamSynchronize(stream);
-        (void)hipFree(p);
+        arena.put(p);
     }
 }
 Tensor Context::tensor(std::initializer_list<int64_t> dims)
@@ -99,8 +149,7 @@ void Context::fork(int nlanes)
         AFESP_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         AFESP_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
         l.ws.bytes = (size_t)32 << 20;   // lanes only carry small problems
-        void* p = nullptr;
-        AFESP_HIP(hipMalloc(&p, l.ws.bytes));
+        void* p = arena.get(l.ws.bytes);
         owned.push_back(p);
         l.ws.ptr = (double*)p;
         lanes.push_back(l);
@@ -151,8 +200,7 @@ Context::~Context()
     if (fork_ev) (void)hipEventDestroy(fork_ev);
     for (hipEvent_t e : marks) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamSynchronize(stream);
-    for (void* p : owned) (void)hipFree(p);
-    for (auto& kv : cache) (void)hipFree(kv.second.first);
+    arena.destroy();   // every block the context ever obtained: owned, cached scratch and idle ones
     if (scal_host) (void)hipHostFree(scal_host);
     if (stream) (void)hipStreamDestroy(stream);
 }
@@ -378,6 +426,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
                 if (all.size() % 2) all.push_back(0);
             }
             int64_t* base = upload(cx, all);
+            cx.plan_bytes += all.size() * sizeof(int64_t);
             for (int q = 0; q < 6; ++q) *dst[q] = base + start[q];
         }
         it = cx.plans.emplace(key, p).first;

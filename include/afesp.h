@@ -171,6 +171,10 @@ int afesp_ccsd_is_split(afesp_ctx* ctx, int* split);
  * callers compare it across ranks before sharding (bench.py and els_amd put it into their first all-reduce). */
 int afesp_ccsd_t_block_size(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr, int* block_size);
 
+/* The context's device arena (csrc/contract.hip): out = {allocations that reached the driver, requests served from blocks the
+ * context had given back, idle bytes, live bytes}. */
+int afesp_arena_stats(afesp_ctx* ctx, double out[4]);
+
 /* Test hook: what = 1 makes the next laned (small-system) amplitude update throw once, from a lane other than the main one
  * -- the failure mode of a capture that dies half-way (tests/test_gpu_cc.py). */
 int afesp_test_inject(afesp_ctx* ctx, int what);
