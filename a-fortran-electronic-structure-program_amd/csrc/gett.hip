@@ -167,7 +167,10 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
 // RAG = false: the K range of every workgroup is whole K steps, which compiles the K-tail masking (8 v_cndmask per
 // 16-byte LDS store, 48 of the ~65 VALU instructions of a K step of the 256x128 tile) out of the loop
 template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int W, bool GRP = false, bool RAG = !GRP>
-__global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
+// Occupancy bound of the 4-wave tiles: two waves per SIMD, i.e. a budget of 256 registers.  With more than that hipcc keeps
+// the accumulators in AGPRs, and on gfx950 v_mfma_f64_16x16x4_f64 with AGPR accumulators issues every 138 cycles instead of
+// every 64 (tools/mfma_peak.hip: 34.7 against 77.7 TFLOP/s, one wave per SIMD, sixteen independent accumulators).
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AFESP_GETT_VARIANT_ & 2048)) ? 2 : 1) void gett_kernel(GettKernelArgs a)
 {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gett_kernel(GettKernelArgs a)
         d[0] = __builtin_amdgcn_s_memtime() - stamp_t0;
         d[1] = stamp_bar;
         d[2] = stamp_stash;
-        d[3] = (VARIANT & 128) ? (stamp_n | (stamp_n2 << 20)) : stamp_n;
+        d[3] = (VARIANT & 128) ? (stamp_n | ((stamp_n2 / (stamp_n ? stamp_n : 1)) << 20)) : stamp_n;
     }
 #undef AFESP_GETT_STEP
 }
@@ -685,7 +688,9 @@ hipError_t gett_launch_grouped(const GettProblem& p, const GettGroup* dev_groups
     if (a.gm > a.mtiles) a.gm = a.mtiles;
     dim3 grid((unsigned)total_tiles, 1, 1);
     if (tm == 16) {
-        if (wide) launch_one<4, 2, 4, 4, true, true, 2, true>(a, grid, stream);
+        if (wide) {
+            launch_one<4, 2, 4, 4, true, true, 2, true>(a, grid, stream);
+        }
         else return hipErrorInvalidValue;
     } else {
         if (wide) launch_one<2, 4, 4, 2, true, true, 2, true>(a, grid, stream);

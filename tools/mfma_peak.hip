@@ -21,6 +21,23 @@ __global__ __launch_bounds__(256, (NACC <= 8 ? 2 : 1)) void k(double* out, unsig
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 template <int NACC>
+__global__ __launch_bounds__(256, 2) void k2(double* out, unsigned long long* clk, int iters)
+{
+    v4d acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = (v4d){0, 0, 0, 0};
+    double a = threadIdx.x * 1e-3 + 0.5, b = 1.0 - threadIdx.x * 1e-4;
+    unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+template <int NACC>
 __global__ __launch_bounds__(256, 2) void k4(double* out, unsigned long long* clk, int iters)
 {
     double acc[NACC];
@@ -90,16 +107,16 @@ void runv(int blocks, int iters, const char* tag)
            ms, fl / ms / 1e9, (double)h[0] / ((double)h[1] * 10.0), (double)h[0] / ((double)iters * NACC));
     CK(hipFree(d)); CK(hipFree(c));
 }
-template <int NACC>
+template <int NACC, bool TWO = false>
 void run(int blocks, int iters, const char* tag)
 {
     double* d; unsigned long long* c;
     CK(hipMalloc(&d, sizeof(double) * blocks * 256));
     CK(hipMalloc(&c, sizeof(unsigned long long) * blocks * 2));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    k<NACC><<<blocks, 256>>>(d, c, 10);
+    if (TWO) k2<NACC><<<blocks, 256>>>(d, c, 10); else k<NACC><<<blocks, 256>>>(d, c, 10);
     CK(hipEventRecord(e0));
-    k<NACC><<<blocks, 256>>>(d, c, iters);
+    if (TWO) k2<NACC><<<blocks, 256>>>(d, c, iters); else k<NACC><<<blocks, 256>>>(d, c, iters);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long h[2]; CK(hipMemcpy(h, c, sizeof(h), hipMemcpyDeviceToHost));
@@ -113,6 +130,10 @@ void run(int blocks, int iters, const char* tag)
 int main()
 {
     run<16>(256, 20000, "1 wave/SIMD");
+    run<8>(256, 20000, "1 wave/SIMD n8");
+    run<16, true>(256, 20000, "1w, 256-reg");
+    run<16, true>(512, 20000, "2w, 256-reg");
+    run<12, true>(512, 20000, "2w, 256-reg");
     run<16>(512, 20000, "2 waves/SIMD");
     run<8>(512, 20000, "2 waves/SIMD");
     run<4>(1024, 40000, "4 waves/SIMD");

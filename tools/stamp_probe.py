@@ -19,7 +19,7 @@ def main():
         a = a[a[:, :, 3].min(axis=1) > 0]
         raw = a[..., 3].astype(np.uint64)
         a[..., 3] = (raw & np.uint64((1 << 20) - 1)).astype(np.float64)
-        dw = (raw >> np.uint64(20)).astype(np.float64)      # variant bit 128: cycles waiting for the gathered data (vmcnt(0))
+        dw = (raw >> np.uint64(20)).astype(np.float64) * a[..., 3]   # variant bit 128: cycles waiting for the gathered data; ping-pong: C01 phase
         tot, bar, st, n = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
         print(f"K={K}: {2.0*M*N*K/ms/1e9:.1f} TF  workgroups {a.shape[0]}  steps/wave {n.mean():.0f}  cycles/step {np.mean(tot/n):.0f} "
               f"(MFMA floor 8192)  barrier {np.mean(bar/n):.0f}  stash {np.mean(st/n):.0f}")
