@@ -396,12 +396,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
             stB.stash(lds + (cur ^ 1) * STAGE + TA::SIZE, pb, t, kbeg + ktn * BK, kend, tail);  \
             if (VARIANT & 64) { __builtin_amdgcn_sched_barrier(0); stamp_stash += __builtin_amdgcn_s_memtime() - s0_; __builtin_amdgcn_sched_barrier(0); } \
         }
-#define AFESP_GETT_STEP(qa, qb, pa, pb, EARLY)                                                  \
+#define AFESP_GETT_STEP(qa, qb, pa, pb, EARLY) AFESP_GETT_STEP_(qa, qb, pa, pb, EARLY, false)
+#define AFESP_GETT_STEP_(qa, qb, pa, pb, EARLY, STEADY)                                         \
     {                                                                                           \
         const int cur = g & 1;                                                                  \
         const double* cA = lds + cur * STAGE;                                                   \
         const double* cB = cA + TA::SIZE;                                                       \
-        const bool ld = g + 2 < G, st = g + 1 < G;                                              \
+        const bool ld = (STEADY) || g + 2 < G, st = (STEADY) || g + 1 < G;                      \
         const int ktn = (kt + 1 == nk) ? 0 : kt + 1;                                            \
         const bool tail = ragged && (ktn == nk - 1);                                            \
         if (EARLY) { AFESP_GETT_STASH(pa, pb) }                                                 \
@@ -443,6 +444,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
 #define AFESP_GETT_LOOP(EARLY)                                                                  \
     {                                                                                           \
         int g = 0;                                                                              \
+        if (!GRP || (VARIANT & 4096))   /* (the grouped kernel spills 49 registers with this second body: A/B 518 -> 591 ms) */ \
+            for (; g + 3 < G; g += 2) {   /* steady state: every step gathers and writes, no flags (+1 % on the plain tiles) */ \
+                AFESP_GETT_STEP_(ra0, rb0, ra1, rb1, EARLY, true)                               \
+                ++g;                                                                            \
+                AFESP_GETT_STEP_(ra1, rb1, ra0, rb0, EARLY, true)                               \
+                --g;                                                                            \
+            }                                                                                   \
         for (; g + 1 < G; g += 2) {                                                             \
             AFESP_GETT_STEP(ra0, rb0, ra1, rb1, EARLY)                                          \
             ++g;                                                                                \
