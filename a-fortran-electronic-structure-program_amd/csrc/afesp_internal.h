@@ -6,6 +6,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gett.h"
@@ -81,6 +82,16 @@ struct Context {
         hipEvent_t done = nullptr;
     };
     std::vector<Lane> lanes;
+    // Lanes made ahead of time on the context's start-up thread (afesp_ctx_create): five streams are five hardware queues,
+    // 10-25 ms that a small molecule would otherwise pay inside its first iteration.  fork() adopts them.
+    struct Prepared {
+        std::vector<Lane> lanes;
+        void* ws_block = nullptr;
+        size_t ws_bytes = 0;
+    };
+    Prepared prepared;
+    std::thread startup;                  // makes `prepared` and preloads the kernels' code; joined by fork() and at destruction
+    static void prepare_lanes(Prepared& out, int nlanes);   // no access to the context: safe beside the caller's thread
     hipEvent_t fork_ev = nullptr;
     int cur_lane = 0;
     void fork(int nlanes);                // every lane waits for what the main stream has queued so far
@@ -94,6 +105,13 @@ struct Context {
     double* scal_host = nullptr;          // pinned mirror
     std::map<std::string, Plan> plans;
     size_t plan_bytes = 0;                // device bytes of their offset tables
+    // plan tables come out of slabs (a small system builds ~45 plans in its first iteration: one device allocation each was
+    // a third of that iteration); large tables get blocks of their own
+    std::vector<void*> plan_blocks;
+    int64_t* plan_slab = nullptr;
+    size_t plan_slab_left = 0;
+    int64_t* plan_alloc(size_t n);        // n int64, 16-byte aligned, not zeroed
+    void plan_clear();                    // drops every plan and its tables
     std::map<std::string, std::pair<void*, size_t>> cache;   // named scratch buffers kept across calls (not zeroed)
     std::string last_error;
     // optional HIP-event timing of the (T) launches (bench.py roofline): enabled by afesp_profile
@@ -168,6 +186,16 @@ void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1
 // Fock matrix from the half-unpacked integrals u(x,y,P) (k_unpack_half); work holds k_build_fock_work(n) doubles
 void k_build_fock(Context& cx, double* fock, const double* hcore, const double* dens, const double* u, double* work, int n);
 int64_t k_build_fock_work(int n);
-double* host_scalars(Context& cx, int n);   // copies cx.scal[0..n) to pinned host memory and synchronises
+double* host_scalars(Context& cx, int n);
+
+// Code-object preload: the runtime loads a translation unit's device code on the first use of one of its kernels (55-70 ms for
+// the GEMM instantiations alone).  Each unit names one of its kernels here; afesp_ctx_create asks for their attributes on a
+// background thread, so the load runs beside the caller's host work (input parsing, the SCF set-up) instead of inside the
+// first CCSD iteration.
+void preload_gett();
+void preload_contract();
+void preload_kernels();
+void preload_ccsd_so();
+void preload_triples();   // copies cx.scal[0..n) to pinned host memory and synchronises
 
 }  // namespace afesp

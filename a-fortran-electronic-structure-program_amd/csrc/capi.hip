@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/afesp.h"
@@ -101,11 +102,16 @@ static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body 
         body();
         return;
     }
-    if (g.calls == 0 || g.epoch != cx.scratch_epoch) {
+    // Capturing and instantiating the ~110-node graph costs ~10 ms; a replay saves ~0.1 ms over the laned launches.  A real
+    // molecule converges in 15-30 iterations, so the capture waits until a context has iterated long enough for it to pay
+    // (AFESP_GRAPH_AFTER, default 40 calls).
+    const char* ga = getenv("AFESP_GRAPH_AFTER");
+    const int graph_after = ga ? atoi(ga) : 40;
+    if (g.calls == 0 || g.epoch != cx.scratch_epoch || g.calls < graph_after) {
         // first call, or cached scratch buffers were dropped since the last one: whatever the body (re)builds or allocates is
         // done here, outside any capture
         body();
-        g.calls = 1;
+        g.calls = (g.epoch != cx.scratch_epoch) ? 1 : g.calls + 1;
         g.epoch = cx.scratch_epoch;
         return;
     }
@@ -179,8 +185,23 @@ int afesp_ctx_create(int device, afesp_ctx** out)
         c->cx.ws.bytes = (size_t)256 << 20;   // split-K slabs
         c->cx.ws.ptr = c->cx.alloc((int64_t)(c->cx.ws.bytes / sizeof(double)));
         c->cx.sync();
+        // The device code of a translation unit is loaded on the first use of one of its kernels -- 55-70 ms in all, which a
+        // small molecule would pay inside its first CCSD iteration.  Ask for it now, on a thread of its own: the caller goes
+        // on with its host work (parsing eri.dat, the SCF set-up) meanwhile.  AFESP_NO_PRELOAD=1 switches it off.
+        const char* np = getenv("AFESP_NO_PRELOAD");
+        if (!(np && np[0] == '1'))
+            c->cx.startup = std::thread([device, c] {
+                if (hipSetDevice(device) != hipSuccess) return;
+                Context::prepare_lanes(c->cx.prepared, 6);   // (the context itself is not touched: fork() adopts them)
+                preload_kernels();
+                preload_contract();
+                preload_gett();
+                preload_triples();
+                preload_ccsd_so();
+            });
     });
     if (rc) {
+        if (c->cx.startup.joinable()) c->cx.startup.join();
         delete c;
         return rc;
     }
@@ -192,6 +213,7 @@ void afesp_ctx_destroy(afesp_ctx* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cx.device);
+    if (ctx->cx.startup.joinable()) ctx->cx.startup.join();
     ctx->graph_cc.reset();
     comm_destroy(ctx->cx.comm);
     ctx->cx.comm = nullptr;

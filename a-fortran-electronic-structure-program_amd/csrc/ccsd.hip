@@ -121,12 +121,7 @@ void ccsd_free(Context& cx, CCState& s)
     // n^2 npair entries: rebuilding them costs a quarter of a second at n = 220), so a new system of the same extents finds
     // them again.  Their offset tables are device memory, though: a context that has seen many different systems drops them
     // here, where no captured iteration refers to them.
-    if (cx.plans.size() > 1024 || cx.plan_bytes > ((size_t)4 << 30)) {
-        for (auto& kv : cx.plans)
-            if (!kv.second.repack) cx.release(kv.second.offAm);
-        cx.plans.clear();
-        cx.plan_bytes = 0;
-    }
+    if (cx.plans.size() > 1024 || cx.plan_bytes > ((size_t)4 << 30)) cx.plan_clear();
     cx.drop_scratch();
     triples_plan_free(s);
     s = CCState();

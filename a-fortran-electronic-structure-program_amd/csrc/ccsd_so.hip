@@ -35,6 +35,14 @@ __global__ void slice_asym_kernel(double* out, const double* packed, int d0, int
 }
 
 // ccsd.f90:437-448
+}  // namespace
+void preload_ccsd_so()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(slice_asym_kernel));
+    (void)hipGetLastError();
+}
+namespace {
 __global__ void so_denominators_kernel(double* D1, double* D2, const double* e, int o, int v)
 {
     const int64_t n2 = (int64_t)o * o * v * v, n1 = (int64_t)o * v;

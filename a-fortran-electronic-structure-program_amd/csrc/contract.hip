@@ -127,6 +127,36 @@ void Context::release(void* p)
         arena.put(p);
     }
 }
+int64_t* Context::plan_alloc(size_t n)
+{
+    n = (n + 1) & ~(size_t)1;
+    constexpr size_t SLAB = (size_t)1 << 19;   // 4 MiB of int64
+    if (n > SLAB / 4) {
+        void* p = arena.get(n * sizeof(int64_t));
+        plan_blocks.push_back(p);
+        return (int64_t*)p;
+    }
+    if (plan_slab_left < n) {
+        plan_slab = (int64_t*)arena.get(SLAB * sizeof(int64_t));
+        plan_blocks.push_back(plan_slab);
+        plan_slab_left = SLAB;
+    }
+    int64_t* p = plan_slab;
+    plan_slab += n;
+    plan_slab_left -= n;
+    return p;
+}
+void Context::plan_clear()
+{
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (void* p : plan_blocks) arena.put(p);
+    plan_blocks.clear();
+    plan_slab = nullptr;
+    plan_slab_left = 0;
+    plans.clear();
+    plan_bytes = 0;
+}
+
 Tensor Context::tensor(std::initializer_list<int64_t> dims)
 {
     int64_t n = 1;
@@ -138,17 +168,27 @@ void Context::sync() { AFESP_HIP(hipStreamSynchronize(stream)); }
 void Context::fork(int nlanes)
 {
     if (cur_lane != 0) throw Error(1, "Context::fork: already forked");
+    if (startup.joinable()) startup.join();
     if (lanes.empty()) {
         lanes.resize(1);
         lanes[0].stream = stream;
         lanes[0].ws = ws;
         AFESP_HIP(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
     }
+    if (lanes.size() == 1 && !prepared.lanes.empty()) {   // made on the start-up thread (joined by the caller of fork)
+        if (prepared.ws_block) {
+            arena.live[prepared.ws_block] = prepared.ws_bytes;
+            owned.push_back(prepared.ws_block);
+        }
+        for (Lane& l : prepared.lanes) lanes.push_back(l);
+        prepared.lanes.clear();
+        prepared.ws_block = nullptr;
+    }
     while ((int)lanes.size() < nlanes) {
         Lane l;
         AFESP_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         AFESP_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
-        l.ws.bytes = (size_t)32 << 20;   // lanes only carry small problems
+        l.ws.bytes = (size_t)8 << 20;   // lanes only carry small problems
         void* p = arena.get(l.ws.bytes);
         owned.push_back(p);
         l.ws.ptr = (double*)p;
@@ -156,6 +196,29 @@ void Context::fork(int nlanes)
     }
     AFESP_HIP(hipEventRecord(fork_ev, lanes[0].stream));
     for (size_t i = 1; i < lanes.size(); ++i) AFESP_HIP(hipStreamWaitEvent(lanes[i].stream, fork_ev, 0));
+}
+
+void Context::prepare_lanes(Prepared& out, int nlanes)
+{
+    const size_t each = (size_t)8 << 20;
+    void* block = nullptr;
+    if (nlanes < 2 || hipMalloc(&block, each * (size_t)(nlanes - 1)) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    out.ws_block = block;
+    out.ws_bytes = each * (size_t)(nlanes - 1);
+    for (int i = 1; i < nlanes; ++i) {
+        Lane l;
+        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            break;   // fork() makes the rest
+        }
+        l.ws.ptr = (double*)((char*)block + each * (size_t)(i - 1));
+        l.ws.bytes = each;
+        out.lanes.push_back(l);
+    }
 }
 
 void Context::use_lane(int i)
@@ -191,12 +254,18 @@ void Context::join()
 }
 Context::~Context()
 {
+    if (startup.joinable()) startup.join();
     use_lane(0);
     for (size_t i = 1; i < lanes.size(); ++i) {
         (void)hipStreamSynchronize(lanes[i].stream);
         (void)hipStreamDestroy(lanes[i].stream);
         (void)hipEventDestroy(lanes[i].done);
     }
+    for (Lane& l : prepared.lanes) {
+        (void)hipStreamDestroy(l.stream);
+        (void)hipEventDestroy(l.done);
+    }
+    if (prepared.ws_block) (void)hipFree(prepared.ws_block);
     if (fork_ev) (void)hipEventDestroy(fork_ev);
     for (hipEvent_t e : marks) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamSynchronize(stream);
@@ -277,7 +346,7 @@ std::vector<int64_t> table(const std::vector<Lab>& g, int which)
 
 int64_t* upload(Context& cx, const std::vector<int64_t>& h)
 {
-    int64_t* d = cx.alloc_i64((int64_t)h.size());
+    int64_t* d = cx.plan_alloc(h.size());
     AFESP_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
     AFESP_HIP(hipStreamSynchronize(cx.stream));   // h is a temporary
     return d;
@@ -533,6 +602,13 @@ __global__ __launch_bounds__(256) void permute_add_tiled_kernel(double* __restri
             out[addr] = val;
         }
     }
+}
+
+void preload_contract()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(permute_add_kernel));
+    (void)hipGetLastError();
 }
 
 void permute_add(Context& cx, double alpha, const Tensor& in, const char* li, double beta, const Tensor& out, const char* lo)

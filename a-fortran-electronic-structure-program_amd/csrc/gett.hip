@@ -523,6 +523,33 @@ __global__ __launch_bounds__(256) void gett_reduce_kernel(GettKernelArgs a)
 
 int g_dbg = 0;
 
+// Every instantiation the launchers can pick (the lists in gett_launch / gett_launch_grouped): the runtime resolves a kernel
+// function on its first use (~0.7 ms each), which adds up to 30 ms in the first iteration of a small molecule.
+template <int WM, int WN, int TM, int TN, int W>
+static void preload_cfg()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, true, true, W>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, true, false, W>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, false, true, W>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, false, false, W>));
+}
+void preload_gett()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_reduce_kernel));
+    // the small tiles first: they are what a small molecule launches within milliseconds of the context's creation
+    preload_cfg<2, 2, 1, 1, 1>(); preload_cfg<2, 2, 1, 2, 1>(); preload_cfg<2, 2, 1, 4, 1>();
+    preload_cfg<2, 2, 2, 1, 1>(); preload_cfg<2, 2, 2, 2, 1>(); preload_cfg<2, 2, 2, 2, 2>(); preload_cfg<2, 2, 2, 4, 1>(); preload_cfg<2, 2, 2, 4, 2>();
+    preload_cfg<2, 2, 4, 1, 1>(); preload_cfg<2, 2, 4, 2, 1>(); preload_cfg<2, 2, 4, 2, 2>();
+    preload_cfg<2, 4, 4, 2, 1>(); preload_cfg<2, 4, 4, 2, 2>();
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<2, 4, 4, 2, true, true, 2, true>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<2, 4, 4, 2, true, true, 1, true>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<4, 2, 4, 4, true, true, 2, true>));
+    preload_cfg<4, 2, 4, 4, 1>(); preload_cfg<4, 2, 4, 4, 2>(); preload_cfg<2, 4, 4, 4, 1>(); preload_cfg<2, 4, 4, 4, 2>();
+    (void)hipGetLastError();
+}
+
 hipError_t gett_read_stamps(unsigned long long* out, int n)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gett_stamp), sizeof(unsigned long long) * (size_t)(n < 256 * 8 * 4 ? n : 256 * 8 * 4));

@@ -288,6 +288,12 @@ __global__ void fock_reduce_kernel(double* fock, const double* hcore, const doub
         AFESP_HIP(hipGetLastError());                                           \
     } while (0)
 
+void preload_kernels()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(fill_kernel));
+    (void)hipGetLastError();
+}
 void k_fill(Context& cx, double* x, int64_t n, double val) { if (n > 0) LAUNCH(fill_kernel, dim3(grid_for(n)), x, n, val); }
 void k_copy(Context& cx, double* dst, const double* src, int64_t n)
 {

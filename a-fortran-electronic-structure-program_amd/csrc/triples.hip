@@ -50,6 +50,13 @@ __global__ __launch_bounds__(256) void triples_sum_kernel(double* out, const dou
     }
 }
 
+void preload_triples()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_sum_kernel));
+    (void)hipGetLastError();
+}
+
 // out[q] += sum of partial[q][0..nblk) for q < nq, two stages when there are many partials; `tmp` holds nq * 128 doubles
 static void sum_partials(Context& cx, double* out, const double* partial, int nq, int nblk, double* tmp)
 {

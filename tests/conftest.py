@@ -12,6 +12,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # the library is loaded.
 os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 16)))
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# The engine captures a small system's iteration into a hipGraph only after 40 calls (a real solve is shorter than the capture
+# pays for); the tests want the replayed path exercised from the second call on, as a long run would see it.
+os.environ.setdefault("AFESP_GRAPH_AFTER", "1")
 
 
 def pytest_configure(config):

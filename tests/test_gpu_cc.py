@@ -195,6 +195,21 @@ def test_failed_graph_capture_leaves_a_working_context():
         assert np.max(np.abs(out - cc.triples(e))) < 1e-10
 
 
+def test_default_graph_policy_short_solve_runs_unreplayed(monkeypatch):
+    """Default policy (AFESP_GRAPH_AFTER unset = 40 calls): a solve of ordinary length never captures a graph -- the laned
+    launches alone must walk the oracle's iteration path too."""
+    from afesp_amd.capi import Engine
+    monkeypatch.delenv("AFESP_GRAPH_AFTER", raising=False)
+    o, v = 4, 9
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05)
+    cc = orc.OracleCC(o, v, eri, e, 8)
+    onit, oen, _ = cc.solve(40, 1e-8, 1e-9)
+    with Engine(0) as eng2:
+        eng2.ccsd_init(o, v, e, eri, 8)
+        nit, en, _ = eng2.do_ccsd_spatial(40, 1e-8, 1e-9)
+    assert nit == onit and np.max(np.abs(en[:nit + 1] - oen[:onit + 1])) < 1e-10
+
+
 def test_pp_ladder_split_form_through_the_replayed_iteration(eng, monkeypatch):
     """The pair form inside the laned, graph-replayed iteration of a small system: a whole solve against the oracle."""
     monkeypatch.setenv("AFESP_PP_SYM", "1")
