@@ -82,9 +82,9 @@ __global__ void synth_packed_kernel(double* packed, int64_t n, double scale, uin
 
 }  // namespace
 
-// Runs `body` (launches on the context's lanes, no host synchronisation) directly the first time, captures it into a graph
-// the second time and replays the graph afterwards.  Nothing executes during capture, so a failed capture simply falls
-// back to running the body.
+// Runs `body` (launches on the context's lanes, no host synchronisation) directly for the first AFESP_GRAPH_AFTER calls,
+// then captures it into a graph once and replays the graph afterwards.  Nothing executes during capture, so a failed
+// capture simply falls back to running the body.
 template <typename Body>
 static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body body)
 {

@@ -500,6 +500,8 @@ def main():
                     help="skip the additional measurements appended to the line: the H2O/cc-pVTZ shape (config 2), the bundled "
                          "N2 / F2 inputs (configs 3 / 4) with their energy check, the spin-orbital H2O/cc-pVTZ shape")
     ap.add_argument("--scale", type=float, default=None)
+    ap.add_argument("--steps-only", dest="legs", action="store_false",
+                    help="only the timed steps: no pp-ladder / AO->MO timing legs behind them (kernel traces of the steps alone)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the multi-rank path on a one-GPU box")
     args = ap.parse_args()
@@ -530,7 +532,7 @@ def main():
         torch.cuda.set_device(local)
     cdev = "cpu" if (world > 1 and args.backend == "gloo") else f"cuda:{local}"   # where torch's collectives run
 
-    res = measure(args, args.workload, args.steps, args.warmup, rank, world, local, dist, cdev, torch, jobdir)
+    res = measure(args, args.workload, args.steps, args.warmup, rank, world, local, dist, cdev, torch, jobdir, with_roofline=args.legs)
     others = {}
     if args.extra:
         if args.workload != "h2o_tz":

@@ -2,7 +2,7 @@
 # HBM traffic (rocprofv3 PMC, one counter per pass) of the AO->MO and Fock-build kernels at n = 220.
 # usage (on the GPU box): tools/pmc_ao2mo_fock.sh r01   -> gpurun_out/<tag>_pmc_ao2mo_fock.json
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out
 mkdir -p $O

@@ -1,22 +1,23 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round (run on the GPU box through gpurun; outputs land in gpurun_out/
-# and are copied to profiles/ afterwards).  usage: tools/refresh_profiles.sh r01
+# and are copied to profiles/ afterwards).  usage: tools/refresh_profiles.sh r02
+# bench.py's default workload is config 5 (o=20, v=200); the H2O/cc-pVTZ shape is --workload h2o_tz.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 echo "== bench lines"; date
-python3 $R/bench.py | tail -1 > $O/${TAG}_bench_default_line.json || exit 1
-python3 $R/bench.py --workload cfg5 --steps 3 --warmup 1 | tail -1 > $O/${TAG}_bench_cfg5_line.json || exit 1
+python3 $R/bench.py | tail -1 > $O/${TAG}_bench_cfg5_line.json || exit 1
+python3 $R/bench.py --workload h2o_tz --steps 50 --warmup 45 --no-extra | tail -1 > $O/${TAG}_bench_h2o_tz_line.json || exit 1
 echo "== kernel traces"; date
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_def -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra > $O/kt_def.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_cfg5 -- python3 $R/bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline > $O/kt_cfg5.log 2>&1 || exit 1
-python3 $R/tools/summarize_profile.py /tmp/kt_def > $O/${TAG}_bench_default_kernels.json
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_cfg5 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/kt_cfg5.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_h2o -- python3 $R/bench.py --workload h2o_tz --steps 50 --warmup 45 --no-cpu-baseline --no-extra --steps-only > $O/kt_h2o.log 2>&1 || exit 1
 python3 $R/tools/summarize_profile.py /tmp/kt_cfg5 > $O/${TAG}_bench_cfg5_kernels.json
-python3 $R/tools/small_system_gaps.py /tmp/kt_def 600 > $O/${TAG}_bench_default_gaps.txt
+python3 $R/tools/summarize_profile.py /tmp/kt_h2o > $O/${TAG}_bench_h2o_tz_kernels.json
+python3 $R/tools/small_system_gaps.py /tmp/kt_h2o 600 > $O/${TAG}_bench_h2o_tz_gaps.txt
 echo "== PMC passes (one counter per pass)"; date
 bash $R/tools/refresh_traffic.sh $TAG || exit 1
 bash $R/tools/pmc_ao2mo_fock.sh $TAG || exit 1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The PMC part of refresh_profiles.sh alone (FETCH_SIZE / WRITE_SIZE / GRBM_GUI_ACTIVE / MFMA busy, one counter per pass).
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out
 mkdir -p $O
