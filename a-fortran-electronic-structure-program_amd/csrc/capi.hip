@@ -1114,6 +1114,7 @@ int afesp_ccsd_t_block_size(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr,
 // diagnostic builds of the GEMM kernel (AFESP_GETT_VARIANT bit 64): the per-wave cycle stamps of the last launch
 int afesp_debug_stamps(unsigned long long* out, int n)
 {
+    if (n < 0) return triples_read_orbit_stamps(out, -n) == hipSuccess ? 0 : 1;   // the (T) orbit kernel's phase sums
     return gett_read_stamps(out, n) == hipSuccess ? 0 : 1;
 }
 

@@ -73,6 +73,7 @@ int64_t triples_count(int o);
 void triples_shard_bounds(int o, int v, bool cr, int world, int64_t* bounds);
 // occupied block size of the flat triple order on this device (ranks must agree on it)
 int triples_block_size(int o, int v, bool cr);
+hipError_t triples_read_orbit_stamps(unsigned long long* out, int n);   // diagnostic builds only (triples_orbit.h)
 // cr = true: also out[4] = sum t_bar.M3, out[5] = out[4] + sum z_bar.M3 (needs ccsd_cr_intermediates)
 // want_d = false: only out[0], out[1] (what plain CCSD(T)/[T] need; the reference skips y and the D sums there too)
 void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, double* out_host, bool cr = false, bool want_d = true);

@@ -50,6 +50,25 @@ __global__ __launch_bounds__(256) void triples_sum_kernel(double* out, const dou
     }
 }
 
+// diagnostic builds (-DAFESP_ORBIT_STAMPS): reads and clears the orbit kernel's phase sums (triples_orbit.h)
+hipError_t triples_read_orbit_stamps(unsigned long long* out, int n)
+{
+#ifdef AFESP_ORBIT_STAMPS
+    std::vector<unsigned long long> buf((size_t)ORB_SLOTS * 16, 0ull);
+    hipError_t e = hipMemcpyFromSymbol(buf.data(), HIP_SYMBOL(g_orbit_stamp), sizeof(unsigned long long) * buf.size());
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < n && i < 16; ++i) {
+        out[i] = 0;
+        for (int sl = 0; sl < ORB_SLOTS; ++sl) out[i] += buf[(size_t)sl * 16 + i];
+    }
+    std::fill(buf.begin(), buf.end(), 0ull);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_orbit_stamp), buf.data(), sizeof(unsigned long long) * buf.size());
+#else
+    for (int i = 0; i < n && i < 16; ++i) out[i] = 0;
+    return hipSuccess;
+#endif
+}
+
 void preload_triples()
 {
     hipFuncAttributes at;

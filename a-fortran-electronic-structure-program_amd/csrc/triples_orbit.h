@@ -21,6 +21,28 @@ struct TriplesIn {
     int o, v;
 };
 
+// Diagnostic builds only (-DAFESP_ORBIT_STAMPS): cycles of wave 0 of a sample of workgroups (one slot per linear block index modulo
+// ORB_SLOTS, plain stores -- atomics on one address serialise the whole launch), per phase -- [0] prologue up to the first barrier,
+// [1+2s] barrier + park + barrier of term s (includes the wait for its HBM data), [2+2s] its permuted reads, [7] energy phase,
+// [8] reduction and store, [9] = 1.  Read (summed over the slots) with afesp_debug_stamps(out, -10).
+#ifdef AFESP_ORBIT_STAMPS
+constexpr int ORB_SLOTS = 4096;
+__device__ unsigned long long g_orbit_stamp[ORB_SLOTS * 16];
+#define ORB_STAMP(k)                                                                                                          \
+    {                                                                                                                         \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                         \
+        if (threadIdx.x == 0) g_orbit_stamp[((blockIdx.y * gridDim.x + blockIdx.x) % ORB_SLOTS) * 16 + (k)] = now_ - orb_last_; \
+        orb_last_ = now_;                                                                                                     \
+    }
+#else
+#define ORB_STAMP(k) {}
+#endif
+
+// terms requested ahead of the one being permuted (A/B in one session, tools/build_orbit_variant.sh with
+// EXTRA=-DAFESP_ORBIT_DEPTH=n, config 5: plain 52.5 / 51.8 / 55.0 ms for n = 1 / 2 / 3, completely renormalised 184 / 174 / 169 ms)
+#ifndef AFESP_ORBIT_DEPTH
+#define AFESP_ORBIT_DEPTH 0   // 0: two, three for the completely renormalised variant
+#endif
 constexpr int TT = 8;                 // cube edge
 constexpr int CUBE = TT * TT * TT;    // 512 elements
 constexpr int PATCH = TT * TT;
@@ -34,7 +56,7 @@ __host__ __device__ constexpr int sig(int s, int d)
 }
 // 1/x for the energy denominators (sums of orbital-energy differences: finite, far from the ends of the exponent range):
 // v_rcp_f64 and two Newton steps, 5 instructions against the ~25 of an IEEE division with its scaling and fix-up -- the orbit
-// kernels are bound by instruction issue (~1800 per thread and item), not by HBM.  Relative error ~1e-16.
+// kernels were bound by instruction issue, not by HBM.  Relative error ~1e-16.
 __device__ __forceinline__ double rcp_nr(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
@@ -49,9 +71,7 @@ __device__ __forceinline__ int cidx(int p0, int p1, int p2) { return ((p0 ^ p1 ^
 // under the six permutations -- the smallest set closed under every index permutation the formulas use:
 //   W(a,b,c) = sum_s X_s(sigma_s(a,b,c))                                              ccsd.f90:2168-2173
 //   t_bar    = [4W(abc) + W(bca) + W(cab) - 2W(acb) - 2W(bac) - 2W(cba)] / 3D         symmetrised :2314-2318
-// Every X element is read from HBM exactly once (whole 4 KiB cubes, 16 bytes per lane) and W never leaves LDS.
-// Thread t owns elements el = t + 256 r (r = 0..11): cube q = r/2 is a compile-time constant after unrolling, so
-// every permuted index below resolves to a fixed register.
+// Every X element is read from HBM exactly once (whole 4 KiB cubes, 16 bytes per lane) and W never leaves the registers.
 // CR = true additionally assembles the completely-renormalised moment M3 (ccsd.f90:2186-2194) from a second pool of
 // blocks (same offsets) and accumulates sum t_bar.M3, sum z_bar.M3 (ccsd.f90:2222-2226); M3 is only needed at (a,b,c)
 // itself, so it stays in registers.
@@ -59,26 +79,43 @@ __device__ __forceinline__ int cidx(int p0, int p1, int p2) { return ((p0 ^ p1 ^
 // xoff[0], xoff[1], xoff[5]; they enter W at the permutations (abc), (bac), (cab) -- terms 0, 1, 5 of the six.
 __host__ __device__ constexpr int orbit_term(bool fused, int idx) { return fused ? (idx == 0 ? 0 : idx == 1 ? 1 : 5) : idx; }
 
+// Index of the composed permutation: sig(compose(q,s), d) == sig(q, sig(s, d)), i.e. sigma_s applied to the q-th image of an
+// element is its compose(q,s)-th image.
+__host__ __device__ constexpr int compose(int q, int s)
+{
+    for (int r = 0; r < 6; ++r)
+        if (sig(r, 0) == sig(q, sig(s, 0)) && sig(r, 1) == sig(q, sig(s, 1)) && sig(r, 2) == sig(q, sig(s, 2))) return r;
+    return 0;
+}
+
+// A THREAD owns the orbit of an element: with e = (a,b,c) in the base cube at local coordinates (l0,l1,l2), its q-th image
+// x^q = (e_sig(q,0), e_sig(q,1), e_sig(q,2)) lies in cube q at the permuted local coordinates, so the W assembly reads the
+// staged cubes at permuted coordinates and leaves W(x^0..x^5) in six registers (two orbits per thread).  Everything the
+// energy formulas combine -- W, Z and y at the six images, one common denominator -- is then in the thread's registers:
+// W is never written back to LDS, D and its reciprocal are evaluated once per orbit instead of once per element, and the
+// t1 rows / V patches are read 27 times per orbit instead of 6 x 6.  (Round 1 gave a thread the SAME local coordinates in all
+// six cubes: 72 LDS reads of W per thread, and the kernel was bound by instruction issue at 4.15 TB/s.)
+// A cube orbit whose tiles coincide has 6/|H| distinct cubes (H = the stabiliser of the tile triple): every element of the
+// distinct cubes is then visited by exactly |H| (thread, image) pairs, so the workgroup's sums are divided by |H|.
 // WANT_D = false (plain CCSD(T)/[T], which the reference also evaluates without y and the D sums, ccsd.f90:2181-2185 and
 // :2228-2247): only E[T] and the z term.  The symmetriser P in z_bar = P Z / D is self-adjoint and D is symmetric, and a
-// workgroup sums over a set of elements closed under every permutation, so  sum z_bar W = sum Z (P W)/D = sum Z t_bar:
-// ONE evaluation of Z per element (6 LDS reads) instead of six (27), and no t2 patches.
-// The plain variant also folds W onto the staging area once the last term has been permuted out (its patches fit behind
-// it), which brings a workgroup under 40 KiB of LDS: four per CU instead of three.
+// thread sums over a set of elements closed under every permutation, so  sum z_bar W = sum Z (P W)/D = sum Z t_bar.
 template <bool CR, bool FUSED, bool WANT_D = true>
-__global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(double* __restrict__ partial, const double* __restrict__ Xpool,
+__global__ __launch_bounds__(256, CR ? 2 : WANT_D ? 3 : 4) void triples_orbit_kernel(double* __restrict__ partial, const double* __restrict__ Xpool,
                                                             const double* __restrict__ Mpool,
                                                             const TripleMeta* __restrict__ meta,
                                                             const int* __restrict__ orbits, TriplesIn in, int nblk_total)
 {
-    constexpr bool ALIAS = !WANT_D;
-    // X cubes of one term; later the V / T2 patches and t1 rows (ALIAS: W, then the V patches and t1 rows)
-    __shared__ __attribute__((aligned(16))) double stage[ALIAS ? 6 * CUBE + 27 * PATCH + 96 : 6 * CUBE + 512];
-    __shared__ double wl_own[ALIAS ? 1 : 6 * CUBE];
-    double* const wl = ALIAS ? stage : wl_own;   // W on the six cubes of the orbit
+    __shared__ __attribute__((aligned(16))) double stage[6 * CUBE];   // the six cubes of one term
+    // patches: vp[pair][sx][sy][lx + 8 ly] = V_pair(x in tile[sx], y in tile[sy]); pairs (j,k), (i,k), (i,j); tp the same of t2
+    __shared__ double vp[27 * PATCH];
+    __shared__ double tp[WANT_D ? 27 * PATCH : 1];
+    __shared__ double t1r[96];                 // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l); then evl[slot][l] = e(o + tile[slot]*8 + l)
     __shared__ int srcq[6][6];                 // srcq[s][q]: which cube of the orbit is sigma_s applied to cube q
-    __shared__ int dup[6];                     // 1 if cube q repeats an earlier cube (degenerate orbit)
     __shared__ double red[24];
+#ifdef AFESP_ORBIT_STAMPS
+    unsigned long long orb_last_ = __builtin_amdgcn_s_memtime();
+#endif
     const TripleMeta m = meta[blockIdx.y];
     const int o = in.o, v = in.v, t = threadIdx.x;
     const int packed = orbits[blockIdx.x];
@@ -91,10 +128,9 @@ __global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(doub
         for (int r = 5; r >= 0; --r)
             if (tile[sig(r, 0)] == want[0] && tile[sig(r, 1)] == want[1] && tile[sig(r, 2)] == want[2]) found = r;
         srcq[s][q] = found;
-        if (s == 0) dup[q] = (found != q);
     }
     const int64_t vv = (int64_t)v * v;
-    // local coordinates of this thread's two elements per cube (half = 0, 1)
+    // local coordinates of this thread's two base elements (half = 0, 1)
     const int l0 = t & 7, l1 = (t >> 3) & 7, l2h[2] = {t >> 6, (t >> 6) + 4};
     // The X blocks are stored cube by cube (triples.hip: element (a,b,c) of a block sits at
     // 512*(a/8 + nt8*(b/8) + nt8^2*(c/8)) + a%8 + 8*(b%8) + 64*(c%8)), so one cube is 4 KiB of contiguous HBM: thread t
@@ -120,61 +156,38 @@ __global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(doub
         for (int q = 0; q < 6; ++q)
             *reinterpret_cast<v2d_t*>(&stage[q * CUBE + sbase]) = flip ? (v2d_t){xin[q][1], xin[q][0]} : xin[q];
     };
-    double wreg[12];
-    double mreg[CR ? 12 : 1];
-#pragma unroll
-    for (int r = 0; r < 12; ++r) wreg[r] = 0.0;
-#pragma unroll
-    for (int r = 0; r < (CR ? 12 : 1); ++r) mreg[r] = 0.0;
-    // term s+1 is in flight while term s is permuted out of LDS
+    // DEPTH terms are requested ahead of the one being permuted out of LDS (6 loads of 16 bytes per thread and term); the next
+    // one follows as soon as a term's registers are parked
     constexpr int NT1 = FUSED ? 3 : 6;
     constexpr int NTERM = CR ? 2 * NT1 : NT1;
-    v2d_t xin[6];
-    load_term(Xpool + m.xoff[orbit_term(FUSED, 0)], xin);
+    constexpr int DEPTH = AFESP_ORBIT_DEPTH > 0 ? (AFESP_ORBIT_DEPTH < NT1 ? AFESP_ORBIT_DEPTH : NT1) : CR ? 3 : 2;
+    v2d_t xin[DEPTH][6];
 #pragma unroll
-    for (int s2 = 0; s2 < NTERM; ++s2) {
-        const int s = orbit_term(FUSED, s2 % NT1);
-        // a block whose occupied pair coincides (Y^{p;qq}) holds X(x;y,z) only: Y = X + X with (y,z) exchanged, i.e. the same
-        // staged cubes read through the permutation s followed by that exchange: (abc)->(acb), (bac)->(bca), (cab)->(cba)
-        const int sT = s == 0 ? 3 : s == 1 ? 4 : 2;
-        const bool sym = FUSED && ((m.pad >> (s2 % NT1)) & 1);
-        __syncthreads();   // the previous term's readers are done with `stage` (also publishes srcq on the first pass)
-        park_term(xin);
-        if (s2 + 1 < NTERM) load_term((s2 + 1 < NT1 ? Xpool : Mpool) + m.xoff[orbit_term(FUSED, (s2 + 1) % NT1)], xin);
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 12; ++r) {
-            const int q = r >> 1;
-            const int l[3] = {l0, l1, l2h[r & 1]};
-            double x = stage[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])];
-            if (FUSED && sym) x += stage[srcq[sT][q] * CUBE + cidx(l[sig(sT, 0)], l[sig(sT, 1)], l[sig(sT, 2)])];
-            if (s2 < NT1) wreg[r] += x;
-            else mreg[CR ? r : 0] += x;
-        }
-    }
-    if (ALIAS) __syncthreads();   // the last term's readers are done with `stage`
-#pragma unroll
-    for (int r = 0; r < 12; ++r) wl[(r >> 1) * CUBE + cidx(l0, l1, l2h[r & 1])] = wreg[r];
-    if (!ALIAS) __syncthreads();  // ALIAS: the patches sit behind W, one barrier below publishes both
-    // patches: vp[pair][sx][sy][lx + 8 ly] = V_pair(x in tile[sx], y in tile[sy]); pairs (j,k), (i,k), (i,j)
-    double* vp = ALIAS ? stage + 6 * CUBE : stage;   // 3*9*64
-    double* tp = stage + 27 * PATCH;                 // 3*9*64 (WANT_D only)
-    double* t1r = ALIAS ? stage + 6 * CUBE + 27 * PATCH : stage + 54 * PATCH;   // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l)
-    double* evl = t1r + 72;              // evl[slot][l] = e(o + tile[slot]*8 + l): virtual orbital energies of the three tiles
-                                         // (LDS is granted in 1280-byte steps: an array of its own cost the full variant its
-                                         // third workgroup per CU)
+    for (int s2 = 0; s2 < DEPTH; ++s2) load_term(Xpool + m.xoff[orbit_term(FUSED, s2)], xin[s2]);
+    // the patches, t1 rows and virtual orbital energies of the three tiles travel under the first term.  Wave g stages patches
+    // g, g+4, ... of the 18 (three occupied pairs x six ordered pairs of tile slots) the energy phase reads: the patch index is
+    // wave-uniform, a lane owns one element
     const int occ[3] = {m.i, m.j, m.k};
     const int pairp[3] = {m.j, m.i, m.i}, pairq[3] = {m.k, m.k, m.j};
-    for (int el = t; el < 27 * PATCH; el += 256) {
-        const int pr = el / (9 * PATCH), rest = el % (9 * PATCH), sx = rest / (3 * PATCH), sy = (rest / PATCH) % 3, loc = rest % PATCH;
-        const int gx = tile[sx] * TT + (loc & 7), gy = tile[sy] * TT + (loc >> 3);
-        const bool ok = gx < v && gy < v;
-        const int64_t off = ok ? gx + (int64_t)v * gy + vv * (pairp[pr] + (int64_t)o * pairq[pr]) : 0;
-        const double a = in.voovv_s[off];
-        vp[el] = ok ? a : 0.0;
-        if (WANT_D) {
-            const double b = in.t2_s[off];
-            tp[el] = ok ? b : 0.0;
+    {
+        const int g = __builtin_amdgcn_readfirstlane(t >> 6), loc = t & 63;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int P = g + 4 * i;
+            if (P < 18) {
+                const int pr = P / 6, pi = P % 6;
+                const int sx = pi < 2 ? 0 : pi < 4 ? 1 : 2, sy = pi == 0 ? 1 : pi == 1 ? 2 : pi == 2 ? 0 : pi == 3 ? 2 : pi == 4 ? 0 : 1;
+                const int gx = tile[sx] * TT + (loc & 7), gy = tile[sy] * TT + (loc >> 3);
+                const bool ok = gx < v && gy < v;
+                const int64_t off = (ok ? gx + (int64_t)v * gy : 0) + vv * (pairp[pr] + (int64_t)o * pairq[pr]);
+                const int dst = (pr * 9 + sx * 3 + sy) * PATCH + loc;
+                const double a = in.voovv_s[off];
+                vp[dst] = ok ? a : 0.0;
+                if (WANT_D) {
+                    const double b = in.t2_s[off];
+                    tp[dst] = ok ? b : 0.0;
+                }
+            }
         }
     }
     if (t < 72) {
@@ -182,66 +195,145 @@ __global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(doub
         t1r[t] = g < v ? in.t1[occ[oc] + o * g] : 0.0;
     } else if (t < 96) {
         const int sl = (t - 72) / 8, l = t & 7, g = tile[sl] * TT + l;
-        evl[t - 72] = in.e[(g < v ? g : 0) + o];
+        t1r[t] = in.e[(g < v ? g : 0) + o];
     }
-    __syncthreads();
+    const double* evl = t1r + 72;
+    double wreg[12];                 // wreg[2q + h] = W at the q-th image of base element h
+    double mreg[CR ? 12 : 1];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) wreg[r] = 0.0;
+#pragma unroll
+    for (int r = 0; r < (CR ? 12 : 1); ++r) mreg[r] = 0.0;
+#pragma unroll
+    for (int s2 = 0; s2 < NTERM; ++s2) {
+        const int s = orbit_term(FUSED, s2 % NT1);
+        // a block whose occupied pair coincides (Y^{p;qq}) holds X(x;y,z) only: Y = X + X with (y,z) exchanged, i.e. the same
+        // staged cubes read through the permutation s followed by that exchange: (abc)->(acb), (bac)->(bca), (cab)->(cba)
+        const int sT = s == 0 ? 3 : s == 1 ? 4 : 2;
+        const bool sym = FUSED && ((m.pad >> (s2 % NT1)) & 1);
+        if (s2 == 0) ORB_STAMP(0)
+        __syncthreads();   // the previous term's readers are done with `stage` (also publishes srcq and the patches on the first pass)
+        park_term(xin[s2 % DEPTH]);
+        if (s2 + DEPTH < NTERM)
+            load_term((s2 + DEPTH < NT1 ? Xpool : Mpool) + m.xoff[orbit_term(FUSED, (s2 + DEPTH) % NT1)], xin[s2 % DEPTH]);
+        __syncthreads();
+        if (s2 < 3) ORB_STAMP(1 + 2 * s2)
+        // W(x^q) = sum_s X_s(sigma_s x^q); sigma_s x^q is the compose(q,s)-th image of the base element: cube srcq[s][q],
+        // local coordinates l[sig(q, sig(s, .))].  (`sym` is uniform over the workgroup: one branch around the twelve reads, not
+        // one per read -- a branch per read made every read wait for the one before.)
+#define ORB_READ(sg) stage[srcq[sg][q] * CUBE + cidx(l[sig(q, sig(sg, 0))], l[sig(q, sig(sg, 1))], l[sig(q, sig(sg, 2))])]
+        double xr[12];
+        if (FUSED && sym) {
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                const int q = r >> 1;
+                const int l[3] = {l0, l1, l2h[r & 1]};
+                xr[r] = ORB_READ(s) + ORB_READ(sT);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                const int q = r >> 1;
+                const int l[3] = {l0, l1, l2h[r & 1]};
+                xr[r] = ORB_READ(s);
+            }
+        }
+#undef ORB_READ
+#pragma unroll
+        for (int r = 0; r < 12; ++r) {
+            if (s2 < NT1) wreg[r] += xr[r];
+            else mreg[CR ? r : 0] += xr[r];
+        }
+        if (s2 < 3) ORB_STAMP(2 + 2 * s2)
+    }
     const double eo = in.e[m.i] + in.e[m.j] + in.e[m.k];
     constexpr int NQ = CR ? 6 : WANT_D ? 4 : 2;
     double acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-    // q stays a run-time (wave-uniform) loop counter here: fully unrolled, the scheduler hoists every LDS read of all
-    // twelve elements and spills; the permutation of cube q then only enters through scalar address arithmetic.
-#pragma unroll 1
-    for (int q = 0; q < 6; ++q) {
-        if (dup[q]) continue;
-        const int sa = sig(q, 0), sb = sig(q, 1), sc = sig(q, 2);   // tile slot of a, b, c in cube q
-        const int ta = sa == 0 ? tile[0] : sa == 1 ? tile[1] : tile[2];
-        const int tb = sb == 0 ? tile[0] : sb == 1 ? tile[1] : tile[2];
-        const int tc = sc == 0 ? tile[0] : sc == 1 ? tile[1] : tile[2];
-        const int slot[3] = {sa, sb, sc};
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int l[3] = {l0, l1, l2h[h]};
-            const int ga = ta * TT + l[0], gb = tb * TT + l[1], gc = tc * TT + l[2];
-            const bool live = ga < v && gb < v && gc < v;
-            const double D = eo - evl[sa * TT + l[0]] - evl[sb * TT + l[1]] - evl[sc * TT + l[2]];
-#define WAT(s) wl[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])]
-            const double w = wl[q * CUBE + cidx(l[0], l[1], l[2])];
-            const double wb = 4.0 * w + WAT(4) + WAT(5) - 2.0 * (WAT(3) + WAT(1) + WAT(2));   // 3 x the bar of ccsd.f90:2314-2318
-            const double r3D = rcp_nr(3.0 * D);
+    for (int h = 0; h < 2; ++h) {
+        // the second orbit's LDS addresses are made to "depend" on the first orbit's sums (an empty asm): its ~30 reads then stay
+        // behind the first orbit's arithmetic instead of being hoisted in front of it and spilled
+        int l2v = l2h[h];
+        if (h == 1) asm volatile("" : "+v"(l2v) : "v"(acc[0]), "v"(acc[NQ - 1]));
+        const int l[3] = {l0, l1, l2v};
+        const bool live = tile[0] * TT + l[0] < v && tile[1] * TT + l[1] < v && tile[2] * TT + l[2] < v;
+        const double D = eo - evl[l[0]] - evl[TT + l[1]] - evl[2 * TT + l[2]];   // the same for the six images
+        const double rD = rcp_nr(3.0 * D);       // (padding reads valid orbital energies: D is finite and non-zero there too)
+        const double r3D = live ? rD : 0.0;
+        double t1v[3][3], Z[6], Y[WANT_D ? 6 : 1];
+#pragma unroll
+        for (int oc = 0; oc < 3; ++oc)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t1v[oc][c] = t1r[oc * 24 + c * TT + l[c]];
+        {
+            double V[3][3][3];
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int cx = 0; cx < 3; ++cx)
+#pragma unroll
+                    for (int cy = 0; cy < 3; ++cy)
+                        if (cx != cy) V[pr][cx][cy] = vp[(pr * 9 + cx * 3 + cy) * PATCH + l[cx] + TT * l[cy]];
             // Z(x,y,z) = t1(i,x) V_jk(y,z) + t1(j,y) V_ik(x,z) + t1(k,z) V_ij(x,y)      ccsd.f90:2178-2179 (numerator)
-#define T1R(oc, d) t1r[(oc) * 24 + slot[d] * 8 + l[d]]
-#define VP(arr, pr, dx, dy) arr[((pr) * 9 + slot[dx] * 3 + slot[dy]) * PATCH + l[dx] + TT * l[dy]]
-#define ZAT(x, y, z) (T1R(0, x) * VP(vp, 0, y, z) + T1R(1, y) * VP(vp, 1, x, z) + T1R(2, z) * VP(vp, 2, x, y))
-            const double tbar = live ? wb * r3D : 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int s0 = sig(q, 0), s1 = sig(q, 1), s2 = sig(q, 2);
+                Z[q] = t1v[0][s0] * V[0][s1][s2] + t1v[1][s1] * V[1][s0][s2] + t1v[2][s2] * V[2][s0][s1];
+            }
+        }
+        if (WANT_D) {
+            // (the t2 patches are read once the V patches are dead: same device)
+            int lt[3] = {l[0], l[1], l[2]};
+            asm volatile("" : "+v"(lt[0]), "+v"(lt[1]), "+v"(lt[2]) : "v"(Z[0]), "v"(Z[1]), "v"(Z[2]), "v"(Z[3]), "v"(Z[4]), "v"(Z[5]));
+            double T2[3][3][3];
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                for (int cx = 0; cx < 3; ++cx)
+#pragma unroll
+                    for (int cy = 0; cy < 3; ++cy)
+                        if (cx != cy) T2[pr][cx][cy] = tp[(pr * 9 + cx * 3 + cy) * PATCH + lt[cx] + TT * lt[cy]];
+            // y (ccsd.f90:2183-2184)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int s0 = sig(q, 0), s1 = sig(q, 1), s2 = sig(q, 2);
+                Y[q] = t1v[0][s0] * t1v[1][s1] * t1v[2][s2] + t1v[0][s0] * T2[0][s1][s2] + t1v[1][s1] * T2[1][s0][s2] +
+                       t1v[2][s2] * T2[2][s0][s1];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const double w = wreg[2 * q + h];
+            // 3 x the bar of ccsd.f90:2314-2318 at the q-th image, over 3D
+#define BAR3(A) (4.0 * A(q) + A(compose(q, 4)) + A(compose(q, 5)) - 2.0 * (A(compose(q, 3)) + A(compose(q, 1)) + A(compose(q, 2))))
+#define W_AT(r) wreg[2 * (r) + h]
+#define Z_AT(r) Z[r]
+            const double tbar = BAR3(W_AT) * r3D;
             acc[0] += tbar * w;
             if (!WANT_D) {
-                acc[1] += tbar * ZAT(0, 1, 2);
+                acc[1] += tbar * Z[q];
                 continue;
             }
-            const double zb = 4.0 * ZAT(0, 1, 2) + ZAT(1, 2, 0) + ZAT(2, 0, 1) - 2.0 * (ZAT(0, 2, 1) + ZAT(1, 0, 2) + ZAT(2, 1, 0));
-            // y (ccsd.f90:2183-2184)
-            const double y = T1R(0, 0) * T1R(1, 1) * T1R(2, 2) + T1R(0, 0) * VP(tp, 0, 1, 2) + T1R(1, 1) * VP(tp, 1, 0, 2) +
-                             T1R(2, 2) * VP(tp, 2, 0, 1);
-            const double zbar = live ? zb * r3D : 0.0;
+            const double zbar = BAR3(Z_AT) * r3D;
+#undef BAR3
+#undef W_AT
+#undef Z_AT
+            const double y = Y[WANT_D ? q : 0];
             acc[1] += zbar * w;
-            acc[2] += tbar * y;
-            acc[3] += zbar * y;
+            acc[WANT_D ? 2 : 0] += tbar * y;
+            acc[WANT_D ? 3 : 0] += zbar * y;
             if (CR) {
-                // mreg is indexed by r = 2q + h: select with a short compare chain (q is a run-time loop counter)
-                double mm = 0.0;
-#pragma unroll
-                for (int r = 0; r < 12; ++r) mm = (r == 2 * q + h) ? mreg[CR ? r : 0] : mm;
+                const double mm = mreg[CR ? 2 * q + h : 0];
                 acc[NQ - 2] += tbar * mm;
                 acc[NQ - 1] += zbar * mm;
             }
-#undef WAT
-#undef T1R
-#undef VP
-#undef ZAT
         }
     }
+    ORB_STAMP(7)
+    // |H|: how many of the six permutations leave the tile triple where it is
+    const int nH = (tile[0] == tile[1] && tile[1] == tile[2]) ? 6 : (tile[0] == tile[1] || tile[1] == tile[2] || tile[0] == tile[2]) ? 2 : 1;
     const int lane = t & 63, wv = t >> 6;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -253,8 +345,12 @@ __global__ __launch_bounds__(256, WANT_D ? 3 : 4) void triples_orbit_kernel(doub
     __syncthreads();
     if (t < NQ) {
         const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-        partial[(int64_t)t * nblk_total + blk] = m.mult * (red[t * 4] + red[t * 4 + 1] + red[t * 4 + 2] + red[t * 4 + 3]);
+        partial[(int64_t)t * nblk_total + blk] = m.mult * (red[t * 4] + red[t * 4 + 1] + red[t * 4 + 2] + red[t * 4 + 3]) / (double)nH;
     }
+    ORB_STAMP(8)
+#ifdef AFESP_ORBIT_STAMPS
+    if (t == 0) g_orbit_stamp[((blockIdx.y * gridDim.x + blockIdx.x) % ORB_SLOTS) * 16 + 9] = 1ull;
+#endif
 }
 
 // Spin-orbital (T), ccsd.f90:1812-1922.  For i<j<k the three GEMM blocks Y^{i;jk}, Y^{j;ik}, Y^{k;ij} (triples.hip,

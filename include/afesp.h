@@ -178,7 +178,8 @@ int afesp_arena_stats(afesp_ctx* ctx, double out[4]);
 /* Test hook: what = 1 makes the next laned (small-system) amplitude update throw once, from a lane other than the main one
  * -- the failure mode of a capture that dies half-way (tests/test_gpu_cc.py). */
 int afesp_test_inject(afesp_ctx* ctx, int what);
-/* Diagnostic builds of the GEMM kernel only (tools/stamp_probe.py): per (workgroup, wave) cycle sums of the last launch. */
+/* Diagnostic builds only: n > 0: per (workgroup, wave) cycle sums of the GEMM kernel's last launch (tools/stamp_probe.py);
+ * n < 0: the first -n phase sums of the (T) orbit kernel since the last call (tools/orbit_stamps.py).  Zeros in a shipped build. */
 int afesp_debug_stamps(unsigned long long* out, int n);
 
 /* Operator layer (src/linalg.fpp), exported for parity tests against the oracle.

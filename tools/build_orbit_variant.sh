@@ -1,0 +1,13 @@
+#!/bin/bash
+# build_orbit_variant.sh TAG -- a build of libafesp_hip.so whose triples.hip is compiled with $EXTRA (e.g. -DAFESP_ORBIT_STAMPS)
+# for A/B runs in one GPU session (tools/t_time.py, tools/orbit_stamps.py).  Output: build/ab/libafesp_TAG.so
+set -e
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+CS="$HERE/a-fortran-electronic-structure-program_amd/csrc"
+OUT="$HERE/build/ab"
+mkdir -p "$OUT"
+make -C "$CS" -j8 > /dev/null
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result ${EXTRA:-} -c "$CS/triples.hip" -o "$OUT/triples_$1.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libafesp_$1.so" "$OUT/triples_$1.o" \
+    "$CS"/{gett,contract,kernels,ccsd,ccsd_so,comm,capi}.o -ldl -lpthread
+echo "built $OUT/libafesp_$1.so"
