@@ -368,7 +368,6 @@ __global__ __launch_bounds__(256, 3) void triples_so_orbit_kernel(double* __rest
     __shared__ double vp[27 * PATCH];                              // <pq||xy> patches for pairs (j,k), (i,k), (i,j)
     __shared__ double t1r[96];                                     // t1r[occ][slot][l] = t1(occ, tile[slot]*8 + l); then evl
     __shared__ int srcq[6][6];
-    __shared__ int dup[6];
     __shared__ double red[4];
     const TripleMeta m = meta[blockIdx.y];
     const int o = in.o, v = in.v, t = threadIdx.x;
@@ -382,7 +381,6 @@ __global__ __launch_bounds__(256, 3) void triples_so_orbit_kernel(double* __rest
         for (int r = 5; r >= 0; --r)
             if (tile[sig(r, 0)] == want[0] && tile[sig(r, 1)] == want[1] && tile[sig(r, 2)] == want[2]) found = r;
         srcq[s][q] = found;
-        if (s == 0) dup[q] = (found != q);
     }
     const int64_t vv = (int64_t)v * v;
     const int nt8 = (v + TT - 1) / TT;
@@ -425,39 +423,53 @@ __global__ __launch_bounds__(256, 3) void triples_so_orbit_kernel(double* __rest
     const int l0 = t & 7, l1 = (t >> 3) & 7, l2h[2] = {t >> 6, (t >> 6) + 4};
     const double eo = in.e[m.i] + in.e[m.j] + in.e[m.k];
     double acc = 0.0;
-#pragma unroll 1
-    for (int q = 0; q < 6; ++q) {
-        if (dup[q]) continue;
-        const int sa = sig(q, 0), sb = sig(q, 1), sc = sig(q, 2);
-        const int ta = sa == 0 ? tile[0] : sa == 1 ? tile[1] : tile[2];
-        const int tb = sb == 0 ? tile[0] : sb == 1 ? tile[1] : tile[2];
-        const int tc = sc == 0 ? tile[0] : sc == 1 ? tile[1] : tile[2];
-        const int slot[3] = {sa, sb, sc};
+    // a thread owns the orbit of two base elements (see triples_orbit_kernel): the q-th image lies in cube srcq[0][q] at the
+    // permuted local coordinates; D, the t1 rows and the V patches are read once per orbit
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int l[3] = {l0, l1, l2h[h]};
-            const int ga = ta * TT + l[0], gb = tb * TT + l[1], gc = tc * TT + l[2];
-            const bool live = ga < v && gb < v && gc < v;
-            const double D = eo - evl[sa * TT + l[0]] - evl[sb * TT + l[1]] - evl[sc * TT + l[2]];
-#define WAT(s) wl[srcq[s][q] * CUBE + cidx(l[sig(s, 0)], l[sig(s, 1)], l[sig(s, 2)])]
-#define T1R(oc, d) t1r[(oc) * 24 + slot[d] * 8 + l[d]]
-#define VP(pr, dx, dy) vp[((pr) * 9 + slot[dx] * 3 + slot[dy]) * PATCH + l[dx] + TT * l[dy]]
-#define RAW(x, y, z) (T1R(0, x) * VP(0, y, z) - T1R(1, x) * VP(1, y, z) + T1R(2, x) * VP(2, y, z))
-            const double t3c = wl[q * CUBE + cidx(l[0], l[1], l[2])] - WAT(1) - WAT(2);
-            const double t3d = RAW(0, 1, 2) - RAW(1, 0, 2) - RAW(2, 1, 0);
-            acc += live ? t3c * (t3c + t3d) * rcp_nr(D) : 0.0;
-#undef WAT
-#undef T1R
-#undef VP
-#undef RAW
+    for (int h = 0; h < 2; ++h) {
+        int l2v = l2h[h];
+        if (h == 1) asm volatile("" : "+v"(l2v) : "v"(acc));   // the second orbit's reads stay behind the first orbit's arithmetic
+        const int l[3] = {l0, l1, l2v};
+        const bool live = tile[0] * TT + l[0] < v && tile[1] * TT + l[1] < v && tile[2] * TT + l[2] < v;
+        const double D = eo - evl[l[0]] - evl[TT + l[1]] - evl[2 * TT + l[2]];
+        const double rD = rcp_nr(D);
+        double R[6], t1v[3][3], V[3][3][3], RAW[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) R[q] = wl[srcq[0][q] * CUBE + cidx(l[sig(q, 0)], l[sig(q, 1)], l[sig(q, 2)])];
+#pragma unroll
+        for (int oc = 0; oc < 3; ++oc)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t1v[oc][c] = t1r[oc * 24 + c * TT + l[c]];
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+            for (int cx = 0; cx < 3; ++cx)
+#pragma unroll
+                for (int cy = 0; cy < 3; ++cy)
+                    if (cx != cy) V[pr][cx][cy] = vp[(pr * 9 + cx * 3 + cy) * PATCH + l[cx] + TT * l[cy]];
+        // RAW(x,y,z) = t1(i,x)<jk||yz> - t1(j,x)<ik||yz> + t1(k,x)<ij||yz> at the q-th image          :1873-1874
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int s0 = sig(q, 0), s1 = sig(q, 1), s2 = sig(q, 2);
+            RAW[q] = t1v[0][s0] * V[0][s1][s2] - t1v[1][s0] * V[1][s1][s2] + t1v[2][s0] * V[2][s1][s2];
         }
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const double t3c = R[q] - R[compose(q, 1)] - R[compose(q, 2)];          // :1894-1896
+            const double t3d = RAW[q] - RAW[compose(q, 1)] - RAW[compose(q, 2)];    // :1890-1892
+            sum += t3c * (t3c + t3d);
+        }
+        acc += live ? sum * rD : 0.0;
     }
+    // |H|: how many of the six permutations leave the tile triple where it is (each element is visited |H| times)
+    const int nH = (tile[0] == tile[1] && tile[1] == tile[2]) ? 6 : (tile[0] == tile[1] || tile[1] == tile[2] || tile[0] == tile[2]) ? 2 : 1;
     const int lane = t & 63, wv = t >> 6;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if (lane == 0) red[wv] = acc;
     __syncthreads();
-    if (t == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) / 6.0;
+    if (t == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) / (6.0 * nH);
 }
 
 }  // namespace afesp
