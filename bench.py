@@ -80,7 +80,10 @@ def synthetic_host(o, v, scale, seed):
 
 
 def cpu_baseline(o, v, scale, seed, eng, budget_s=25.0):
-    """Time the CPU restatement (oracle/, kind "port") on a bounded sample of the same workload."""
+    """Time the CPU restatement (oracle/, kind "port") on a bounded sample of the same workload.  (T) and the pp-ladder run in
+    the reference's own shape -- one dgemm per permuted term with OpenMP over (i,j,k), a multi-threaded dgemm for the ladder
+    (oracle/afesp_oracle_blas.c on the OpenBLAS numpy bundles) -- so the baseline is BLAS-backed like the reference's CPU path
+    (src/ccsd.f90:2056-2066, :2091, :1669); the loop form of oracle/afesp_oracle.c is timed beside it on the small workload."""
     # A GPU box advertises many more hardware threads than the CPU share its job gets (16 per GPU on this pool); more
     # OpenMP threads than that only spin against each other.  AFESP_BENCH_THREADS overrides.
     cores = os.cpu_count() or 1
@@ -89,12 +92,32 @@ def cpu_baseline(o, v, scale, seed, eng, budget_s=25.0):
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import orc
     L = orc.lib()
+    LB = orc.blas_lib()
     try:
         omp = ctypes.CDLL("libgomp.so.1")
         omp.omp_set_num_threads(threads)
     except OSError:
         pass
     n = o + v
+    f = lambda a: np.ascontiguousarray(a.ravel(order="F"))
+    blas_note = ("(T): one dgemm per permuted term, OpenMP over (i,j,k) with serial BLAS inside, as src/ccsd.f90:2056-2066/:2091; "
+                 "OpenBLAS bundled with numpy") if LB is not None else "numpy's OpenBLAS not found: loop form only"
+
+    def time_triples(fn, args, per_hint=None):
+        """as many ordered triples as fit the budget (at least one per thread), extrapolated to the reference's o^3"""
+        out = np.zeros(4)
+        t0 = time.perf_counter()
+        fn(*args, 0, threads, out)
+        per = max(time.perf_counter() - t0, 1e-6)              # one round of `threads` triples
+        ns = int(min(o**3, max(threads, threads * int(budget_s * 0.4 / per))))
+        if ns > threads:
+            t0 = time.perf_counter()
+            fn(*args, 0, ns, out)
+            per, cnt = time.perf_counter() - t0, ns
+        else:
+            cnt = threads
+        return per * (o**3 / cnt), cnt
+
     if n <= 64:
         e, eri = synthetic_host(o, v, scale, seed)
         cc = orc.OracleCC(o, v, eri, e, 8)
@@ -105,44 +128,43 @@ def cpu_baseline(o, v, scale, seed, eng, budget_s=25.0):
         L.orc_cc_energy(cc.h, 1e-6, 1e-7)
         L.orc_cc_diis_update(cc.h)
         t_iter = time.perf_counter() - t0
-        # (T): as many ordered triples as fit the budget, extrapolated to the reference's o^3
-        t0 = time.perf_counter()
-        cc.triples(e, 0, 1)
-        per = max(time.perf_counter() - t0, 1e-6)
-        ns = int(max(threads, min(o**3, budget_s / per * threads * 0.5)))
-        ns = min(ns, o**3)
-        t0 = time.perf_counter()
-        cc.triples(e, 0, ns)
-        t_t = (time.perf_counter() - t0) * (o**3 / ns)
-        sample = f"1 full CCSD iteration + {ns}/{o**3} ordered (i,j,k) triples of (T), scaled to o^3"
-        return {"value": t_iter + t_t, "unit": "s/step", "ccsd_iter_s": t_iter, "t_s": t_t, "cores": threads,
-                "kind": "port", "sample": sample,
+        targs = (o, v, np.ascontiguousarray(e), f(cc.t1), f(cc.t2), f(cc.field("v_vvov")), f(cc.field("v_oovo")), f(cc.field("v_oovv")))
+        t_loops, ns = time_triples(L.orc_ccsd_t, targs)
+        t_t, nsb = time_triples(LB.orcb_ccsd_t, targs) if LB is not None else (t_loops, ns)
+        sample = f"1 full CCSD iteration (loop form) + {nsb}/{o**3} ordered (i,j,k) triples of (T), scaled to o^3"
+        return {"value": t_iter + t_t, "unit": "s/step", "ccsd_iter_s": t_iter, "t_s": t_t, "t_s_loop_form": t_loops, "cores": threads,
+                "kind": "port", "blas": blas_note, "sample": sample,
                 "gflops": (flops_iter(o, v) + flops_t_ref(o, v)) / (t_iter + t_t) / 1e9}
     # large system: the reference formulation cannot run here (n<=99); time slabs of the restatement
     t1, t2 = eng.amplitudes()
-    f = lambda a: np.ascontiguousarray(a.ravel(order="F"))
     e = np.concatenate([-2.0 + np.arange(o) / max(o - 1, 1), 1.0 + 2.0 * np.arange(v) / max(v - 1, 1)])
-    vvov, oovo, oovv = f(eng.tensor("v_vvov")), f(eng.tensor("v_oovo")), f(eng.tensor("v_oovv"))
-    out = np.zeros(4)
-    ns = threads
-    t0 = time.perf_counter()
-    L.orc_ccsd_t(o, v, e, f(t1), f(t2), vvov, oovo, oovv, 0, ns, out)
-    t_t = (time.perf_counter() - t0) * (o**3 / ns)
+    targs = (o, v, e, f(t1), f(t2), f(eng.tensor("v_vvov")), f(eng.tensor("v_oovo")), f(eng.tensor("v_oovv")))
+    if LB is not None:
+        t_t, ns = time_triples(LB.orcb_ccsd_t, targs)
+    else:
+        out = np.zeros(4)
+        ns = threads
+        t0 = time.perf_counter()
+        L.orc_ccsd_t(*targs, 0, ns, out)
+        t_t = (time.perf_counter() - t0) * (o**3 / ns)
     # pp-ladder slab: ncol columns (a,b) of the o^2 x v^2 x v^2 product (ccsd.f90:1669)
-    c = f(eng.tensor("c_oovv")).reshape(o * o, v * v, order="F")
-    ncol = 64
-    vv = np.zeros((v * v, ncol))
-    vv[:] = 0.01
-    t0 = time.perf_counter()
+    c = f(eng.tensor("c_oovv"))
+    ncol = 1024 if LB is not None else 64
+    vv = np.full(v * v * ncol, 0.01)
     res = np.zeros(o * o * ncol)
-    L.orc_gemm(0, 0, o * o, ncol, v * v, 0.5, np.ascontiguousarray(c.ravel(order="F")), np.ascontiguousarray(vv.ravel(order="F")),
-               0.0, res)
+    if LB is not None:
+        LB.orcb_gemm(o * o, ncol, v * v, 0.5, c, vv, 0.0, res, threads)      # warm-up (thread pool, pages)
+        t0 = time.perf_counter()
+        LB.orcb_gemm(o * o, ncol, v * v, 0.5, c, vv, 0.0, res, threads)
+    else:
+        t0 = time.perf_counter()
+        L.orc_gemm(0, 0, o * o, ncol, v * v, 0.5, c, vv, 0.0, res)
     t_lad = (time.perf_counter() - t0) * (v * v / ncol)
     t_iter = t_lad * flops_iter(o, v, 2 * o**2 * v**4) / (2 * o**2 * v**4)   # the reference's formulation: full dgemm
-    sample = (f"(T): {ns}/{o**3} ordered triples scaled to o^3; CCSD iteration: {ncol}/{v*v} columns of the pp-ladder scaled "
+    sample = (f"(T): {ns}/{o**3} ordered triples scaled to o^3; CCSD iteration: {ncol}/{v*v} columns of the pp-ladder dgemm scaled "
               "to v^2 and to the iteration's full flop count (extrapolated)")
     return {"value": t_iter + t_t, "unit": "s/step", "ccsd_iter_s": t_iter, "t_s": t_t, "cores": threads, "kind": "port",
-            "sample": sample, "gflops": (flops_iter(o, v) + flops_t_ref(o, v)) / (t_iter + t_t) / 1e9}
+            "blas": blas_note, "sample": sample, "gflops": (flops_iter(o, v) + flops_t_ref(o, v)) / (t_iter + t_t) / 1e9}
 
 
 def time_ao2mo(eng, o, v, reps):

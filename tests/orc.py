@@ -20,7 +20,7 @@ def lib():
     if _LIB is not None:
         return _LIB
     so = os.path.join(ROOT, "oracle", "liborc.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("afesp_oracle.c", "afesp_oracle_so.c")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("afesp_oracle.c", "afesp_oracle_so.c", "afesp_oracle_blas.c")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liborc.so"])
     L = C.CDLL(so)
@@ -94,8 +94,23 @@ def lib():
     L.orc_so_set_foo_as_published.restype = None
     L.orc_so_field.argtypes = [C.c_void_p, C.c_int]
     L.orc_so_field.restype = C.POINTER(dbl)
+    L.orcb_load.argtypes = [C.c_char_p]
+    L.orcb_ccsd_t.argtypes = [i64, i64, dp, dp, dp, dp, dp, dp, i64, i64, dp]
+    L.orcb_gemm.argtypes = [i64, i64, i64, dbl, dp, dp, dbl, dp, C.c_int]
     _LIB = L
     return L
+
+
+def blas_lib():
+    """liborc.so with the dgemm of the OpenBLAS that numpy bundles loaded into it (oracle/afesp_oracle_blas.c), or None if that
+    library cannot be found -- the BLAS-backed CPU baseline of bench.py is then skipped, never replaced by something else."""
+    import glob
+    L = lib()
+    cands = sorted(glob.glob(os.path.join(os.path.dirname(np.__file__), "..", "numpy.libs", "libscipy_openblas64_*.so")))
+    for path in cands:
+        if L.orcb_load(os.path.abspath(path).encode()) == 0:
+            return L
+    return None
 
 
 FIELDS = {"v_oovv": 0, "v_ovov": 1, "v_vvov": 2, "v_oovo": 3, "v_oooo": 4, "v_vvvv": 5, "I_vo": 6, "I_vv": 7,
@@ -161,6 +176,27 @@ class OracleCC:
         self.L.orc_ccsd_t(o, v, np.ascontiguousarray(e), f(self.t1), f(self.t2), f(self.field("v_vvov")),
                           f(self.field("v_oovo")), f(self.field("v_oovv")), t_begin, t_end, out)
         return out
+
+
+def _blas_methods():
+    def triples_blas(self, e, t_begin=0, t_end=None):
+        """The same four sums from the dgemm-per-term form (oracle/afesp_oracle_blas.c); None without numpy's OpenBLAS."""
+        L = blas_lib()
+        if L is None:
+            return None
+        o, v = self.o, self.v
+        out = np.zeros(4)
+        if t_end is None:
+            t_end = o ** 3
+        f = lambda a: np.ascontiguousarray(a.ravel(order="F"))
+        rc = L.orcb_ccsd_t(o, v, np.ascontiguousarray(e), f(self.t1), f(self.t2), f(self.field("v_vvov")),
+                           f(self.field("v_oovo")), f(self.field("v_oovv")), t_begin, t_end, out)
+        assert rc == 0, rc
+        return out
+    OracleCC.triples_blas = triples_blas
+
+
+_blas_methods()
 
 
 def _cr_methods():

@@ -73,6 +73,27 @@ def test_triples_range_is_additive():
     assert np.allclose(full, parts, atol=1e-12)
 
 
+def test_blas_backed_triples_equal_the_pinned_loops():
+    """oracle/afesp_oracle_blas.c (one dgemm per permuted term, the reference's shape; bench.py's CPU baseline) against the loop
+    form that the bundled outputs pin, on H2O and on a shard of the list."""
+    si, ints, res, _ = molecules.load("h2o-cc-pvdz")
+    n, o = ints.nbasis, ints.nel // 2
+    mo = orc.ao2mo(n, res.canon_coeff, ints.eri)
+    cc = orc.OracleCC(o, n - o, mo, res.canon_levels, 8)
+    cc.solve(50, 1e-6, 1e-7)
+    full = cc.triples_blas(res.canon_levels)
+    if full is None:
+        pytest.skip("numpy's bundled OpenBLAS not found")
+    assert np.allclose(full, cc.triples(res.canon_levels), atol=1e-12, rtol=0)
+    assert np.allclose(cc.triples_blas(res.canon_levels, 17, 61), cc.triples(res.canon_levels, 17, 61), atol=1e-12, rtol=0)
+    # the ladder-shaped product
+    rng = np.random.default_rng(5)
+    a, b = rng.standard_normal((12, 30)), rng.standard_normal((30, 9))
+    c = np.zeros(12 * 9)
+    assert orc.blas_lib().orcb_gemm(12, 9, 30, 0.5, np.ascontiguousarray(a.ravel(order="F")), np.ascontiguousarray(b.ravel(order="F")), 0.0, c, 2) == 0
+    assert np.allclose(c.reshape((12, 9), order="F"), 0.5 * a @ b, atol=1e-13)
+
+
 def test_pack_unpack_roundtrip_and_canonical_order():
     L = orc.lib()
     n = 7
