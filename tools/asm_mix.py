@@ -1,7 +1,8 @@
 """Instruction mix per basic block of one gett_kernel instantiation (device asm from hipcc -S)."""
 import re, subprocess, sys
 from collections import Counter
-src = "/root/repo/a-fortran-electronic-structure-program_amd/csrc/gett.hip"
+import os
+src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "a-fortran-electronic-structure-program_amd", "csrc", "gett.hip")
 subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-S", "--cuda-device-only", src, "-o", "/tmp/gett.s"],
                stderr=subprocess.DEVNULL, check=True)
 s = open('/tmp/gett.s').read()
