@@ -344,6 +344,54 @@ std::vector<int64_t> table(const std::vector<Lab>& g, int which)
     return t;
 }
 
+// The same table written by the device: for the big enumerations (the AO->MO transforms walk 220 x 24310 = 5.3 M columns: six
+// host loops and 170 MB of uploads made the first transform of a process 309 ms against 54 ms for the next one).
+struct TabArgs {
+    int nd;
+    int64_t dim[8], stride[8];
+    int64_t n;
+};
+
+__global__ __launch_bounds__(256) void plan_table_kernel(int64_t* __restrict__ out, TabArgs a)
+{
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < a.n; x += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = x, off = 0;
+        for (int q = 0; q < a.nd; ++q) {
+            off += (r % a.dim[q]) * a.stride[q];
+            r /= a.dim[q];
+        }
+        out[x] = off;
+    }
+}
+
+int64_t stride_in(const Lab& l, int which) { return which == 0 ? l.sa : which == 1 ? l.sb : l.sc; }
+
+int64_t table_size(const std::vector<Lab>& g)
+{
+    int64_t n = 1;
+    for (auto& l : g) n *= l.dim;
+    return n;
+}
+
+// What pairs() / evens() below find by scanning a table, from the strides alone.  Labels of extent 1 contribute nothing; labels
+// that continue each other (stride of the next = extent x stride of this one) enumerate like one label.
+void table_flags(const std::vector<Lab>& g, int which, bool* pairs, bool* evens)
+{
+    std::vector<std::pair<int64_t, int64_t>> ds;   // (extent, stride), fastest first, merged
+    for (auto& l : g) {
+        if (l.dim == 1) continue;
+        const int64_t st = stride_in(l, which);
+        if (!ds.empty() && st == ds.back().first * ds.back().second) ds.back().first *= l.dim;
+        else ds.push_back({l.dim, st});
+    }
+    *evens = true;
+    for (auto& d : ds)
+        if (d.second & 1) *evens = false;
+    *pairs = !ds.empty() && ds[0].first % 2 == 0 && ds[0].second == 1;
+    for (size_t q = 1; q < ds.size(); ++q)
+        if (ds[q].second & 1) *pairs = false;
+}
+
 int64_t* upload(Context& cx, const std::vector<int64_t>& h)
 {
     int64_t* d = cx.plan_alloc(h.size());
@@ -465,38 +513,79 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
         if (it == cx.plans.end()) {
         p.a_kc = !K.empty() && K[0].c == afast && K[0].sa == 1;
         p.b_kc = !K.empty() && K[0].c == bfast && K[0].sb == 1;
-        auto tAm = table(M, 0), tAk = table(K, 0), tBk = table(K, 1), tBn = table(N, 1), tCm = table(M, 2), tCn = table(N, 2);
-        if (tAm.size() > INT32_MAX || tBn.size() > INT32_MAX || tAk.size() > INT32_MAX) throw Error(3, "contract: extent too large");
-        p.M = (int)tAm.size(); p.N = (int)tBn.size(); p.K = (int)tAk.size();
+        const std::vector<Lab>* grp[6] = {&M, &K, &K, &N, &M, &N};
+        const int whichs[6] = {0, 0, 1, 1, 2, 2};   // offAm, offAk, offBk, offBn, offCm, offCn
+        int64_t nn[6];
+        for (int q = 0; q < 6; ++q) nn[q] = table_size(*grp[q]);
+        if (nn[0] > INT32_MAX || nn[3] > INT32_MAX || nn[1] > INT32_MAX) throw Error(3, "contract: extent too large");
+        p.M = (int)nn[0]; p.N = (int)nn[3]; p.K = (int)nn[1];
         // 16-byte staging is legal when every offset is even and the contiguous direction advances in unit-stride pairs
-        auto pairs = [](const std::vector<int64_t>& t) {
-            if (t.size() % 2) return false;
-            for (size_t x = 0; x + 1 < t.size(); x += 2)
-                if ((t[x] & 1) || t[x + 1] != t[x] + 1) return false;
-            return true;
-        };
-        auto evens = [](const std::vector<int64_t>& t) {
-            for (int64_t x : t)
-                if (x & 1) return false;
-            return true;
-        };
-        p.wide = (p.a_kc ? (pairs(tAk) && evens(tAm)) : (pairs(tAm) && evens(tAk))) &&
-                 (p.b_kc ? (pairs(tBk) && evens(tBn)) : (pairs(tBn) && evens(tBk)));
-        // the six tables in one allocation and one copy (a plan per contraction site: ~45 of them in a CCSD iteration),
-        // each starting on a 16-byte boundary
+        bool pr[6], ev[6];
+        for (int q = 0; q < 6; ++q) table_flags(*grp[q], whichs[q], &pr[q], &ev[q]);
+        p.wide = (p.a_kc ? (pr[1] && ev[0]) : (pr[0] && ev[1])) && (p.b_kc ? (pr[2] && ev[3]) : (pr[3] && ev[2]));
+        // the six tables in one allocation (a plan per contraction site: ~45 of them in a CCSD iteration), each starting on a
+        // 16-byte boundary; small ones are enumerated here and copied, big ones are written by the device
         {
-            const std::vector<int64_t>* tabs[6] = {&tAm, &tAk, &tBk, &tBn, &tCm, &tCn};
+            const bool verify = getenv("AFESP_PLAN_VERIFY") != nullptr;   // tests: both builders, and the flags, must agree
+            const int64_t device_from = getenv("AFESP_PLAN_DEVICE_FROM") ? atoll(getenv("AFESP_PLAN_DEVICE_FROM")) : 32768;
             int64_t** dst[6] = {&p.offAm, &p.offAk, &p.offBk, &p.offBn, &p.offCm, &p.offCn};
-            std::vector<int64_t> all;
-            size_t start[6];
+            size_t start[6], total = 0;
             for (int q = 0; q < 6; ++q) {
-                start[q] = all.size();
-                all.insert(all.end(), tabs[q]->begin(), tabs[q]->end());
-                if (all.size() % 2) all.push_back(0);
+                start[q] = total;
+                total += (size_t)nn[q] + ((size_t)nn[q] & 1);
             }
-            int64_t* base = upload(cx, all);
-            cx.plan_bytes += all.size() * sizeof(int64_t);
-            for (int q = 0; q < 6; ++q) *dst[q] = base + start[q];
+            int64_t* base = cx.plan_alloc(total);
+            cx.plan_bytes += total * sizeof(int64_t);
+            std::vector<int64_t> small;   // the host-built tables, one copy
+            std::vector<std::pair<size_t, size_t>> runs;   // (start in `small`, start in the allocation) of each
+            for (int q = 0; q < 6; ++q) {
+                *dst[q] = base + start[q];
+                if (nn[q] >= device_from) {
+                    TabArgs ta;
+                    ta.nd = 0;
+                    for (auto& l : *grp[q]) {
+                        if (ta.nd == 8) throw Error(3, "contract: too many labels in one group: " + key);
+                        ta.dim[ta.nd] = l.dim;
+                        ta.stride[ta.nd++] = stride_in(l, whichs[q]);
+                    }
+                    ta.n = nn[q];
+                    const unsigned blocks = (unsigned)std::min<int64_t>((nn[q] + 255) / 256, 8192);
+                    hipLaunchKernelGGL(plan_table_kernel, dim3(blocks), dim3(256), 0, cx.stream, base + start[q], ta);
+                    AFESP_HIP(hipGetLastError());
+                } else {
+                    const std::vector<int64_t> t = table(*grp[q], whichs[q]);
+                    runs.push_back({small.size(), start[q]});
+                    small.insert(small.end(), t.begin(), t.end());
+                }
+            }
+            for (size_t r = 0; r < runs.size(); ++r) {
+                const size_t len = (r + 1 < runs.size() ? runs[r + 1].first : small.size()) - runs[r].first;
+                if (len)
+                    AFESP_HIP(hipMemcpyAsync(base + runs[r].second, small.data() + runs[r].first, len * sizeof(int64_t), hipMemcpyHostToDevice,
+                                             cx.stream));
+            }
+            AFESP_HIP(hipStreamSynchronize(cx.stream));   // `small` is a temporary
+            if (verify) {
+                auto pairs = [](const std::vector<int64_t>& t) {
+                    if (t.size() % 2) return false;
+                    for (size_t x = 0; x + 1 < t.size(); x += 2)
+                        if ((t[x] & 1) || t[x + 1] != t[x] + 1) return false;
+                    return true;
+                };
+                auto evens = [](const std::vector<int64_t>& t) {
+                    for (int64_t x : t)
+                        if (x & 1) return false;
+                    return true;
+                };
+                for (int q = 0; q < 6; ++q) {
+                    const std::vector<int64_t> ref = table(*grp[q], whichs[q]);
+                    std::vector<int64_t> got(ref.size());
+                    AFESP_HIP(hipMemcpy(got.data(), base + start[q], ref.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+                    if (got != ref) throw Error(2, "contract: device-built offset table differs from the host enumeration: " + key);
+                    if (pairs(ref) != pr[q] || evens(ref) != ev[q])
+                        throw Error(2, "contract: analytic alignment flags differ from the scanned table: " + key);
+                }
+            }
         }
         it = cx.plans.emplace(key, p).first;
         }
@@ -608,6 +697,7 @@ void preload_contract()
 {
     hipFuncAttributes at;
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(permute_add_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(plan_table_kernel));
     (void)hipGetLastError();
 }
 

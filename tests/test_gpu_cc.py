@@ -170,6 +170,35 @@ def test_ao2mo_pair_symmetric_transform(eng, n, o):
     assert np.array_equal(again, eri_mo) and e2 == e_mp2
 
 
+@pytest.mark.parametrize("device_from", ["1", "1000000000"])
+def test_offset_tables_built_on_the_device_equal_the_host_enumeration(device_from, monkeypatch):
+    """The planner writes the big offset tables of a contraction with a kernel and derives the 16-byte-staging flags from the
+    strides; AFESP_PLAN_VERIFY makes every new plan compare both with the host enumeration and the scanned table (an error
+    status if they differ).  A fresh context (no cached plans), odd and even extents, AO->MO and a whole iteration + (T)."""
+    from afesp_amd import inputs
+    from afesp_amd.capi import Engine
+    monkeypatch.setenv("AFESP_PLAN_VERIFY", "1")
+    monkeypatch.setenv("AFESP_PLAN_DEVICE_FROM", device_from)
+    for n, o in ((13, 4), (24, 5)):
+        rng = np.random.default_rng(7 * n + o)
+        eri = rng.standard_normal(inputs.neri(n)) * 0.05
+        c = rng.standard_normal((n, n))
+        e = np.concatenate([-2.0 - rng.random(o), 1.0 + rng.random(n - o)])
+        with Engine(0) as fresh:
+            e_mp2, eri_mo = fresh.do_mp2_spatial(n, o, c, e, eri)
+            ref = orc.ao2mo(n, c, eri)
+            assert np.max(np.abs(eri_mo - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref)))
+            fresh.ccsd_init(o, n - o, e, eri_mo, 4)
+            cc = orc.OracleCC(o, n - o, eri_mo, e, 4)
+            for _ in range(2):
+                fresh.update_intermediates(); fresh.update_amplitudes()
+                cc.L.orc_cc_intermediates(cc.h); cc.L.orc_cc_amplitudes(cc.h)
+            t1, t2 = fresh.amplitudes()
+            assert np.max(np.abs(t2 - cc.t2)) < 1e-9 * max(1.0, np.max(np.abs(cc.t2)))
+            ref_t = cc.triples(e)
+            assert np.allclose(fresh.do_ccsd_t_spatial(), ref_t, atol=1e-9 * max(1.0, np.max(np.abs(ref_t))), rtol=0)
+
+
 def test_failed_graph_capture_leaves_a_working_context():
     """The iteration of a small system is captured into a hipGraph on its second call.  A failure in the middle of the captured
     body -- thrown while a lane other than the main one is selected (afesp_test_inject) -- must end the capture on the origin
