@@ -339,7 +339,7 @@ static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_b
 static int fused_block_size(int o, int v, bool cr, int64_t budget_bytes)
 {
     const int64_t nt8 = (v + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;
-    const int64_t per_block = (cr ? 2 : 1) * vp3 * (int64_t)sizeof(double);
+    const int64_t per_block = vp3 * (int64_t)sizeof(double);   // the budget is per pool (the completely renormalised variant has two)
     int smax = 1;
     while (smax < o && (int64_t)3 * (smax + 1) * (smax + 1) * (smax + 1) * per_block <= budget_bytes) ++smax;
     // among the three largest sizes that fit, the one whose GEMMs (M = v^2 rows in 256-row tiles, N = v*s columns in
@@ -360,7 +360,11 @@ static int64_t device_pool_budget()
     AFESP_HIP(hipMemGetInfo(&mem_free, &mem_total));
     const char* e = getenv("AFESP_T_POOL_GIB");   // tuning knob
     if (e) return (int64_t)atoll(e) << 30;
-    return std::min<int64_t>((int64_t)64 << 30, (int64_t)(mem_total / 4));
+    // An eighth of the device, 32 GiB at most: five occupied indices per block at config 5 (a 24 GB pool), where the GEMM groups
+    // fill their column tiles as well as with seven (97.7 %) and (T) takes 506.8 ms instead of 506.0 -- but 32 GB less are
+    // allocated on first use, and on this runtime a large allocation out of recycled device memory costs ~60 ms per GB
+    // (DESIGN.md 4.4).  Below that the launches get short: 16 GiB -> 549 ms.
+    return std::min<int64_t>((int64_t)32 << 30, (int64_t)(mem_total / 8));
 }
 
 static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end, bool cr)
