@@ -157,7 +157,7 @@ void k_t2_update(Context& cx, double* t2, const double* r2, const double* v_oovv
 void k_r2_full(Context& cx, double* out, const double* r2, const double* pp, int o, int v);
 void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v);
 // symmetric / antisymmetric operands of the pp-ladder (pairs x <= y indexed y(y+1)/2 + x, pairs x < y indexed y(y-1)/2 + x)
-void k_vvvv_sympack(Context& cx, double* vs, double* va, const double* vvvv, int v, int64_t ks, int64_t ka);
+void k_vvvv_sympack_packed(Context& cx, double* vs, double* va, const double* packed, int o, int v, int64_t ks, int64_t ka);
 void k_c_sympack(Context& cx, double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na);
 void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na,
                  int64_t p0 = 0, int64_t p1 = -1);   // rows [p0, p1) of PP only (a rank's share); default: all

@@ -238,6 +238,7 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
             throw Error(1, "afesp_ao2mo_mp2: eri_packed is NULL and no AO integrals were read onto the device for this basis size");
         // upload buffer, then the packed MO integrals; a transform of the same basis size overwrites the previous result
         double* packed = ctx->eri_mo_dev;
+        if (ctx->cc.eri_src == packed) ctx->cc.eri_src = nullptr;   // a solver state initialised from them can no longer form <ef|ab>
         if (!packed || ctx->eri_mo_n != n) {
             if (packed) cx.release(packed);
             ctx->eri_mo_dev = nullptr;
@@ -304,7 +305,11 @@ int afesp_ccsd_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, const double* e
         ctx->graph_cc.reset();
         cx.drop_scratch("ao2mo_");   // the AO->MO temporaries
         ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, src, canon_levels, diis_n_errmat);
-        if (tmp) cx.release(tmp);
+        if (tmp) {
+            // a large system forms <ef|ab> on request only (ccsd_need_vvvv): its state keeps the device copy of the integrals
+            if (ctx->cc.v_vvvv.d) { cx.release(tmp); ctx->cc.eri_src = nullptr; }
+            else ctx->cc.eri_own = tmp;
+        }
     });
 }
 
@@ -448,6 +453,10 @@ int afesp_ccsd_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t
             AFESP_HIP(hipMemcpyAsync(out, t.d, sizeof(double) * t.size(), hipMemcpyDeviceToHost, cx.stream));
             cx.sync();
             return;
+        }
+        if (!strcmp(name, "v_vvvv")) {
+            AFESP_HIP(hipSetDevice(ctx->cx.device));
+            ccsd_need_vvvv(ctx->cx, s);
         }
         for (auto& e : tab)
             if (!strcmp(e.n, name)) {
@@ -887,7 +896,8 @@ int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double sca
         AFESP_HIP(hipGetLastError());
         ctx->graph_cc.reset();
         ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, packed, e.data(), diis_n_errmat);
-        cx.release(packed);
+        if (ctx->cc.v_vvvv.d) { cx.release(packed); ctx->cc.eri_src = nullptr; }
+        else ctx->cc.eri_own = packed;   // kept for ccsd_need_vvvv
     });
 }
 

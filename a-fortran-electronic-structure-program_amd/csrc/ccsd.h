@@ -44,12 +44,18 @@ struct CCState : DiisRing {
     double energy = 0.0, energy_old = 0.0, rms = 0.0;
     void* tplan = nullptr;      // cached (T) launch plan (triples.hip)
     Tensor I_vovv_pp, I_ooov_pp;   // completely renormalised moments (ccsd.f90:2338-2551), built on request
+    // v_vvvv is only formed at init when the plain ladder reads it (small systems); otherwise on request (ccsd_need_vvvv) from
+    // the packed MO integrals: eri_src points at them (the context's resident array, or eri_own when the host handed them in and
+    // the state keeps its device copy); NULL once they have been replaced
+    const double* eri_src = nullptr;
+    double* eri_own = nullptr;
     bool have_cr = false;
 };
 void triples_plan_free(CCState& s);
 
 // eri_mo_dev: packed chemist MO integrals ON DEVICE (length neri(o+v)); e_host: orbital energies (host)
 void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, const double* e_host, int diis_nerr);
+void ccsd_need_vvvv(Context& cx, CCState& s);          // forms <ef|ab> (v^4) if the state does not hold it yet
 void ccsd_refresh_sharding(Context& cx, CCState& s);   // call before an iteration: picks up the context's communicator
 bool ccsd_uses_lanes(const CCState& s);   // small systems: the iteration's chains run on parallel lanes (ccsd.hip)
 void ccsd_diis_save(Context& cx, CCState& s);

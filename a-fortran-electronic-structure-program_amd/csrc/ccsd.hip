@@ -28,7 +28,10 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     AFESP_HIP(hipMemcpyAsync(s.e, e_host, sizeof(double) * n, hipMemcpyHostToDevice, cx.stream));
     cx.sync();
     s.v_oovv = cx.tensor({O, O, V, V}); s.v_ovov = cx.tensor({O, V, O, V}); s.v_vvov = cx.tensor({V, V, O, V});
-    s.v_oovo = cx.tensor({O, O, V, O}); s.v_oooo = cx.tensor({O, O, O, O}); s.v_vvvv = cx.tensor({V, V, V, V});
+    s.v_oovo = cx.tensor({O, O, V, O}); s.v_oooo = cx.tensor({O, O, O, O});
+    s.pp_sym = pp_sym_pays(O, V);
+    s.eri_src = eri_mo_dev;
+    if (!s.pp_sym) s.v_vvvv = cx.tensor({V, V, V, V});   // the plain ladder reads <ef|ab>; the pair form is built from the packed array
     s.w_oovv = cx.tensor({O, O, V, V}); s.w_vvov = cx.tensor({V, V, O, V}); s.w_oovo = cx.tensor({O, O, V, O});
     // ccsd.f90:496-512: <pq|rs> = (pr|qs), virtual offsets removed
     k_slice_phys(cx, s.v_oovv.d, eri_mo_dev, o, o, v, v, 0, 0, o, o);
@@ -36,7 +39,7 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     k_slice_phys(cx, s.v_vvov.d, eri_mo_dev, v, v, o, v, o, o, 0, o);
     k_slice_phys(cx, s.v_oovo.d, eri_mo_dev, o, o, v, o, 0, 0, o, 0);
     k_slice_phys(cx, s.v_oooo.d, eri_mo_dev, o, o, o, o, 0, 0, 0, 0);
-    k_slice_phys(cx, s.v_vvvv.d, eri_mo_dev, v, v, v, v, o, o, o, o);
+    if (!s.pp_sym) k_slice_phys(cx, s.v_vvvv.d, eri_mo_dev, v, v, v, v, o, o, o, o);
     k_antisym_pair(cx, s.w_oovv.d, s.v_oovv.d, O, O, V, V, 1);   // 2<ij|ab> - <ij|ba>   (ccsd.f90:1089)
     k_antisym_pair(cx, s.w_vvov.d, s.v_vvov.d, V, V, O, V, 0);   // 2<ab|ic> - <ba|ic>   (ccsd.f90:1101)
     k_antisym_pair(cx, s.w_oovo.d, s.v_oovo.d, O, O, V, O, 0);   // 2<ij|ak> - <ji|ak>   (ccsd.f90:1121)
@@ -57,7 +60,6 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
         const int64_t np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
         s.pp = cx.alloc(N2 * np + O * O * V * V);
         s.r2_sh = s.pp + N2 * np;
-        s.pp_sym = pp_sym_pays(O, V);
         std::vector<int64_t> tab;
         if (!s.pp_sym) {
             // rows p of <ef|ab> viewed as [ef x ab], all (i,j) columns
@@ -83,7 +85,7 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
                 s.pp_va = cx.alloc(ka * npa); s.pp_ca = cx.alloc(na * ka); s.pp_pa = cx.alloc(na * nm);
                 s.ov_wa = cx.alloc(ka * O * V);
             }
-            k_vvvv_sympack(cx, s.pp_vs, s.pp_va, s.v_vvvv.d, v, ks, ka);
+            k_vvvv_sympack_packed(cx, s.pp_vs, s.pp_va, eri_mo_dev, o, v, ks, ka);
             k_vvx_sympack(cx, s.ov_ws, s.ov_wa, s.v_vvov.d, v, O * V, ks, ka);
             // [ x (k or n) | ks*m | ka*m | ns*k | na*k | ns*m | na*m ]: entries beyond the antisymmetric extents unused
             s.pp_kn = std::max(ks, ns);
@@ -108,9 +110,21 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     cx.sync();
 }
 
+void ccsd_need_vvvv(Context& cx, CCState& s)
+{
+    if (s.v_vvvv.d) return;
+    if (!s.eri_src)
+        throw Error(1, "the <ef|ab> slice is formed on request from the packed MO integrals, and those have been replaced since "
+                       "afesp_ccsd_init: initialise the solver again");
+    const int64_t V = s.v;
+    s.v_vvvv = cx.tensor({V, V, V, V});
+    k_slice_phys(cx, s.v_vvvv.d, s.eri_src, s.v, s.v, s.v, s.v, s.o, s.o, s.o, s.o);
+}
+
 void ccsd_free(Context& cx, CCState& s)
 {
     if (!s.o) return;
+    if (s.eri_own) cx.release(s.eri_own);
     double* bufs[] = {s.e, s.v_oovv.d, s.v_ovov.d, s.v_vvov.d, s.v_oovo.d, s.v_oooo.d, s.v_vvvv.d, s.w_oovv.d, s.w_vvov.d,
                       s.w_oovo.d, s.D1.d, s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.I_vo.d, s.I_vv.d, s.I_oo_p.d, s.I_oo.d, s.c.d,
                       s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_ooov_p.d, s.y_ooov.d, s.y_oovo.d, s.amp_s, s.hist_t,
@@ -515,6 +529,7 @@ void ccsd_cr_intermediates(Context& cx, CCState& s)
     C(1.0, s.t1, "ke", s.v_oovv, "ijea", 1.0, xovoo, "kaij");
     // I_vovv_pp(c,i,a,b)  (:2513-2520)
     permute_add(cx, 1.0, s.v_vvov, "baic", 0.0, s.I_vovv_pp, "ciab");
+    ccsd_need_vvvv(cx, s);
     C(1.0, s.v_vvvv, "ecba", s.t1, "ie", 1.0, s.I_vovv_pp, "ciab");
     C(-1.0, xovov_p, "icma", s.t1, "mb", 1.0, s.I_vovv_pp, "ciab");
     C(-1.0, s.t1, "ma", xvoov_p, "cimb", 1.0, s.I_vovv_pp, "ciab");

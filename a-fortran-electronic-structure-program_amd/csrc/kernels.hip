@@ -338,7 +338,9 @@ void k_r2_full(Context& cx, double* out, const double* r2, const double* pp, int
 // ---- symmetric / antisymmetric form of the particle-particle ladder (ccsd.hip, ccsd_pp_ladder)
 // Vs(ef,ab) = 1/2 (<ef|ab> + <fe|ab>) (x 1/2 on e == f) over e <= f, a <= b;  Va(ef,ab) = 1/2 (<ef|ab> - <fe|ab>) over
 // e < f, a < b.  Columns (a,b) have leading dimensions ks / ka; built once per calculation.
-__global__ void vvvv_sympack_kernel(double* vs, double* va, const double* vvvv, int v, int64_t ks, int64_t ka)
+// Read straight from the packed chemist MO integrals, <ef|ab> = (ea|fb) (ccsd.f90:496-512): a large system never forms the v^4
+// slice <ef|ab> itself (12.8 GB and a 13 ms gather at v = 200; ccsd_need_vvvv builds it on request).
+__global__ void vvvv_sympack_packed_kernel(double* vs, double* va, const double* packed, int o, int v, int64_t ks, int64_t ka)
 {
     const int64_t V = v, nps = V * (V + 1) / 2, n = V * V * nps;
     GRID_STRIDE(x, n)
@@ -348,8 +350,7 @@ __global__ void vvvv_sympack_kernel(double* vs, double* va, const double* vvvv, 
         const int64_t mp = x / (V * V);
         int a, b;
         unpair(mp, a, b);
-        const int64_t col = V * V * (a + V * b);
-        const double p = vvvv[e + V * f + col], q = vvvv[f + V * e + col];
+        const double p = packed[tri(tri(o + e, o + a), tri(o + f, o + b))], q = packed[tri(tri(o + f, o + a), tri(o + e, o + b))];
         vs[(int64_t)f * (f + 1) / 2 + e + ks * mp] = (e == f ? 0.25 : 0.5) * (p + q);
         if (va && e < f && a < b) va[(int64_t)f * (f - 1) / 2 + e + ka * ((int64_t)b * (b - 1) / 2 + a)] = 0.5 * (p - q);
     }
@@ -433,9 +434,9 @@ void k_pair_expand_add(Context& cx, double* out, const double* ps, const double*
 {
     LAUNCH(pair_expand_add_kernel, dim3(grid_for((int64_t)o * o * ncol)), out, ps, pa, o, ncol, ns, na);
 }
-void k_vvvv_sympack(Context& cx, double* vs, double* va, const double* vvvv, int v, int64_t ks, int64_t ka)
+void k_vvvv_sympack_packed(Context& cx, double* vs, double* va, const double* packed, int o, int v, int64_t ks, int64_t ka)
 {
-    LAUNCH(vvvv_sympack_kernel, dim3(grid_for((int64_t)v * v * ((int64_t)v * (v + 1) / 2), 65536)), vs, va, vvvv, v, ks, ka);
+    LAUNCH(vvvv_sympack_packed_kernel, dim3(grid_for((int64_t)v * v * ((int64_t)v * (v + 1) / 2), 65536)), vs, va, packed, o, v, ks, ka);
 }
 void k_c_sympack(Context& cx, double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na)
 {

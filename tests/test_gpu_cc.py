@@ -477,6 +477,47 @@ def test_completely_renormalised_triples_on_synthetic_extents(eng, o, v):
     assert np.max(np.abs(parts - out)) < 1e-12 * max(1.0, np.max(np.abs(out)))
 
 
+def test_vvvv_slice_is_formed_on_request_when_the_ladder_runs_in_pair_form(monkeypatch):
+    """A system whose pp-ladder runs in pair form builds V+- straight from the packed MO integrals and never forms <ef|ab>
+    (12.8 GB at v = 200) unless asked: afesp_ccsd_get_tensor("v_vvvv") and the completely renormalised intermediates
+    (src/ccsd.f90:2513-2520) build it then -- from the state's own copy when the host handed the integrals in, from the
+    context's resident array after afesp_ao2mo_mp2; once that array has been replaced the request is an error, not stale data."""
+    from afesp_amd import inputs
+    from afesp_amd.capi import Engine, AfespError
+    monkeypatch.setenv("AFESP_PP_SYM", "1")
+    o, v = 4, 10
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.04, seed=15)
+    cc = orc.OracleCC(o, v, eri, e, 6)
+    onit, _, _ = cc.solve(60, 1e-9, 1e-9)
+    cc.cr_intermediates()
+    ref = cc.triples_cr(e)
+    with Engine(0) as eng:
+        eng.ccsd_init(o, v, e, eri, 6)                       # host-supplied integrals: the state keeps its device copy
+        live_without = eng.arena_stats()["live_gb"]
+        assert eng.do_ccsd_spatial(60, 1e-9, 1e-9)[0] == onit
+        assert np.max(np.abs(eng.tensor("v_vvvv") - cc.field("v_vvvv"))) == 0.0
+        assert eng.arena_stats()["live_gb"] > live_without   # formed now, not before
+        eng.build_cr_intermediates()
+        out = eng.do_ccsd_t_spatial_cr()
+        assert np.max(np.abs(out - ref)) < 1e-10 * max(1.0, np.max(np.abs(ref)))
+    with Engine(0) as eng:
+        c = np.eye(n)
+        eng.do_mp2_spatial(n, o, c, e, eri, want_eri_mo=False)   # identity coefficients: the MO integrals are the AO ones
+        eng.ccsd_init(o, v, e, None, 6)
+        assert eng.do_ccsd_spatial(60, 1e-9, 1e-9)[0] == onit
+        eng.build_cr_intermediates()                           # forms <ef|ab> from the resident array
+        out = eng.do_ccsd_t_spatial_cr()
+        assert np.max(np.abs(out - ref)) < 1e-10 * max(1.0, np.max(np.abs(ref)))
+    with Engine(0) as eng:
+        eng.do_mp2_spatial(n, o, np.eye(n), e, eri, want_eri_mo=False)
+        eng.ccsd_init(o, v, e, None, 6)
+        eng.do_mp2_spatial(n, o, np.eye(n), e, 2.0 * eri, want_eri_mo=False)   # replaces the resident integrals
+        with pytest.raises(AfespError):
+            eng.tensor("v_vvvv")
+        eng.ccsd_init(o, v, e, None, 6)                        # ... a new initialisation sees the new ones
+        assert np.max(np.abs(eng.tensor("v_vvvv") - 2.0 * cc.field("v_vvvv"))) < 1e-15
+
+
 @pytest.mark.parametrize("o,v,tiny_pool", [(5, 12, False), (7, 10, True), (4, 17, False)])
 def test_coinciding_pair_blocks_in_their_own_launch(o, v, tiny_pool, monkeypatch):
     """Blocks Y^{p;qq} are computed as X over half the summation index in a launch of their own and symmetrised by the orbit
