@@ -60,6 +60,7 @@ struct Arena {
     std::multimap<size_t, void*> idle;       // blocks given back, by size
     size_t idle_bytes = 0, driver_calls = 0, reuse_hits = 0;
     void* get(size_t bytes);
+    void* take_largest(size_t min_bytes, size_t max_bytes, size_t* got);   // the largest idle block within the limits (or null), whole
     void put(void* p);
     void trim();                             // hipFree every idle block
     void destroy();                          // ... and every live one

@@ -237,6 +237,7 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         if (!eri_packed && (!ctx->eri_ao_dev || ctx->eri_ao_n != n))
             throw Error(1, "afesp_ao2mo_mp2: eri_packed is NULL and no AO integrals were read onto the device for this basis size");
         // upload buffer, then the packed MO integrals; a transform of the same basis size overwrites the previous result
+        cx.drop_scratch("t_");   // the (T) pool of a previous system holds the blocks the two temporaries below were
         double* packed = ctx->eri_mo_dev;
         if (ctx->cc.eri_src == packed) ctx->cc.eri_src = nullptr;   // a solver state initialised from them can no longer form <ef|ab>
         if (!packed || ctx->eri_mo_n != n) {

@@ -43,6 +43,21 @@ void* Arena::get(size_t bytes)
     live[p] = bytes;
     return p;
 }
+void* Arena::take_largest(size_t min_bytes, size_t max_bytes, size_t* got)
+{
+    for (auto it = idle.rbegin(); it != idle.rend(); ++it) {
+        if (it->first > max_bytes) continue;
+        if (it->first < min_bytes) break;
+        void* p = it->second;
+        *got = it->first;
+        live[p] = it->first;
+        idle_bytes -= it->first;
+        idle.erase(std::next(it).base());
+        ++reuse_hits;
+        return p;
+    }
+    return nullptr;
+}
 void Arena::put(void* p)
 {
     auto it = live.find(p);

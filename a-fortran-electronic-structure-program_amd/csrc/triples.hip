@@ -214,7 +214,55 @@ struct TriplesPlan {
     TripleMeta* meta = nullptr;
     int* orbits = nullptr;
     GettGroup* gdesc = nullptr;    // fused scheme: group descriptors of all chunks
+    double* pool0 = nullptr;       // fused scheme, not completely renormalised: base the block offsets refer to (assemble_pool)
 };
+
+// The block pool of the fused (T) as a list of device blocks.  A block of the pool is only ever addressed as base + offset
+// (GEMM column tables, TripleMeta::xoff), and the address space is flat, so the pool need not be ONE allocation: blocks the
+// context's arena holds idle -- the two AO->MO temporaries, 2 x 9.4 GB at config 5 -- are taken whole and filled with as many
+// blocks as fit, and only the rest is asked for anew (5 GB instead of 24: on this runtime a fresh allocation out of recycled
+// device memory costs 60-75 ms per GB).  Returns the element offset of every block relative to *pool0.
+static std::vector<int64_t> assemble_pool(Context& cx, int64_t nblocks, int64_t vp3, double** pool0)
+{
+    const size_t bb = (size_t)vp3 * sizeof(double);
+    struct Piece { char* base; int64_t n; };
+    std::vector<Piece> have;
+    int64_t cap = 0;
+    for (int i = 0;; ++i) {
+        auto it = cx.cache.find("t_xpool" + std::to_string(i));
+        if (it == cx.cache.end()) break;
+        have.push_back({(char*)it->second.first, (int64_t)(it->second.second / bb)});
+        cap += have.back().n;
+    }
+    if (cap < nblocks) {
+        if (!have.empty()) cx.drop_scratch("t_xpool");
+        have.clear();
+        int64_t need = nblocks;
+        for (int i = 0; need > 0; ++i) {
+            const std::string name = "t_xpool" + std::to_string(i);
+            size_t got = 0;
+            // an idle block that holds a good part of what is still needed, and is not much more than that
+            void* q = cx.arena.take_largest((size_t)std::min<int64_t>(need, 8) * bb, (size_t)need * bb * 2, &got);
+            int64_t k;
+            if (q) {
+                k = std::min<int64_t>(need, (int64_t)(got / bb));
+                cx.cache[name] = {q, got};
+            } else {
+                k = need;
+                q = cx.scratch(name, k * vp3);
+            }
+            have.push_back({(char*)q, k});
+            need -= k;
+        }
+    }
+    *pool0 = (double*)have[0].base;
+    std::vector<int64_t> off;
+    off.reserve((size_t)nblocks);
+    for (const Piece& pc : have)
+        for (int64_t b = 0; b < pc.n && (int64_t)off.size() < nblocks; ++b)
+            off.push_back((int64_t)((pc.base - have[0].base) / (ptrdiff_t)sizeof(double)) + b * vp3);
+    return off;
+}
 
 // Plan of the spin-orbital (T): i<j<k, three blocks per triple, one launch per integral slab and chunk.
 static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end)
@@ -398,6 +446,32 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
     const int mtiles = (int)((v2 + BM - 1) / BM);
     const char* split_env = getenv("AFESP_T_SPLIT_TILES");   // test / tuning knob, read when a plan is built
     const int64_t split_min_tiles = split_env ? atoll(split_env) : 1024;
+    // first pass: the largest number of distinct blocks Y^{p;qr} of one block triple inside the requested range = the pool size
+    {
+        int64_t fl = 0;
+        for (int I = 0; I < nbk; ++I)
+            for (int J = I; J < nbk; ++J)
+                for (int K = J; K < nbk; ++K) {
+                    std::unordered_map<int64_t, int> seen;
+                    for (int i = I * sb; i < std::min(o, (I + 1) * sb); ++i)
+                        for (int j = std::max(i, J * sb); j < std::min(o, (J + 1) * sb); ++j)
+                            for (int k = std::max(j, K * sb); k < std::min(o, (K + 1) * sb); ++k, ++fl) {
+                                if (fl < t_begin || fl >= t_end) continue;
+                                const int pq[3][3] = {{i, j, k}, {j, i, k}, {k, i, j}};
+                                for (auto& b : pq) seen.emplace(((int64_t)b[0] * o + std::min(b[1], b[2])) * o + std::max(b[1], b[2]), 0);
+                            }
+                    max_blocks = std::max<int64_t>(max_blocks, (int64_t)seen.size());
+                }
+    }
+    // where block b of the pool lives (element offset from the pool base): one allocation for the completely renormalised
+    // variant (its second pool mirrors the first), pieces of idle memory otherwise
+    std::vector<int64_t> blk_off;
+    if (cr || getenv("AFESP_T_ONE_POOL")) {
+        for (int64_t b = 0; b < max_blocks; ++b) blk_off.push_back(b * vp3);
+        p->pool0 = nullptr;
+    } else {
+        blk_off = assemble_pool(cx, max_blocks, vp3, &p->pool0);
+    }
     for (int I = 0; I < nbk; ++I)
         for (int J = I; J < nbk; ++J)
             for (int K = J; K < nbk; ++K) {
@@ -426,9 +500,9 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
                             m.mult = (i == j && j == k) ? 1.0 : (i == j || j == k) ? 3.0 : 6.0;
                             m.woff = 0;
                             for (int q = 0; q < 6; ++q) m.xoff[q] = 0;
-                            m.xoff[0] = block_of(i, j, k) * vp3;   // Y^{i;jk}(a;b,c)
-                            m.xoff[1] = block_of(j, i, k) * vp3;   // Y^{j;ik}(b;a,c)
-                            m.xoff[5] = block_of(k, i, j) * vp3;   // Y^{k;ij}(c;a,b)
+                            m.xoff[0] = blk_off[(size_t)block_of(i, j, k)];   // Y^{i;jk}(a;b,c)
+                            m.xoff[1] = blk_off[(size_t)block_of(j, i, k)];   // Y^{j;ik}(b;a,c)
+                            m.xoff[5] = blk_off[(size_t)block_of(k, i, j)];   // Y^{k;ij}(c;a,b)
                             cur.push_back(m);
                         }
                 if (cur.empty()) continue;
@@ -436,7 +510,7 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
                 ch.nt = (int)cur.size();
                 ch.meta_off = (int64_t)metas.size();
                 metas.insert(metas.end(), cur.begin(), cur.end());
-                max_blocks = std::max<int64_t>(max_blocks, (int64_t)blks.size());
+                if ((int64_t)blks.size() > max_blocks) throw Error(2, "triples plan: block count of a chunk exceeds the pool");
                 // groups of columns that share {q,r}
                 std::vector<int64_t> hBn, hCn, hK;
                 std::stable_sort(blks.begin(), blks.end(), [](const Blk& x, const Blk& y) { return x.q != y.q ? x.q < y.q : x.r < y.r; });
@@ -448,7 +522,7 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
                     for (size_t bi = b0; bi < b1; ++bi)
                         for (int64_t x = 0; x < V; ++x) {
                             hBn.push_back(Kc * (x + V * (q + O * blks[bi].p)));           // tt(:, x, q, p); second half: (r, p)
-                            hCn.push_back(CUBE * (x / TT) + x % TT + vp3 * blks[bi].buf);
+                            hCn.push_back(CUBE * (x / TT) + x % TT + blk_off[(size_t)blks[bi].buf]);
                         }
                     b0 = b1;
                     TriplesPlan::Group g;
@@ -684,7 +758,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     const int nq = cr ? 6 : want_d ? 4 : 2;
     k_fill(cx, cx.scal, 6, 0.0);
     TriplesIn in{s.e, s.t1.d, vs.d, ts.d, s.t2.d, o, v};
-    double* Xpool = cx.scratch("t_xpool", p->nb * vp3);
+    double* Xpool = p->pool0 ? p->pool0 : cx.scratch("t_xpool", p->nb * vp3);
     int64_t max_nt = 1;
     for (const TriplesPlan::Chunk& ch : p->chunks) max_nt = std::max<int64_t>(max_nt, ch.nt);
     double* partial = cx.scratch("t_partial", 6 * std::max<int64_t>((int64_t)p->norb * max_nt, 512));
