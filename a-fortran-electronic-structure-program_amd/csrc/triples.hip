@@ -241,8 +241,10 @@ static std::vector<int64_t> assemble_pool(Context& cx, int64_t nblocks, int64_t 
         for (int i = 0; need > 0; ++i) {
             const std::string name = "t_xpool" + std::to_string(i);
             size_t got = 0;
-            // an idle block that holds a good part of what is still needed, and is not much more than that
-            void* q = cx.arena.take_largest((size_t)std::min<int64_t>(need, 8) * bb, (size_t)need * bb * 2, &got);
+            // an idle block that is just what is still needed; else the largest one that can be filled completely (and holds a
+            // good part of it); else a new one for the rest
+            void* q = cx.arena.take_largest((size_t)need * bb, (size_t)need * bb + (size_t)need * bb / 4, &got);
+            if (!q) q = cx.arena.take_largest((size_t)std::min<int64_t>(need, 8) * bb, (size_t)need * bb, &got);
             int64_t k;
             if (q) {
                 k = std::min<int64_t>(need, (int64_t)(got / bb));
