@@ -435,6 +435,40 @@ def test_plain_triples_equal_the_full_evaluation(eng, o, v):
     assert np.max(np.abs(parts - plain)) < 1e-13 * max(1.0, np.max(np.abs(plain)))
 
 
+def test_block_pool_in_pieces_of_idle_memory_equals_one_allocation(monkeypatch):
+    """The (T) block pool is assembled from blocks the context holds idle (here: the AO->MO temporaries, which at these extents are
+    larger than a few blocks but not more than the pool needs) plus a fresh remainder; the GEMM column tables and the orbit
+    kernel address blocks across the pieces.  Same sums as with the pool in one allocation (AFESP_T_ONE_POOL) and as the oracle;
+    a second system in the same context finds the pieces of the first."""
+    from afesp_amd.capi import Engine
+    o, v = 6, 24
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.04, seed=29)
+    cc = orc.OracleCC(o, v, eri, e, 6)
+    cc.solve(40, 1e-9, 1e-9)
+    ref = cc.triples(e)
+    out = {}
+    for mode in ("pieces", "one"):
+        if mode == "one":
+            monkeypatch.setenv("AFESP_T_ONE_POOL", "1")
+        with Engine(0) as eng:
+            eng.do_mp2_spatial(n, o, np.eye(n), e, eri, want_eri_mo=False)    # leaves its two temporaries idle at ccsd_init
+            eng.ccsd_init(o, v, e, None, 6)
+            eng.do_ccsd_spatial(40, 1e-9, 1e-9)
+            idle_before = eng.arena_stats()["idle_gb"]
+            out[mode] = eng.do_ccsd_t_spatial()
+            if mode == "pieces":
+                assert eng.arena_stats()["idle_gb"] < idle_before        # the pool took idle blocks
+                nt = eng.ntriples()
+                parts = eng.do_ccsd_t_spatial(0, nt // 3) + eng.do_ccsd_t_spatial(nt // 3, nt)
+                assert np.max(np.abs(parts - out[mode])) < 1e-12 * max(1.0, np.max(np.abs(out[mode])))
+                eng.do_mp2_spatial(n, o, np.eye(n), e, eri, want_eri_mo=False)   # next system: gives the pool back first
+                eng.ccsd_init(o, v, e, None, 6)
+                eng.do_ccsd_spatial(40, 1e-9, 1e-9)
+                assert np.array_equal(eng.do_ccsd_t_spatial(), out[mode])
+    assert np.array_equal(out["pieces"], out["one"])
+    assert np.max(np.abs(out["pieces"] - ref)) < 1e-10 * max(1.0, np.max(np.abs(ref)))
+
+
 def test_iteration_graph_survives_other_work_in_the_same_context(eng):
     """The small-system iteration is replayed as a captured graph; (T) calls, tensor downloads and a spin-orbital solve in
     the same context (which frees cached scratch buffers) must not leave it replaying stale buffers."""
