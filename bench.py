@@ -319,8 +319,16 @@ class Reducer:
                 eng.comm_init(rank, world, capi.COMM_HOST, os.path.join(jobdir, f"afesp_seg_{Reducer.count}"))
                 self.kind = "afesp_allreduce_sum (host segment: ranks share a GPU)"
             else:
-                box = [eng.comm_unique_id() if rank == 0 else None]
+                # rank 0's failure to produce an id must still reach the broadcast, or the other ranks wait in it for ever
+                box = [None]
+                if rank == 0:
+                    try:
+                        box = [eng.comm_unique_id()]
+                    except Exception as exc:   # noqa: BLE001
+                        box = [f"error: {exc}"]
                 dist.broadcast_object_list(box, src=0)
+                if not isinstance(box[0], (bytes, bytearray)):
+                    raise RuntimeError(f"no RCCL unique id from rank 0 ({box[0]})")
                 eng.comm_init(rank, world, capi.COMM_RCCL, None, box[0])
                 self.kind = "afesp_allreduce_sum (ncclAllReduce on the engine stream)"
             self.own = True
