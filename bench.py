@@ -360,6 +360,45 @@ class Reducer:
             self.eng.comm_destroy()
 
 
+def live_pmc(workload, timeout_s=240.0):
+    """HBM traffic and MFMA-pipe busy fraction of the grouped (T) GEMM launches, measured NOW: four rocprofv3 --pmc passes of
+    this very command (one counter per pass, kernel trace only -- counters are collected in runs of their own, MI355X_MICROARCH
+    guide) as child processes on the same GPU.  FETCH_SIZE counts 64 B per 128-B request on gfx950 (x2; calibrated on a stream of
+    known size, profiles/r01_pmc_*).  Returns None if rocprofv3 is missing, a pass fails or the budget runs out."""
+    import csv, glob, shutil, subprocess
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    if any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None   # this process is being profiled itself: no profiler inside a profiler
+    t_end = time.time() + timeout_s
+    grouped = lambda name: "gett_kernel" in name and ", true, false>" in name   # <..., GRP = true, RAG = false>
+    mean = {}
+    with tempfile.TemporaryDirectory(prefix="afesp_pmc_", dir="/tmp") as td:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+            out = os.path.join(td, counter)
+            cmd = [exe, "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                   "--no-extra", "--steps-only", "--no-live-pmc"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.DEVNULL, timeout=max(5.0, t_end - time.time()))
+            except (subprocess.TimeoutExpired, OSError):
+                return None
+            files = glob.glob(out + "/*/*counter_collection.csv")
+            if r.returncode != 0 or not files:
+                return None
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if row["Counter_Name"] == counter and grouped(row["Kernel_Name"])]
+            if not vals:
+                return None
+            mean[counter] = (sum(vals) / len(vals), len(vals))
+    fetch, write = mean["FETCH_SIZE"][0] * 1024 * 2, mean["WRITE_SIZE"][0] * 1024
+    return {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+            "dispatches": mean["FETCH_SIZE"][1],
+            "mfma_busy_frac": mean["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (256 * 4) / (mean["GRBM_GUI_ACTIVE"][0] / 8)}
+
+
 def latest_profile(pattern):
     """Newest profiles/rNN_<pattern> file (the PMC passes are separate rocprofv3 runs of this same command, tools/refresh_profiles.sh)."""
     import glob
@@ -463,7 +502,15 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             roof["flop_per_launch"] = prof["gemm_flop"] / nl
             roof["share_of_step_time"] = prof["gemm_ms"] * 1e-3 / elapsed
             tfile = latest_profile("traffic.json")
-            if tfile:
+            live = live_pmc(workload) if (args.live_pmc and world == 1 and workload == args.workload) else None
+            if live:
+                roof["traffic"] = live["hbm_bytes_per_launch"]
+                roof["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES | "
+                                          f"GRBM_GUI_ACTIVE, one pass each, of `bench.py --workload {workload} --steps 1 --warmup 0` as child "
+                                          f"processes ({live['dispatches']} grouped launches; FETCH_SIZE x2 per the gfx950 correction); "
+                                          f"fetched {live['fetch_bytes_per_launch']:.4g} B + written {live['write_bytes_per_launch']:.4g} B per launch")
+                roof["mfma_busy"] = live["mfma_busy_frac"]
+            elif tfile:
                 tr = json.load(open(tfile)).get(workload + "_t_gemm")
                 if tr:
                     roof["traffic"] = tr["hbm_bytes_per_launch"]
@@ -532,6 +579,9 @@ def main():
     ap.add_argument("--scale", type=float, default=None)
     ap.add_argument("--steps-only", dest="legs", action="store_false",
                     help="only the timed steps: no pp-ladder / AO->MO timing legs behind them (kernel traces of the steps alone)")
+    ap.add_argument("--no-live-pmc", dest="live_pmc", action="store_false",
+                    help="take roofline.traffic / mfma_busy from the newest profiles/rNN_traffic.json instead of measuring them in "
+                         "this run (four rocprofv3 --pmc passes of this command as child processes, N = 1 only)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the multi-rank path on a one-GPU box")
     args = ap.parse_args()

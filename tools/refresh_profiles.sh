@@ -13,8 +13,8 @@ echo "== bench lines"; date
 python3 $R/bench.py | tail -1 > $O/${TAG}_bench_cfg5_line.json || exit 1
 python3 $R/bench.py --workload h2o_tz --steps 50 --warmup 45 --no-extra | tail -1 > $O/${TAG}_bench_h2o_tz_line.json || exit 1
 echo "== kernel traces"; date
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_cfg5 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $O/kt_cfg5.log 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_h2o -- python3 $R/bench.py --workload h2o_tz --steps 50 --warmup 45 --no-cpu-baseline --no-extra --steps-only > $O/kt_h2o.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_cfg5 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-live-pmc > $O/kt_cfg5.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_h2o -- python3 $R/bench.py --workload h2o_tz --steps 50 --warmup 45 --no-cpu-baseline --no-extra --no-live-pmc --steps-only > $O/kt_h2o.log 2>&1 || exit 1
 python3 $R/tools/summarize_profile.py /tmp/kt_cfg5 > $O/${TAG}_bench_cfg5_kernels.json
 python3 $R/tools/summarize_profile.py /tmp/kt_h2o > $O/${TAG}_bench_h2o_tz_kernels.json
 python3 $R/tools/small_system_gaps.py /tmp/kt_h2o 600 > $O/${TAG}_bench_h2o_tz_gaps.txt
