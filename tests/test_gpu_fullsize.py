@@ -63,6 +63,36 @@ def test_triples_shards_add_up_and_match_oracle_on_device_tensors(big):
     assert np.max(np.abs(got - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref)))
 
 
+@pytest.mark.parametrize("pool_gib", ["6", None])
+def test_first_block_of_triples_against_the_blas_backed_restatement(big, monkeypatch, pool_gib):
+    """All sorted triples i <= j <= k over the first s occupied orbitals (the first block triple of the engine's enumeration: coinciding
+    pairs, a triple with i = j = k, every multiplicity) = all s^3 ordered triples of the reference's loop over those orbitals,
+    evaluated by the dgemm-per-term restatement (oracle/afesp_oracle_blas.c, pinned to the loop form by tests/test_oracle_golden.py)
+    on the tensors the device holds.  A smaller pool than the default makes s = 3 (27 reference triples); the default pool
+    s = 5 (125)."""
+    L = orc.blas_lib()
+    if L is None:
+        pytest.skip("numpy's bundled OpenBLAS not found")
+    if pool_gib:
+        monkeypatch.setenv("AFESP_T_POOL_GIB", pool_gib)
+    s = big.t_block_size()
+    assert 2 <= s <= (4 if pool_gib else 8)
+    nsorted = s * (s + 1) * (s + 2) // 6
+    got = big.do_ccsd_t_spatial(0, nsorted)
+    t1, t2 = big.amplitudes()
+    f = lambda a: np.ascontiguousarray(a.ravel(order="F"))
+    e = np.concatenate([-2.0 + np.arange(O) / (O - 1), 1.0 + 2.0 * np.arange(V) / (V - 1)])
+    args = (O, V, e, f(t1), f(t2), f(big.tensor("v_vvov")), f(big.tensor("v_oovo")), f(big.tensor("v_oovv")))
+    ref = np.zeros(4)
+    for i in range(s):
+        for j in range(s):               # ordered triples (i, j, 0..s-1) are consecutive in the reference's flat order
+            out = np.zeros(4)
+            lo = (i * O + j) * O
+            assert L.orcb_ccsd_t(*args, lo, lo + s, out) == 0
+            ref += out
+    assert np.max(np.abs(got - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref))), (got, ref)
+
+
 def _hash_uniform(k, seed):
     """numpy twin of the device generator (csrc/capi.hip, splitmix64) used by afesp_synthetic_ao / afesp_synthetic_init"""
     with np.errstate(over="ignore"):
