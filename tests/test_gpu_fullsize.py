@@ -93,6 +93,24 @@ def test_first_block_of_triples_against_the_blas_backed_restatement(big, monkeyp
     assert np.max(np.abs(got - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref))), (got, ref)
 
 
+def test_one_amplitude_update_at_config_5_against_the_pinned_restatement(capsys):
+    """Config 5, element by element: all twelve intermediates, both residuals and the updated t1 / t2 of one CCSD update from
+    non-trivial amplitudes against the loop-form restatement (the one the reference's bundled outputs pin) on the same hashed
+    integrals -- 1e-10 relative; measured 3.4e-14 (profiles/r02_full_iteration_check.txt).  The restatement needs about two
+    minutes on the box's 16 host threads, by far the longest test of the suite (tools/full_iteration_check.py does the work)."""
+    import importlib.util, os, sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "full_iteration_check.py")
+    spec = importlib.util.spec_from_file_location("full_iteration_check", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv, sys.argv = sys.argv, [path, str(O), str(V)]
+    try:
+        rc = mod.main()
+    finally:
+        sys.argv = argv
+    assert rc == 0, capsys.readouterr().out[-2000:]
+
+
 def _hash_uniform(k, seed):
     """numpy twin of the device generator (csrc/capi.hip, splitmix64) used by afesp_synthetic_ao / afesp_synthetic_init"""
     with np.errstate(over="ignore"):
