@@ -93,6 +93,21 @@ def test_first_block_of_triples_against_the_blas_backed_restatement(big, monkeyp
     assert np.max(np.abs(got - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref))), (got, ref)
 
 
+def test_completely_renormalised_variant_at_full_size_carries_the_same_sums(big):
+    """The completely renormalised evaluation (second pool of moment blocks, its own orbit-kernel instantiation at two workgroups
+    per CU) returns E[T], E(T), D[T], D(T) of the plain evaluation on a shard of config 5, and finite moment sums that add up
+    over sub-shards."""
+    big.build_cr_intermediates()
+    nt = big.ntriples()
+    hi = nt // 12
+    ref = big.do_ccsd_t_spatial(0, hi)
+    cr = big.do_ccsd_t_spatial_cr(0, hi)
+    assert np.max(np.abs(cr[:4] - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref)))
+    assert np.all(np.isfinite(cr)) and abs(cr[4]) > 0.0
+    parts = big.do_ccsd_t_spatial_cr(0, hi // 3) + big.do_ccsd_t_spatial_cr(hi // 3, hi)
+    assert np.max(np.abs(parts - cr)) < 1e-11 * max(1.0, np.max(np.abs(cr)))
+
+
 def test_one_amplitude_update_at_config_5_against_the_pinned_restatement(capsys):
     """Config 5, element by element: all twelve intermediates, both residuals and the updated t1 / t2 of one CCSD update from
     non-trivial amplitudes against the loop-form restatement (the one the reference's bundled outputs pin) on the same hashed
