@@ -1126,6 +1126,7 @@ int afesp_ccsd_t_block_size(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr,
 int afesp_debug_stamps(unsigned long long* out, int n)
 {
     if (n < 0) return triples_read_orbit_stamps(out, -n) == hipSuccess ? 0 : 1;   // the (T) orbit kernel's phase sums
+    if (getenv("AFESP_STAMPS_GROUPED")) return gett_read_stamps_grouped(out, n) == hipSuccess ? 0 : 1;
     return gett_read_stamps(out, n) == hipSuccess ? 0 : 1;
 }
 

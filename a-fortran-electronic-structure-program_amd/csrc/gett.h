@@ -66,7 +66,9 @@ struct GettWorkspace {
 hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_t stream, int force_split = 0,
                        int force_tm = 0, int force_tn = 0);
 
-hipError_t gett_read_stamps(unsigned long long* out, int n);   // diagnostic builds (gett.hip)
+hipError_t gett_read_stamps(unsigned long long* out, int n);           // diagnostic builds (gett.hip)
+hipError_t gett_read_stamps_grouped(unsigned long long* out, int n);   // ... of the grouped kernels (gett_grouped.hip)
+void preload_gett_grouped();
 
 extern int g_group_m, g_force_tm, g_force_tn, g_force_split, g_allow_wide, g_dbg;
 

@@ -22,7 +22,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // Diagnostic builds only (AFESP_GETT_VARIANT bit 64): per (workgroup, wave) cycle sums -- [0] whole stream, [1] parked at the
 // step barrier (incl. the LDS-write drain in front of it), [2] the LDS-write block (incl. its wait for the gathered data),
 // [3] number of steps.  Read with gett_read_stamps; never part of a timed or shipped build.
-__device__ unsigned long long g_gett_stamp[256 * 8 * 4];
+static __device__ unsigned long long g_gett_stamp[256 * 8 * 4];   // (one per translation unit: gett.hip, gett_grouped.hip)
 
 constexpr int BK = 16;
 
@@ -484,6 +484,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
 #undef AFESP_GETT_STEP
 }
 
+#ifndef AFESP_GETT_GROUPED_TU
 // Deterministic split-K combine: fixed summation order over the split index.  The slab loads of one element are
 // independent (issued eight at a time), only the adds are ordered; 32-bit index arithmetic whenever M*N allows it (the
 // 64-bit division alone was a third of this kernel's 10 us on the 25 x 2809 outputs of the o=5, v=53 iteration).
@@ -543,9 +544,7 @@ void preload_gett()
     preload_cfg<2, 2, 2, 1, 1>(); preload_cfg<2, 2, 2, 2, 1>(); preload_cfg<2, 2, 2, 2, 2>(); preload_cfg<2, 2, 2, 4, 1>(); preload_cfg<2, 2, 2, 4, 2>();
     preload_cfg<2, 2, 4, 1, 1>(); preload_cfg<2, 2, 4, 2, 1>(); preload_cfg<2, 2, 4, 2, 2>();
     preload_cfg<2, 4, 4, 2, 1>(); preload_cfg<2, 4, 4, 2, 2>();
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<2, 4, 4, 2, true, true, 2, true>));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<2, 4, 4, 2, true, true, 1, true>));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<4, 2, 4, 4, true, true, 2, true>));
+    preload_gett_grouped();   // (gett_grouped.hip)
     preload_cfg<4, 2, 4, 4, 1>(); preload_cfg<4, 2, 4, 4, 2>(); preload_cfg<2, 4, 4, 4, 1>(); preload_cfg<2, 4, 4, 4, 2>();
     (void)hipGetLastError();
 }
@@ -554,6 +553,24 @@ hipError_t gett_read_stamps(unsigned long long* out, int n)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gett_stamp), sizeof(unsigned long long) * (size_t)(n < 256 * 8 * 4 ? n : 256 * 8 * 4));
 }
+
+#else
+extern int g_dbg;
+// the grouped instantiations (the lists in gett_launch_grouped)
+void preload_gett_grouped()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<2, 4, 4, 2, true, true, 2, true>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<2, 4, 4, 2, true, true, 1, true>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<4, 2, 4, 4, true, true, 2, true>));
+    (void)hipGetLastError();
+}
+// diagnostic builds: the stamps of the grouped kernels live in this translation unit
+hipError_t gett_read_stamps_grouped(unsigned long long* out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gett_stamp), sizeof(unsigned long long) * (size_t)(n < 256 * 8 * 4 ? n : 256 * 8 * 4));
+}
+#endif
 
 // Resident workgroups the device holds for one kernel instantiation (CUs x occupancy), found once per instantiation.
 template <typename Kern>
@@ -592,6 +609,9 @@ static void launch_cfg(const GettKernelArgs& a, dim3 grid, hipStream_t st)
     else launch_one<WM, WN, TM, TN, false, false, W>(a, grid, st);
 }
 
+#ifdef AFESP_GETT_GROUPED_TU
+extern int g_group_m, g_allow_wide;
+#else
 int g_group_m = 0;   // >0 overrides the tile-walk group size (tuning knob, see afesp_set_tuning)
 int g_force_tm = 0, g_force_tn = 0, g_force_split = 0, g_allow_wide = 1;
 
@@ -699,6 +719,9 @@ void gett_grouped_tile(int M, bool wide, int* tm, int* tn, int* BM, int* BN)
     else { *tm = 4; *tn = 4; *BM = 128; *BN = 128; }
 }
 
+#endif   // !AFESP_GETT_GROUPED_TU
+
+#ifdef AFESP_GETT_GROUPED_TU
 hipError_t gett_launch_grouped(const GettProblem& p, const GettGroup* dev_groups, int ngroups, int total_tiles, int max_ntiles,
                                hipStream_t stream)
 {
@@ -733,5 +756,6 @@ hipError_t gett_launch_grouped(const GettProblem& p, const GettGroup* dev_groups
     }
     return hipGetLastError();
 }
+#endif   // AFESP_GETT_GROUPED_TU
 
 }  // namespace afesp
