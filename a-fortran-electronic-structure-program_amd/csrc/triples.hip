@@ -388,19 +388,20 @@ static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_b
 // per pair.  The flat index [t_begin, t_end) the ranks shard refers to THIS order.
 static int fused_block_size(int o, int v, bool cr, int64_t budget_bytes)
 {
+    (void)cr;   // the budget is per pool (the completely renormalised variant has two)
     const int64_t nt8 = (v + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;
-    const int64_t per_block = vp3 * (int64_t)sizeof(double);   // the budget is per pool (the completely renormalised variant has two)
+    const int64_t per_block = vp3 * (int64_t)sizeof(double);
     int smax = 1;
     while (smax < o && (int64_t)3 * (smax + 1) * (smax + 1) * (smax + 1) * per_block <= budget_bytes) ++smax;
-    // among the three largest sizes that fit, the one whose GEMMs (M = v^2 rows in 256-row tiles, N = v*s columns in
-    // 128-column tiles) leave the fullest last round of 256 workgroups
-    int best = smax;
-    double best_fill = -1.0;
-    for (int sz = smax; sz >= std::max(1, smax - 2); --sz) {
-        const int64_t tiles = (((int64_t)v * v + 255) / 256) * (((int64_t)v * sz + 127) / 128);
-        const double fill = (double)tiles / (double)((tiles + 255) / 256 * 256);
-        if (fill > best_fill + 0.03) { best_fill = fill; best = sz; }
-    }
+    // What a larger block buys is wider column groups (N = s v columns per occupied pair, in 128-column tiles) and longer
+    // launches; from about 900 columns on neither matters any more (config 5: s = 5, 7 -> 506.8, 506.0 ms; s = 4 -> 549), while
+    // the pool grows with s^3 -- and every byte allocated for the first time costs on this runtime.  So: the
+    // smallest size with >= 900 columns per group, or one of the next two if it fills its column tiles more than 2 % better.
+    const int smin = std::min(smax, std::max(1, (900 + v - 1) / v));
+    auto fill = [&](int sz) { return (double)((int64_t)v * sz) / (double)((((int64_t)v * sz + 127) / 128) * 128); };
+    int best = smin;
+    for (int sz = smin + 1; sz <= std::min(smax, smin + 2); ++sz)
+        if (fill(sz) > fill(best) + 0.02) best = sz;
     return best;
 }
 
@@ -410,11 +411,9 @@ static int64_t device_pool_budget()
     AFESP_HIP(hipMemGetInfo(&mem_free, &mem_total));
     const char* e = getenv("AFESP_T_POOL_GIB");   // tuning knob
     if (e) return (int64_t)atoll(e) << 30;
-    // An eighth of the device, 32 GiB at most: five occupied indices per block at config 5 (a 24 GB pool), where the GEMM groups
-    // fill their column tiles as well as with seven (97.7 %) and (T) takes 506.8 ms instead of 506.0 -- but 32 GB less are
-    // allocated on first use, and on this runtime a large allocation out of recycled device memory costs ~60 ms per GB
-    // (DESIGN.md 4.4).  Below that the launches get short: 16 GiB -> 549 ms.
-    return std::min<int64_t>((int64_t)32 << 30, (int64_t)(mem_total / 8));
+    // upper limit of one pool: a quarter of the device, 64 GiB at most (fused_block_size normally stays well below it: 24 GB at
+    // config 5)
+    return std::min<int64_t>((int64_t)64 << 30, (int64_t)(mem_total / 4));
 }
 
 static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end, bool cr)
