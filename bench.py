@@ -380,13 +380,23 @@ def live_pmc(workload, timeout_s=240.0):
             cmd = [exe, "--kernel-trace", "--output-format", "csv", "--pmc", counter, "-d", out, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
                    "--no-extra", "--steps-only", "--no-live-pmc"]
+            try:   # (a session of its own: on a time-out the profiler AND the program under it are ended, by process group)
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                        stderr=subprocess.DEVNULL, start_new_session=True)
+            except OSError:
+                return None
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                                   stderr=subprocess.DEVNULL, timeout=max(5.0, t_end - time.time()))
-            except (subprocess.TimeoutExpired, OSError):
+                rc = proc.wait(timeout=max(5.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
                 return None
             files = glob.glob(out + "/*/*counter_collection.csv")
-            if r.returncode != 0 or not files:
+            if rc != 0 or not files:
                 return None
             vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
                     if row["Counter_Name"] == counter and grouped(row["Kernel_Name"])]
