@@ -178,9 +178,11 @@ void k_diis_solve(Context& cx, double* coef, double* bmat, const double* dots, d
 constexpr int DIIS_FLAG_SLOT = 48;   // cx.scal[48]: set by diis_solve_kernel when the solve fails, read with the energies
 void diis_check_flag(Context& cx, const double* host_scal);   // throws the reference's error (ccsd.f90:666) if it is set
 // pair-symmetric AO->MO: u(i,j,KL) from the packed array; out(k,l,PQ) = in(q,p,tri(k,l)); packed[tri(PQ,RS)] = full(s,r,PQ)
-void k_unpack_half(Context& cx, double* u, const double* packed, int n);
+void k_unpack_half(Context& cx, double* u, const double* packed, int n, int64_t c_begin = 0, int64_t c_end = -1);   // slab of (kl) pairs
 void k_pair_transpose(Context& cx, double* out, const double* in, int n);
-void k_pack_pairs(Context& cx, double* packed, const double* full, int n);
+void k_pair_square_packed(Context& cx, double* out, const double* g, int n, int64_t c_begin, int64_t c_end);   // out(k,l,P) = g(P, tri(k,l))
+void k_tri_pack(Context& cx, double* g, const double* half, int n, int64_t k_begin, int64_t k_end);           // g(PQ,K) = half(q,p,K)
+void k_pack_pairs(Context& cx, double* packed, const double* full, int n, int64_t p_begin = 0, int64_t p_end = -1);
 // out(p,q,r,s) = packed[ index( (p+b0)(r+b2) | (q+b1)(s+b3) ) ]  physicist <pq|rs> from packed chemist (pr|qs)
 void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1, int d2, int d3, int b0, int b1, int b2,
                   int b3);

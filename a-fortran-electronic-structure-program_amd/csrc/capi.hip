@@ -255,20 +255,57 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         // Pair symmetry: (ij|kl) is transformed for the n(n+1)/2 pairs k >= l only, the half-transformed (pq|kl) kept for
         // p >= q only -- 4 n^5 flop and two buffers of n^2 x npair instead of 8 n^5 and two of n^4.
         const int64_t np = n * (n + 1) / 2;
-        // the two temporaries are cached scratch: a second transform in the same context reuses them, the next afesp_ccsd_init /
-        // afesp_ccsd_so_init gives them back (hipMalloc of several GB is not reliably cheap on this runtime)
-        Tensor Ta = view(cx.scratch("ao2mo_a", n * n * np), {n, n, np}), Tb = view(cx.scratch("ao2mo_b", n * n * np), {n, n, np});
-        if (!(ao == ctx->eri_ao_dev && ctx->half_n == n && ctx->half_epoch == cx.scratch_epoch))
-            k_unpack_half(cx, Ta.d, ao, (int)n);                     // (ij|KL), ij squared up (afesp_build_fock may have left it)
-        ctx->half_n = 0;                                             // the transform overwrites it
-        contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
-        contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348
-        k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                    // (kl|PQ), kl squared up, p >= q
-        contract(cx, 1.0, Cm, "rk", Tb, "klP", 0.0, Ta, "rlP");      // mp2.f90:357-367
-        contract(cx, 1.0, Cm, "sl", Ta, "rlP", 0.0, Tb, "rsP");      // mp2.f90:375-385
+        const bool have_u = ao == ctx->eri_ao_dev && ctx->half_n == n && ctx->half_epoch == cx.scratch_epoch;   // afesp_build_fock left (ij|KL)
+        const char* blk_env = getenv("AFESP_AO2MO_BLOCKED");
+        // slab by slab from temporaries of 16 GiB each (n >= 256): at n = 220 the blocked form is 5 % slower (58.9 against 55.8 ms:
+        // one more pass over the half-transformed integrals) for 12.5 GB less -- it is there for the sizes where 2 n^2 npair
+        // doubles no longer fit beside the rest (n = 400: 2 x 103 GB)
+        const bool blocked = blk_env ? blk_env[0] == '1' : n * n * np >= ((int64_t)1 << 31);
+        if (!blocked) {
+            // Small bases: the whole tensor at once, nine launches.  The two temporaries are cached scratch: a second transform in
+            // the same context reuses them, the next afesp_ccsd_init / afesp_ccsd_so_init gives them back.
+            Tensor Ta = view(cx.scratch("ao2mo_a", n * n * np), {n, n, np}), Tb = view(cx.scratch("ao2mo_b", n * n * np), {n, n, np});
+            if (!have_u) k_unpack_half(cx, Ta.d, ao, (int)n);            // (ij|KL), ij squared up
+            ctx->half_n = 0;                                             // the transform overwrites it
+            contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
+            contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348
+            k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                    // (kl|PQ), kl squared up, p >= q
+            contract(cx, 1.0, Cm, "rk", Tb, "klP", 0.0, Ta, "rlP");      // mp2.f90:357-367
+            contract(cx, 1.0, Cm, "sl", Ta, "rlP", 0.0, Tb, "rsP");      // mp2.f90:375-385
+            k_pack_pairs(cx, packed, Tb.d, (int)n);                      // mp2.f90:388-410
+        } else {
+            // Large bases: slab by slab.  The first pair of transforms acts on every (kl) pair separately and the second on every
+            // (pq) pair, so only the half-transformed integrals have to exist as a whole -- pair-packed, g(PQ,K), np^2 doubles
+            // (4.7 GB at n = 220) -- and the n^2 npair temporaries (2 x 9.4 GB) shrink to two slabs of S pairs.  S is chosen so
+            // that a slab's column tiles fill whole rounds of the persistent GEMM grid.
+            int64_t S = std::max<int64_t>(16, ((int64_t)256 * 128 * 14 / n) / 16 * 16);
+            if (S > np) S = (np + 15) / 16 * 16;
+            double* g = cx.scratch("ao2mo_g", np * np);
+            double* sa = have_u ? nullptr : cx.scratch("ao2mo_a", n * n * S);   // (with (ij|KL) left by the Fock build: its slabs, in place)
+            double* sb = cx.scratch("ao2mo_b", n * n * S);
+            double* u = have_u ? cx.scratch("ao2mo_a", n * n * np) : nullptr;
+            ctx->half_n = 0;                                             // the transform overwrites it
+            for (int64_t k0 = 0; k0 < np; k0 += S) {
+                const int64_t k1 = std::min(np, k0 + S), len = k1 - k0;
+                double* a_s = have_u ? u + n * n * k0 : sa;
+                if (!have_u) k_unpack_half(cx, a_s, ao, (int)n, k0, k1);                     // (ij|K), ij squared up, K in the slab
+                Tensor Ta = view(a_s, {n, n, len}), Tb = view(sb, {n, n, len});
+                contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");                      // mp2.f90:321-333
+                contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");                      // mp2.f90:338-348
+                k_tri_pack(cx, g, a_s, (int)n, k0, k1);                                      // g(PQ,K), p >= q
+            }
+            if (have_u) { sa = u; }                                      // (dead now: its first slab serves the second pair)
+            for (int64_t p0 = 0; p0 < np; p0 += S) {
+                const int64_t p1 = std::min(np, p0 + S), len = p1 - p0;
+                k_pair_square_packed(cx, sb, g, (int)n, p0, p1);                             // (kl|P), kl squared up, P in the slab
+                Tensor Ta = view(sa, {n, n, len}), Tb = view(sb, {n, n, len});
+                contract(cx, 1.0, Cm, "rk", Tb, "klP", 0.0, Ta, "rlP");                      // mp2.f90:357-367
+                contract(cx, 1.0, Cm, "sl", Ta, "rlP", 0.0, Tb, "rsP");                      // mp2.f90:375-385
+                k_pack_pairs(cx, packed, sb, (int)n, p0, p1);                                // mp2.f90:388-410
+            }
+        }
         ctx->eri_mo_dev = packed;
         ctx->eri_mo_n = n;
-        k_pack_pairs(cx, packed, Tb.d, (int)n);                      // mp2.f90:388-410
         // MP2 energy on the <ij|ab> slice (mp2.f90:418-440)
         Tensor voovv = view(cx.scratch("ao2mo_v", o * o * v * v), {o, o, v, v}), D1 = view(cx.scratch("ao2mo_d1", o * v), {o, v}),
                D2 = view(cx.scratch("ao2mo_d2", o * o * v * v), {o, o, v, v});

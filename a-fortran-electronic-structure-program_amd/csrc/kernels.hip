@@ -556,8 +556,11 @@ void k_lincomb(Context& cx, double* out, const double* xbase, int64_t xstride, c
 // and the writes (16 consecutive x) are 128-byte runs; the tile and its mirror image (x and y exchanged) come from one read.
 //   MODE 0  unpack_half:     out(i,j,KL) = packed[tri(tri(i,j), KL)]          (ij|kl) with ij squared up, for every pair KL
 //   MODE 1  pair_transpose:  out(k,l,PQ) = in(q,p,tri(k,l)), PQ = tri(p,q)    (pq|kl) -> (kl|PQ), kl squared up, p >= q
+//   MODE 2  out(k,l,P) = g(P, tri(k,l)), g a plain [np x np] array         the same from the pair-packed half-transformed integrals
+// The C blocks [c_begin, c_end) of the result are produced (c_begin a multiple of 16), at out(x,y,C - c_begin): the blocked
+// transform of afesp_ao2mo_mp2 works on slabs of C.
 template <int MODE>
-__global__ __launch_bounds__(256) void pair_square_kernel(double* out, const double* src, int n)
+__global__ __launch_bounds__(256) void pair_square_kernel(double* out, const double* src, int n, int64_t c_begin, int64_t c_end)
 {
     constexpr int T = 16, TP = T + 1, SC = T * TP + 3;   // rows padded: the mirrored tile is read out of LDS along y
     __shared__ double tile[T * SC];
@@ -569,14 +572,14 @@ __global__ __launch_bounds__(256) void pair_square_kernel(double* out, const dou
     int yb, xb;
     unpair((int64_t)blockIdx.x % nbp, yb, xb);
     const int x0 = xb * T, y0 = yb * T;
-    const int64_t c0 = cb * T;
+    const int64_t c0 = c_begin + cb * T;
     // which tile direction is contiguous in src: C (dir 0) or y (dir 1: the whole tile lies in rows C of the packed triangle,
     // where the members x >= y of a pair run along y)
     int dir = 0;
     if (MODE == 0 && tri(min(x0 + T, n) - 1, min(y0 + T, n) - 1) <= c0) dir = 1;
     const int lane = threadIdx.x % T, row = threadIdx.x / T;
     int64_t pq_off = 0;
-    if (MODE == 1 && c0 + lane < np) {
+    if (MODE == 1 && c0 + lane < c_end) {
         int q, p;
         unpair(c0 + lane, q, p);
         pq_off = q + N * p;
@@ -585,16 +588,18 @@ __global__ __launch_bounds__(256) void pair_square_kernel(double* out, const dou
     for (int it = 0; it < T; ++it) {
         const int c = dir == 0 ? lane : row, yi = dir == 0 ? it : lane, xi = dir == 0 ? row : it;
         const int X = x0 + xi, Y = y0 + yi;
-        if (X < n && Y < n && c0 + c < np)
-            tile[c * SC + yi * TP + xi] = MODE == 0 ? src[tri(tri(X, Y), c0 + c)] : src[pq_off + N * N * tri(X, Y)];
+        if (X < n && Y < n && c0 + c < c_end)
+            tile[c * SC + yi * TP + xi] = MODE == 0 ? src[tri(tri(X, Y), c0 + c)]
+                                        : MODE == 1 ? src[pq_off + N * N * tri(X, Y)] : src[(c0 + c) + np * tri(X, Y)];
     }
     __syncthreads();
+    const int64_t cr = c0 - c_begin;   // position of the block in the slab
     {
         const int X = x0 + lane, Y = y0 + row;          // out(x,y,C): lanes along x
         if (X < n && Y < n) {
 #pragma unroll 4
             for (int c = 0; c < T; ++c)
-                if (c0 + c < np) out[X + N * Y + N * N * (c0 + c)] = tile[c * SC + row * TP + lane];
+                if (c0 + c < c_end) out[X + N * Y + N * N * (cr + c)] = tile[c * SC + row * TP + lane];
         }
     }
     if (xb != yb) {
@@ -602,40 +607,67 @@ __global__ __launch_bounds__(256) void pair_square_kernel(double* out, const dou
         if (X < n && Y < n) {
 #pragma unroll 4
             for (int c = 0; c < T; ++c)
-                if (c0 + c < np) out[X + N * Y + N * N * (c0 + c)] = tile[c * SC + lane * TP + row];
+                if (c0 + c < c_end) out[X + N * Y + N * N * (cr + c)] = tile[c * SC + lane * TP + row];
         }
     }
 }
-// packed[tri(PQ,RS)] = full(s,r,PQ) for RS = tri(r,s) <= PQ  (mp2.f90:388-410 on the pair-packed result)
-__global__ void pack_pairs_kernel(double* packed, const double* full, int n)
+// packed[tri(PQ,RS)] = full(s,r,PQ - p_begin) for RS = tri(r,s) <= PQ, PQ in [p_begin, p_end)  (mp2.f90:388-410 on the
+// pair-packed result; the whole range in one call, or slab by slab)
+__global__ void pack_pairs_kernel(double* packed, const double* full, int n, int64_t p_begin, int64_t p_end)
 {
-    const int64_t N = n, np = N * (N + 1) / 2, tot = np * np;
+    const int64_t N = n, np = N * (N + 1) / 2, tot = np * (p_end - p_begin);
     GRID_STRIDE(x, tot)
     {
-        const int64_t rs = x % np, pq = x / np;
+        const int64_t rs = x % np, pq = p_begin + x / np;
         if (rs > pq) continue;
         int s_, r_;
         unpair(rs, s_, r_);
-        packed[pq * (pq + 1) / 2 + rs] = full[s_ + N * r_ + N * N * pq];
+        packed[pq * (pq + 1) / 2 + rs] = full[s_ + N * r_ + N * N * (pq - p_begin)];
     }
 }
-static unsigned pair_square_grid(int n)
+// g(PQ, K) = half(q, p, K - k_begin), PQ = tri(p,q) over p >= q, K in [k_begin, k_end): the half-transformed integrals of a slab
+// of (kl) pairs, pair-packed in (pq), into the [np x np] array the second pair of transforms gathers from
+__global__ void tri_pack_kernel(double* g, const double* half, int n, int64_t k_begin, int64_t k_end)
 {
-    const int64_t nb = (n + 15) / 16, np = (int64_t)n * (n + 1) / 2;
-    return (unsigned)(nb * (nb + 1) / 2 * ((np + 15) / 16));
+    const int64_t N = n, np = N * (N + 1) / 2, tot = np * (k_end - k_begin);
+    GRID_STRIDE(x, tot)
+    {
+        const int64_t pq = x % np, k = x / np;
+        int q, p;
+        unpair(pq, q, p);
+        g[pq + np * (k_begin + k)] = half[q + N * p + N * N * k];
+    }
 }
-void k_unpack_half(Context& cx, double* u, const double* packed, int n)
+static unsigned pair_square_grid(int n, int64_t c_begin, int64_t c_end)
 {
-    LAUNCH(pair_square_kernel<0>, dim3(pair_square_grid(n)), u, packed, n);
+    const int64_t nb = (n + 15) / 16;
+    return (unsigned)(nb * (nb + 1) / 2 * ((c_end - c_begin + 15) / 16));
+}
+void k_unpack_half(Context& cx, double* u, const double* packed, int n, int64_t c_begin, int64_t c_end)
+{
+    const int64_t np = (int64_t)n * (n + 1) / 2;
+    if (c_end < 0) c_end = np;
+    if (c_end > c_begin) LAUNCH(pair_square_kernel<0>, dim3(pair_square_grid(n, c_begin, c_end)), u, packed, n, c_begin, c_end);
 }
 void k_pair_transpose(Context& cx, double* out, const double* in, int n)
 {
-    LAUNCH(pair_square_kernel<1>, dim3(pair_square_grid(n)), out, in, n);
+    const int64_t np = (int64_t)n * (n + 1) / 2;
+    LAUNCH(pair_square_kernel<1>, dim3(pair_square_grid(n, 0, np)), out, in, n, (int64_t)0, np);
 }
-void k_pack_pairs(Context& cx, double* packed, const double* full, int n)
+void k_pair_square_packed(Context& cx, double* out, const double* g, int n, int64_t c_begin, int64_t c_end)
 {
-    int64_t np = (int64_t)n * (n + 1) / 2;
-    LAUNCH(pack_pairs_kernel, dim3(grid_for(np * np, 65536)), packed, full, n);
+    if (c_end > c_begin) LAUNCH(pair_square_kernel<2>, dim3(pair_square_grid(n, c_begin, c_end)), out, g, n, c_begin, c_end);
+}
+void k_tri_pack(Context& cx, double* g, const double* half, int n, int64_t k_begin, int64_t k_end)
+{
+    const int64_t np = (int64_t)n * (n + 1) / 2;
+    if (k_end > k_begin) LAUNCH(tri_pack_kernel, dim3(grid_for(np * (k_end - k_begin), 65536)), g, half, n, k_begin, k_end);
+}
+void k_pack_pairs(Context& cx, double* packed, const double* full, int n, int64_t p_begin, int64_t p_end)
+{
+    const int64_t np = (int64_t)n * (n + 1) / 2;
+    if (p_end < 0) p_end = np;
+    if (p_end > p_begin) LAUNCH(pack_pairs_kernel, dim3(grid_for(np * (p_end - p_begin), 65536)), packed, full, n, p_begin, p_end);
 }
 void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1, int d2, int d3, int b0, int b1, int b2, int b3)
 {

@@ -151,11 +151,15 @@ def test_pp_ladder_split_form_on_ragged_extents(eng, o, v, monkeypatch):
     assert np.max(np.abs(h2 - g2)) < 1e-13
 
 
+@pytest.mark.parametrize("blocked", ["0", "1"])
 @pytest.mark.parametrize("n,o", [(2, 1), (3, 2), (7, 3), (13, 4), (24, 5), (33, 16), (58, 5)])
-def test_ao2mo_pair_symmetric_transform(eng, n, o):
+def test_ao2mo_pair_symmetric_transform(eng, n, o, blocked, monkeypatch):
     """AO->MO over the unique pairs (kl), then (pq): every packed MO integral and E(MP2) against the restatement of the four
-    quarter transforms (src/mp2.f90:321-410), with a general (non-orthogonal) coefficient matrix and odd extents."""
+    quarter transforms (src/mp2.f90:321-410), with a general (non-orthogonal) coefficient matrix and odd extents -- the whole
+    tensor at once (what small bases run) and slab by slab through the pair-packed half-transformed array (what large bases
+    run; forced here), the latter also starting from the (ij|KL) copy a Fock build leaves on the device."""
     from afesp_amd import inputs
+    monkeypatch.setenv("AFESP_AO2MO_BLOCKED", blocked)
     rng = np.random.default_rng(100 * n + o)
     eri = rng.standard_normal(inputs.neri(n))
     c = rng.standard_normal((n, n))
@@ -168,6 +172,10 @@ def test_ao2mo_pair_symmetric_transform(eng, n, o):
     eng.set_eri(n, eri)
     e2, again = eng.do_mp2_spatial(n, o, c, e, None)       # AO integrals already resident on the device
     assert np.array_equal(again, eri_mo) and e2 == e_mp2
+    eng.set_eri(n, eri)
+    eng.build_fock(n, np.eye(n), np.zeros((n, n)))          # leaves (ij|KL), ij squared up, as the transform's starting point
+    e3, third = eng.do_mp2_spatial(n, o, c, e, None)
+    assert np.array_equal(third, eri_mo) and e3 == e_mp2
 
 
 @pytest.mark.parametrize("device_from", ["1", "1000000000"])

@@ -145,11 +145,15 @@ def _packed(i, j, k, l):
     return _tri(_tri(i, j), _tri(k, l))          # integrals.f90:196-210, 0-based
 
 
-def test_ao2mo_full_size_with_a_signed_permutation():
-    """n = 220 (config 5): with C a signed permutation matrix every MO integral is one AO integral with a sign,
+@pytest.mark.parametrize("blocked", [None, "1"])
+def test_ao2mo_full_size_with_a_signed_permutation(blocked, monkeypatch):
+    """n = 220 (config 5), the whole tensor at once (what this size runs) and slab by slab (what n >= 256 runs; forced):
+    with C a signed permutation matrix every MO integral is one AO integral with a sign,
     (pq|rs) = s_p s_q s_r s_s (P(p)P(q)|P(r)P(s)) -- exact in floating point, so the pair-squaring, the four quarter transforms over
     unique pairs and the repack are checked element by element (200 000 sampled index quadruples) at the full size."""
     from afesp_amd.capi import Engine
+    if blocked:
+        monkeypatch.setenv("AFESP_AO2MO_BLOCKED", blocked)
     n, o, scale, seed = O + V, O, 0.02, 4242
     rng = np.random.default_rng(17)
     perm = rng.permutation(n)
