@@ -1,0 +1,46 @@
+// tgemm.h -- grouped fp64 GEMM for operands that are both contiguous along the summation index, staged by LDS-DMA.
+//
+// The (T) products of src/ccsd.f90:2168-2173 (csrc/triples.hip, plan_fused) are 85 % of a config-5 step.  Both of their
+// operands -- vt(kappa; b,c,r) and tt(kappa; a,q,p) -- are contiguous along the summation index, every K step of 16 is one
+// 128-byte line per row, and the summation index of a group of columns is at most two contiguous runs (the slab of r, then
+// the transposed slab of q).  That is all this kernel supports, and what it buys over the general gather kernel (gett.h):
+//   * operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers, no ds_write, no address VALU in the
+//     loop: a row is SGPR base + 32-bit VGPR byte offset, the K step moves the SGPR base);
+//   * two independent 4-wave workgroups per CU on 128 x 128 tiles instead of one 8-wave workgroup on 256 x 128: the barrier
+//     skew, the tile epilogue and the DMA waits of one workgroup lie under the other one's MFMAs;
+//   * fragments are read as ds_read_b128 pairs of k (the k order inside a step is remapped identically for A and B).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace afesp {
+
+// One group of columns: its A panel (two runs of the summation index), the shift of its B columns in the second run, its
+// column tables.  Device array of ngroups + 1 entries; the last one only carries tile_start.
+struct TgGroup {
+    int64_t a1, a2;          // element offsets (from TgProblem::A) of the A panel in K steps [0, nk1) and [nk1, nk)
+    int64_t b2;              // element shift of every B column in K steps [nk1, nk)
+    const uint32_t* colB;    // [N] byte offsets of the columns of B (from TgProblem::B)
+    const int64_t* offCn;    // [N] element offsets of the columns of C
+    int N, ntiles, tile_start, nk1, nk;
+    unsigned inv_width;      // tgemm_inverse(tgemm_group_m(M, max_ntiles) * ntiles)
+};
+
+struct TgProblem {
+    const double* A;
+    const double* B;
+    double* C;
+    const uint32_t* rowA;    // [M] byte offsets of the rows of A inside a panel
+    const int64_t* offCm;    // [M] element offsets of the rows of C
+    int M;
+};
+
+constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 16;
+
+// Every group needs nk >= 2 and 1 <= nk1 <= nk; tables as above.  max_ntiles = the largest ntiles of a group.
+hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngroups, int total_tiles, int max_ntiles, hipStream_t stream);
+void preload_tgemm();
+unsigned tgemm_inverse(int d);
+int tgemm_group_m(int M, int max_ntiles);
+
+}  // namespace afesp

@@ -18,11 +18,14 @@
 // path launches its three blocks per slab (plan_for).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <unordered_map>
 
 #include "ccsd.h"
 #include "ccsd_so.h"
+#include "tgemm.h"
 #include "triples_orbit.h"
 
 namespace afesp {
@@ -74,6 +77,7 @@ void preload_triples()
     hipFuncAttributes at;
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_sum_kernel));
     (void)hipGetLastError();
+    preload_tgemm();
 }
 
 // out[q] += sum of partial[q][0..nblk) for q < nq, two stages when there are many partials; `tmp` holds nq * 128 doubles
@@ -207,13 +211,18 @@ struct TriplesPlan {
                    // fused scheme, groups with q == r: Y^{p;qq}(x;y,z) = X(x;y,z) + X(x;z,y), only X is computed (half the
                    // summation length, a launch of its own) and the orbit kernel adds the transpose (TripleMeta::pad)
                    int64_t gdesc_diag_off = 0; int ngroups_diag = 0, total_tiles_diag = 0, max_ntiles_diag = 0, ngroups_off = 0;
-                   int64_t ncol_off = 0, ncol_diag = 0; bool split_diag = false; };
+                   int64_t ncol_off = 0, ncol_diag = 0; bool split_diag = false;
+                   // LDS-DMA kernel (tgemm.h): all groups of the chunk in one launch, the q == r groups with half the K steps
+                   int64_t tg_off = 0, tab32_off = 0; int tg_ngroups = 0, tg_tiles = 0, tg_max_ntiles = 0; };
     std::vector<Chunk> chunks;
     int64_t* tables = nullptr;     // [kappa | Am | Cm | per chunk: offBn, offCn]
     int64_t off_k = 0, off_Am = 0, off_Cm = 0;
     TripleMeta* meta = nullptr;
     int* orbits = nullptr;
     GettGroup* gdesc = nullptr;    // fused scheme: group descriptors of all chunks
+    bool use_tg = false;           // fused scheme: the products run on tgemm_kernel (tgemm.h) instead of the grouped gett_kernel
+    TgGroup* tgdesc = nullptr;
+    uint32_t* tables32 = nullptr;  // [rowA (v^2) | per chunk: colB]  byte offsets
     double* pool0 = nullptr;       // fused scheme, not completely renormalised: base the block offsets refer to (assemble_pool)
 };
 
@@ -416,18 +425,33 @@ static int64_t device_pool_budget()
     return std::min<int64_t>((int64_t)64 << 30, (int64_t)(mem_total / 4));
 }
 
+// Which kernel runs the fused products: the LDS-DMA kernel (tgemm.h) whenever its 32-bit byte offsets reach every row of vt
+// and every column of tt; AFESP_T_GEMM=gett forces the grouped gather kernel (A/B runs, tests of both).
+static bool fused_use_tg(int o, int v)
+{
+    const char* e = getenv("AFESP_T_GEMM");
+    if (e && !strcmp(e, "gett")) return false;
+    const int64_t O = o, V = v, Kc = (V + O + 15) / 16 * 16;
+    return 8 * Kc * V * V < ((int64_t)1 << 32) && 8 * Kc * V * O * O < ((int64_t)1 << 32);
+}
+
 static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end, bool cr)
 {
     TriplesPlan* p = (TriplesPlan*)slot;
+    const bool use_tg = fused_use_tg(o, v);
     if (p && p->o == o && p->v == v && p->t_begin == t_begin && p->t_end == t_end && p->cr == cr && p->mode == 0 &&
-        p->epoch == cx.scratch_epoch)
+        p->epoch == cx.scratch_epoch && p->use_tg == use_tg)
         return p;
     delete p;
     p = new TriplesPlan();
     slot = p;
     const int64_t O = o, V = v, v2 = V * V, Kc = (V + O + 15) / 16 * 16;
     const int64_t nt8 = (V + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;
-    p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = cr; p->mode = 0;
+    p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = cr; p->mode = 0; p->use_tg = use_tg;
+    const int nk1 = (int)(Kc / TG_BK);
+    std::vector<uint32_t> tab32;
+    if (use_tg)
+        for (int64_t m = 0; m < v2; ++m) tab32.push_back((uint32_t)(8 * Kc * m));   // rows (b,c) of vt / vtT, bytes
     const int sb = fused_block_size(o, v, cr, device_pool_budget());
     p->sblock = sb;
     const int nbk = (o + sb - 1) / sb;
@@ -542,9 +566,16 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
                 for (const TriplesPlan::Group& g : ch.groups)
                     if (g.q == g.r) diag_tiles += mtiles * ((g.N + BN - 1) / BN);
                 ch.split_diag = diag_tiles >= split_min_tiles;
+                // (the LDS-DMA kernel takes a K-step count per group: the q == r groups always run over half the summation
+                // index, in the same launch -- unless that would be a single step, which its pipeline does not take)
+                if (use_tg) ch.split_diag = nk1 >= 2;
                 if (!ch.split_diag)
                     for (int t = 0; t < ch.nt; ++t) metas[ch.meta_off + t].pad = 0;
                 ch.ntab = (int64_t)hBn.size();
+                if (use_tg) {
+                    ch.tab32_off = (int64_t)tab32.size();
+                    for (int64_t x : hBn) tab32.push_back((uint32_t)(8 * x));
+                }
                 ch.tab_off = (int64_t)tab.size();
                 tab.insert(tab.end(), hBn.begin(), hBn.end());
                 tab.insert(tab.end(), hCn.begin(), hCn.end());
@@ -602,6 +633,45 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
     }
     p->gdesc = (GettGroup*)cx.scratch("t_gdesc", (int64_t)(gd.size() * sizeof(GettGroup) / sizeof(double) + 1));
     AFESP_HIP(hipMemcpyAsync(p->gdesc, gd.data(), gd.size() * sizeof(GettGroup), hipMemcpyHostToDevice, cx.stream));
+    std::vector<TgGroup> tg;
+    if (use_tg) {
+        p->tables32 = (uint32_t*)cx.scratch("t_tables32", (int64_t)(tab32.size() / 2 + 1));
+        AFESP_HIP(hipMemcpyAsync(p->tables32, tab32.data(), tab32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, cx.stream));
+        const int mt = (int)((v2 + TG_BM - 1) / TG_BM);
+        for (TriplesPlan::Chunk& ch : p->chunks) {
+            const int64_t* tabs = p->tables + ch.tab_off;
+            ch.tg_off = (int64_t)tg.size();
+            int mx = 0;
+            for (const TriplesPlan::Group& g : ch.groups) mx = std::max(mx, (int)((g.N + TG_BN - 1) / TG_BN));
+            const int gm = tgemm_group_m((int)v2, mx);
+            int tile = 0;
+            for (const TriplesPlan::Group& g : ch.groups) {
+                TgGroup d;
+                d.a1 = Kc * v2 * g.r;                   // vt(:, ., ., r)
+                d.a2 = Kc * v2 * O + Kc * v2 * g.q;     // vtT(:, ., ., q)
+                d.b2 = Kc * V * ((int64_t)g.r - g.q);   // tt(:, x, r, p) instead of tt(:, x, q, p)
+                d.colB = p->tables32 + ch.tab32_off + g.start;
+                d.offCn = tabs + ch.ntab + g.start;
+                d.N = (int)g.N;
+                d.ntiles = (int)((g.N + TG_BN - 1) / TG_BN);
+                d.tile_start = tile;
+                d.nk1 = nk1;
+                d.nk = (ch.split_diag && g.q == g.r) ? nk1 : 2 * nk1;
+                d.inv_width = tgemm_inverse(gm * d.ntiles);
+                if ((int64_t)mt * d.ntiles * gm * d.ntiles >= ((int64_t)1 << 32)) throw Error(2, "triples plan: tile walk out of range");
+                tile += mt * d.ntiles;
+                tg.push_back(d);
+            }
+            TgGroup end{};
+            end.tile_start = tile;
+            tg.push_back(end);
+            ch.tg_ngroups = (int)ch.groups.size();
+            ch.tg_tiles = tile;
+            ch.tg_max_ntiles = mx;
+        }
+        p->tgdesc = (TgGroup*)cx.scratch("t_tgdesc", (int64_t)(tg.size() * sizeof(TgGroup) / sizeof(double) + 1));
+        AFESP_HIP(hipMemcpyAsync(p->tgdesc, tg.data(), tg.size() * sizeof(TgGroup), hipMemcpyHostToDevice, cx.stream));
+    }
     cx.sync();   // the host vectors die here
     p->epoch = cx.scratch_epoch;
     return p;
@@ -711,6 +781,8 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     t_begin = std::max<int64_t>(0, t_begin);
     t_end = std::min<int64_t>(triples_count(o), t_end);
     TriplesPlan* p = plan_fused(cx, s.tplan, s.o, s.v, t_begin, t_end, cr);
+    if (getenv("AFESP_T_DEBUG"))
+        fprintf(stderr, "afesp (T): o %d v %d block %d chunks %zu kernel %s\n", o, v, p->sblock, p->chunks.size(), p->use_tg ? "tgemm" : "gett");
     // concatenated operands, summed index kappa = [d ; l] first (the reference also moves the summed index first, :2056-2066)
     //   vt(kappa,b,c,k): kappa<v: <cb|kd> = v_vvov(c,b,k,d);  kappa=v+l: t2(l,k,b,c)
     //   tt(kappa,a,j,i): kappa<v: t2(i,j,a,d);                kappa=v+l: -<ij|al> = -v_oovo(i,j,a,l)
@@ -796,6 +868,14 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             gm.A = vt2.d;
             gm.B = tt2.d;
             gm.C = Mpool;
+            if (p->use_tg) {
+                TgProblem tp{vt.d, tt.d, Xpool, p->tables32, p->tables + p->off_Cm, (int)v2};
+                AFESP_HIP(tgemm_launch(tp, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream));
+                if (cr) {
+                    TgProblem tm{vt2.d, tt2.d, Mpool, p->tables32, p->tables + p->off_Cm, (int)v2};
+                    AFESP_HIP(tgemm_launch(tm, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream));
+                }
+            } else {
             if (ch.ngroups_off > 0) {
                 const GettGroup* gd = p->gdesc + ch.gdesc_off;
                 AFESP_HIP(gett_launch_grouped(gp, gd, ch.ngroups_off, ch.total_tiles, ch.max_ntiles, cx.stream));
@@ -807,8 +887,9 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
                 AFESP_HIP(gett_launch_grouped(gp, gd, ch.ngroups_diag, ch.total_tiles_diag, ch.max_ntiles_diag, cx.stream));
                 if (cr) AFESP_HIP(gett_launch_grouped(gm, gd, ch.ngroups_diag, ch.total_tiles_diag, ch.max_ntiles_diag, cx.stream));
             }
+            }
             if (cx.prof) {
-                cx.prof_gemm_launches += (ch.ngroups_off > 0) + (ch.ngroups_diag > 0);
+                cx.prof_gemm_launches += p->use_tg ? 1 : (ch.ngroups_off > 0) + (ch.ngroups_diag > 0);
                 cx.prof_gemm_flop += 2.0 * (double)gp.M * (double)(2 * ch.ncol_off + ch.ncol_diag) * (double)(V + O);
             }
         }

@@ -1,0 +1,78 @@
+// tgemm_check.hip -- tgemm_kernel on a small random grouped problem against a host loop (diagnostic).
+// build: hipcc -O2 --offload-arch=gfx950 tools/tgemm_check.hip -o tools/tgemm_check_bin     usage: tgemm_check_bin [M Kc N0 N1]
+#include "../a-fortran-electronic-structure-program_amd/csrc/tgemm.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace afesp;
+int main(int argc, char** argv)
+{
+    const int M = argc > 1 ? atoi(argv[1]) : 300, Kc = argc > 2 ? atoi(argv[2]) : 48;
+    const int Ns[2] = {argc > 3 ? atoi(argv[3]) : 200, argc > 4 ? atoi(argv[4]) : 70};
+    const int nk1 = Kc / 16, ncol = Ns[0] + Ns[1];
+    std::vector<double> A((size_t)2 * M * Kc), B((size_t)2 * ncol * Kc), C((size_t)M * ncol, -7.0), R((size_t)M * ncol, 0.0);
+    srand(3);
+    for (auto& x : A) x = (rand() % 2001 - 1000) / 1000.0;
+    for (auto& x : B) x = (rand() % 2001 - 1000) / 1000.0;
+    std::vector<uint32_t> rowA(M), colB(ncol);
+    std::vector<int64_t> offCm(M), offCn(ncol);
+    for (int m = 0; m < M; ++m) { rowA[m] = (uint32_t)(8 * Kc * m); offCm[m] = m; }
+    for (int n = 0; n < ncol; ++n) { colB[n] = (uint32_t)(8 * Kc * ((n * 7) % ncol)); offCn[n] = (int64_t)M * n; }   // 7 coprime to ncol assumed
+    const int mt = (M + 127) / 128;
+    uint32_t* d32; int64_t* d64; double *dA, *dB, *dC; TgGroup* dg;
+    hipMalloc(&d32, (M + ncol) * 4); hipMalloc(&d64, (M + ncol) * 8);
+    hipMalloc(&dA, A.size() * 8); hipMalloc(&dB, B.size() * 8); hipMalloc(&dC, C.size() * 8); hipMalloc(&dg, 3 * sizeof(TgGroup));
+    hipMemcpy(d32, rowA.data(), M * 4, hipMemcpyHostToDevice); hipMemcpy(d32 + M, colB.data(), ncol * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d64, offCm.data(), M * 8, hipMemcpyHostToDevice); hipMemcpy(d64 + M, offCn.data(), ncol * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dC, C.data(), C.size() * 8, hipMemcpyHostToDevice);
+    TgGroup g[3] = {};
+    int mx = 0, tile = 0;
+    for (int q = 0; q < 2; ++q) mx = std::max(mx, (Ns[q] + 127) / 128);
+    const int gm = tgemm_group_m(M, mx);
+    for (int q = 0; q < 2; ++q) {
+        g[q].a1 = 0; g[q].a2 = (int64_t)M * Kc; g[q].b2 = (int64_t)ncol * Kc;
+        g[q].colB = d32 + M + (q ? Ns[0] : 0); g[q].offCn = d64 + M + (q ? Ns[0] : 0);
+        g[q].N = Ns[q]; g[q].ntiles = (Ns[q] + 127) / 128; g[q].tile_start = tile; g[q].nk1 = nk1; g[q].nk = q ? (nk1 >= 2 ? nk1 : 2 * nk1) : 2 * nk1;
+        g[q].inv_width = tgemm_inverse(gm * g[q].ntiles);
+        tile += mt * g[q].ntiles;
+    }
+    g[2].tile_start = tile;
+    hipMemcpy(dg, g, sizeof(g), hipMemcpyHostToDevice);
+    TgProblem p{dA, dB, dC, d32, d64, M};
+    hipError_t e = tgemm_launch(p, dg, 2, tile, mx, 0);
+    hipError_t e2 = hipDeviceSynchronize();
+    printf("launch %s sync %s tiles %d gm %d\n", hipGetErrorString(e), hipGetErrorString(e2), tile, gm);
+    hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost);
+    for (int q = 0, n0 = 0; q < 2; n0 += Ns[q], ++q)
+        for (int n = n0; n < n0 + Ns[q]; ++n)
+            for (int m = 0; m < M; ++m) {
+                double s = 0.0;
+                const double* b1 = B.data() + colB[n] / 8;
+                for (int k = 0; k < Kc; ++k) s += A[(size_t)m * Kc + k] * b1[k];
+                if (g[q].nk == 2 * nk1)
+                    for (int k = 0; k < Kc; ++k) s += A[(size_t)M * Kc + (size_t)m * Kc + k] * b1[(size_t)ncol * Kc + k];
+                R[(size_t)m + (size_t)M * n] = s;
+            }
+    double mxe = 0.0; long bad = 0, untouched = 0;
+    for (size_t i = 0; i < C.size(); ++i) { double d = fabs(C[i] - R[i]); if (d > mxe) mxe = d; if (d > 1e-10) ++bad; if (C[i] == -7.0) ++untouched; }
+    printf("max err %.3e, bad %ld of %zu, untouched %ld\n", mxe, bad, C.size(), untouched);
+    if (bad) {
+        printf("16x16 sub-block map (rows m/16, cols n/16): '.' ok, 'x' wrong, 'u' untouched\n");
+        for (int mb = 0; mb < (M + 15) / 16; ++mb) {
+            for (int nb = 0; nb < (ncol + 15) / 16; ++nb) {
+                int w = 0, u = 0;
+                for (int m = mb * 16; m < std::min(M, mb * 16 + 16); ++m)
+                    for (int n = nb * 16; n < std::min(ncol, nb * 16 + 16); ++n) {
+                        size_t i = (size_t)m + (size_t)M * n;
+                        if (C[i] == -7.0) ++u; else if (fabs(C[i] - R[i]) > 1e-10) ++w;
+                    }
+                putchar(u ? 'u' : w ? 'x' : '.');
+            }
+            putchar('\n');
+        }
+        int shown = 0;
+        for (size_t i = 0; i < C.size() && shown < 8; ++i) if (fabs(C[i] - R[i]) > 1e-10) { printf("  C[%zu] (m %zu n %zu) = %.6f ref %.6f\n", i, i % M, i / M, C[i], R[i]); ++shown; }
+    }
+    return bad ? 1 : 0;
+}
