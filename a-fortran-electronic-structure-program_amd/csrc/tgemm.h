@@ -38,6 +38,8 @@ struct TgProblem {
 constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 16;
 
 // Every group needs nk >= 2 and 1 <= nk1 <= nk; tables as above.  max_ntiles = the largest ntiles of a group.
+// The kernel fetches a tile's tables in 1-KiB pieces: rowA and every colB must be readable up to 255 entries, offCm and every
+// offCn up to 127 entries beyond their last element (pad the buffers; what is read there is never used).
 hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngroups, int total_tiles, int max_ntiles, hipStream_t stream);
 void preload_tgemm();
 unsigned tgemm_inverse(int d);

@@ -4,23 +4,25 @@
 // f64 MFMA issues every 64 cycles with VGPR accumulators and every 138 with AGPR ones, so the bound of two waves per SIMD --
 // 256 registers -- is also what keeps hipcc from moving them).  Two workgroups per CU: each SIMD holds one wave of each.
 //
-// LDS: two stages of [A image 16 KiB | B image 16 KiB], then two slots of C offsets (128 row + 128 column int64 each).
+// LDS: two stages of [A image 16 KiB | B image 16 KiB], then two slots of a tile's tables (C row / column offsets, A row /
+// B column byte offsets), which arrive by LDS-DMA as well.
 //   image row = one row (column) of the operand, 16 doubles = 128 B = eight 16-byte chunks; chunk c of row r is stored at
 //   chunk position c ^ ((r >> 1) & 7): a wave-wide ds_read_b128 of one chunk column of 16 rows is then bank-conflict free.
-//   A global_load_lds_dwordx4 writes 1 KiB = 8 image rows, lane l -> row l >> 3, position l & 7; the swizzle is applied to
-//   the SOURCE address (lane l fetches chunk (l & 7) ^ swizzle(row)).
+//   A global_load_lds_dwordx4 writes 1 KiB = 8 image rows, lane l -> row l >> 3, position l & 7 (LDS address = M0 +
+//   instruction offset + 16 l, M0 any LDS byte address: tools/glds_probe.hip); the swizzle is applied to the SOURCE address
+//   (lane l fetches chunk (l & 7) ^ swizzle(row)).
 // Fragments: lane (m = l & 15, f = l >> 4) reads chunk f + 4h of its row in half h = 0, 1 of a step: two consecutive k.  The
 // first doubles of the four f feed one MFMA (k = 2(f + 4h)), the second doubles the next (k + 1); A and B use the same map, so
 // every k of the step is summed exactly once.
 //
 // One stream step (stage `cur` holds this step's data, F0 its first-half fragments):
-//     read F1(cur) | 32 MFMA on F0 | s_waitcnt vmcnt(0) lgkmcnt(0), s_barrier | read F0(cur^1) of the next step |
-//     DMA of step + 2 into stage cur | 32 MFMA on F1 | (last step of a tile: store C, clear the accumulators)
+//     32 MFMA on F0, F1(cur) requested in their first gaps | s_waitcnt vmcnt(0) lgkmcnt(0), s_barrier |
+//     32 MFMA on F1, in their gaps: F0(cur^1) of the next step requested, the DMA of step + 2 into stage cur issued |
+//     (last step of a tile: store C, clear the accumulators)
 // The barrier in the middle of the step says: every wave has its fragments of stage `cur` in registers (the stage may be
 // overwritten) and every wave's DMA of the next step has landed (it was issued one whole step earlier).
-// All vector-memory instructions of the loop are issued and waited for by hand (asm), so hipcc's own wait insertion never
-// sees a transfer in flight; the tables of the next tile are ordinary loads issued right after a DMA batch and first used
-// right after the following barrier's vmcnt(0).
+// All vector-memory loads of the kernel are LDS-DMA transfers issued and waited for by hand (asm) -- the tables of the next
+// tile too -- so hipcc's own wait insertion never sees one in flight and never drains the queue.
 #include "tgemm.h"
 
 #include <algorithm>
@@ -33,31 +35,29 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int TG_STAGE = 32768;             // bytes per stage
 constexpr int TG_BIMG = 16384;              // B image inside a stage
-constexpr int TG_SIDE = 2 * TG_STAGE;       // C-offset slots
-constexpr int TG_LDS = TG_SIDE + 2 * 2048;
-// marks a row / column beyond M / N in the C-offset slots (a valid offset may well be negative: the (T) block pool is pieces of
-// memory addressed relative to the first one)
-constexpr int64_t TG_NONE = INT64_MIN;
+constexpr int TG_SIDE = 2 * TG_STAGE;       // table slots of the tile being fetched / computed, 4 KiB each:
+constexpr int TG_SLOT = 4096;               //   [C row offsets 128 x int64 | C column offsets 128 x int64 | rowA 256 x u32 | colB 256 x u32]
+constexpr int TG_LDS = TG_SIDE + 2 * TG_SLOT;
 
 struct TgArgs {
     TgProblem p;
     const TgGroup* groups;
     int mtiles, gm, total_tiles;
     unsigned inv_gm, inv_gl;   // reciprocals (tgemm_inverse) of gm and of the size of the last, partial group of m-tiles
-    int dbg;                   // measurement only (AFESP_TG_DBG): 1 no C stores, 2 no DMA after the prologue, 4 no vmcnt wait at the barrier
+    int dbg;                   // measurement only (AFESP_TG_DBG): 1 no C stores
 };
+
+#ifdef TG_STAMPS
+// Diagnostic builds only (tools/tgemm_check.hip -DTG_STAMPS): per (workgroup, wave) cycle sums -- [0] the whole stream, [1] the
+// step barriers (wait + barrier), [2] the tile epilogues, [3] steps, [4] tiles, [5] the longest single barrier
+__device__ unsigned long long g_tg_stamp[512 * 4 * 8];
+#endif
 
 __device__ __forceinline__ int tg_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ int64_t tg_uni64(int64_t x)
 {
     const int lo = __builtin_amdgcn_readfirstlane((int)x), hi = __builtin_amdgcn_readfirstlane((int)(x >> 32));
     return ((int64_t)hi << 32) | (unsigned)lo;
-}
-template <typename T>
-__device__ __forceinline__ const T* tg_uniptr(const T* p)
-{
-    typedef const T __attribute__((address_space(1)))* gptr;
-    return (const T*)reinterpret_cast<gptr>(tg_uni64(reinterpret_cast<int64_t>(p)));
 }
 __device__ __forceinline__ int tg_xcd_remap(int b, int nwg)
 {
@@ -87,9 +87,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         while (tile >= G[cursor + 1].tile_start) ++cursor;
         tile -= G[cursor].tile_start;
         const int nt = G[cursor].ntiles;
-        // (divisions by multiplication with reciprocals made on the host: scalar instructions only -- a division by a run-time
-        // number goes through the vector unit, and a vector register it overwrites may still be the target of a table load,
-        // which would put a vmcnt(0) behind the DMA batch just issued)
+        // (divisions by multiplication with reciprocals made on the host: scalar instructions only)
         const unsigned iw = G[cursor].inv_width;
         const int width = a.gm * nt, grp = iw ? (int)__umulhi((unsigned)tile, iw) : tile, first = grp * a.gm;
         const int gsz = min(a.mtiles - first, a.gm), rem = tile - grp * width;
@@ -103,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     const int drow = 32 * wave + (lane >> 3);                                   // + 8 q
     const unsigned dch0 = (unsigned)(((lane & 7) ^ (lane >> 4)) * 16);          // q even
     const unsigned dch1 = (unsigned)(((lane & 7) ^ (4 + (lane >> 4))) * 16);    // q odd
+    const unsigned lane4 = (unsigned)(lane * 4);
     // ---- fragment lanes
     const int fm = lane & 15, ff = lane >> 4, fs = fm >> 1;
     unsigned rdA0 = (unsigned)((wm * 64 + fm) * 128 + ((ff ^ fs) & 7) * 16);
@@ -112,16 +111,15 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
 
     // ---- fetch cursor (two steps ahead of the MFMAs) and the tile entered but not yet committed
     int fj = 0, fkt = 0, fnk = 0, fnk1 = 0;
+    int fmrem = 0, fnrem = 0;   // rows / columns of C from the tile's origin to M / N
     const char *fa1 = nullptr, *fa2 = nullptr, *fb1 = nullptr, *fb2 = nullptr;
-    bool ffull = false;
     unsigned voffA[4], voffB[4];
-    int pnk = 0, pnk1 = 0;
+    int pnk = 0, pnk1 = 0, pmrem = 0, pnrem = 0;
     const char *pa1 = nullptr, *pa2 = nullptr, *pb1 = nullptr, *pb2 = nullptr;
-    bool pfull = false, pending = false;
-    unsigned nvA[4], nvB[4];
-    int64_t nc = 0;
-    bool nc_valid = false;
+    bool pending = false;
 
+    // A tile is entered one step before its first transfer: its group's scalars are read (scalar loads) and its four tables go
+    // to table slot j & 1, one per wave, 1 KiB each (the row tables are read 128 entries beyond the tile: the host pads them).
     auto enter_tile = [&](int j) {
         int m0, n0;
         origin(j, m0, n0);
@@ -133,71 +131,61 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         pa2 = (const char*)(p.A + g->a2);
         pb1 = (const char*)p.B;
         pb2 = (const char*)(p.B + g->b2);
-        pfull = (m0 + TG_BM <= p.M) && (n0 + TG_BN <= N);
-        typedef const uint32_t __attribute__((address_space(1)))* u32g;
-        typedef const int64_t __attribute__((address_space(1)))* i64g;
-        const uint32_t* colB = (const uint32_t*)(u32g)(uintptr_t)g->colB;
-        const int64_t* offCn = (const int64_t*)(i64g)(uintptr_t)g->offCn;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int m = m0 + drow + 8 * q, n = n0 + drow + 8 * q;
-            nvA[q] = p.rowA[m < p.M ? m : p.M - 1];
-            nvB[q] = colB[n < N ? n : N - 1];
-        }
-        // (validity is applied when the value is used, so that nothing here waits for a load)
-        {
-            const int m = m0 + t, n = n0 + t - 128;
-            const int64_t* src = t < 128 ? p.offCm + (m < p.M ? m : p.M - 1) : offCn + (n < N ? n : N - 1);
-            nc = *src;
-            nc_valid = t < 128 ? m < p.M : n < N;
-        }
+        pmrem = p.M - m0;
+        pnrem = N - n0;
+        const char* src = wave == 0   ? (const char*)(p.offCm + m0)
+                          : wave == 1 ? (const char*)((const int64_t*)(uintptr_t)g->offCn + n0)
+                          : wave == 2 ? (const char*)(p.rowA + m0)
+                                      : (const char*)((const uint32_t*)(uintptr_t)g->colB + n0);
+        src = (const char*)tg_uni64((int64_t)src);
+        const unsigned dst = (unsigned)tg_uni((int)(lds0 + (unsigned)(TG_SIDE + (j & 1) * TG_SLOT + wave * 1024)));
+        // (the instruction offset moves the source and the LDS address alike; s_nop 4: a scalar register fresh from a
+        // readfirstlane must not be read by a vector-memory instruction in the next five states)
+        asm volatile("s_nop 4\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %[v], %[p]\n\tglobal_load_lds_dword %[v], %[p] offset:256\n\t"
+                     "global_load_lds_dword %[v], %[p] offset:512\n\tglobal_load_lds_dword %[v], %[p] offset:768"
+                     :
+                     : [v] "v"(lane4), [p] "s"(src), [d] "s"(dst)
+                     : "memory");
         pending = true;
     };
+    // ... and committed after the next barrier (its tables are in LDS): row / column byte offsets of this thread's transfers
     auto commit_tile = [&](int j) {
-        // (every asm below is ordered after the barrier statement: the loads above are first needed here)
+        const unsigned* sr = reinterpret_cast<const unsigned*>(lds + TG_SIDE + (j & 1) * TG_SLOT + 2048);
+        const int lm = min(TG_BM, pmrem) - 1, ln = min(TG_BN, pnrem) - 1;   // rows / columns beyond M / N fetch the last valid one
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            asm volatile("" : "+v"(nvA[q]), "+v"(nvB[q]));
-            voffA[q] = nvA[q] + ((q & 1) ? dch1 : dch0);
-            voffB[q] = nvB[q] + ((q & 1) ? dch1 : dch0);
+            const int r = drow + 8 * q;
+            voffA[q] = sr[min(r, lm)] + ((q & 1) ? dch1 : dch0);
+            voffB[q] = sr[256 + min(r, ln)] + ((q & 1) ? dch1 : dch0);
         }
-        asm volatile("" : "+v"(nc));
-        *reinterpret_cast<int64_t*>(lds + TG_SIDE + (j & 1) * 2048 + t * 8) = nc_valid ? nc : TG_NONE;
-        fnk = pnk; fnk1 = pnk1; fa1 = pa1; fa2 = pa2; fb1 = pb1; fb2 = pb2; ffull = pfull;
+        fnk = pnk; fnk1 = pnk1; fa1 = pa1; fa2 = pa2; fb1 = pb1; fb2 = pb2; fmrem = pmrem; fnrem = pnrem;
         pending = false;
     };
-    // eight 1-KiB transfers of this wave: A image rows 32w .. 32w+31, B image rows 32w .. 32w+31 of stage `stage`
-    auto dma = [&](int stage) {
-        // (readfirstlane: the values are uniform, but hipcc is free to compute a select of them in vector registers, and the
-        // asm below needs scalar ones; the s_nop 4 that opens it covers the VALU-write -> VMEM-read hazard of such a register)
+    // The eight 1-KiB transfers of this wave for the cursor's step (A image rows 32w .. 32w+31, then B image rows 32w .. 32w+31 of
+    // the stage) are issued one by one between MFMAs (TG_DMA below); dma_setup computes their scalar operands.
+    // (readfirstlane: the values are uniform, but hipcc is free to compute a select of them in vector registers, and the asm
+    // needs scalar ones; the s_nop 4 that opens the first piece covers the VALU-write -> VMEM-read hazard of such a register)
+    const char *dma_ap = nullptr, *dma_bp = nullptr;
+    unsigned dma_dst = 0;
+    auto dma_setup = [&](int stage) {
         const int k = tg_uni(fkt), k1 = tg_uni(fnk1);
-        const char* ap = (const char*)tg_uni64((int64_t)((k < k1) ? fa1 + (int64_t)k * 128 : fa2 + (int64_t)(k - k1) * 128));
-        const char* bp = (const char*)tg_uni64((int64_t)((k < k1) ? fb1 + (int64_t)k * 128 : fb2 + (int64_t)(k - k1) * 128));
-        const unsigned dst = (unsigned)tg_uni((int)(lds0 + (unsigned)(stage * TG_STAGE + wave * 4096)));
-        asm volatile(
-            "s_nop 4\n\t"
-            "s_mov_b32 m0, %[d]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a0], %[ap]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a1], %[ap]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a2], %[ap]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[a3], %[ap]\n\t"
-            "s_add_u32 m0, m0, 0x3400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[b0], %[bp]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[b1], %[bp]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[b2], %[bp]\n\t"
-            "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[b3], %[bp]"
-            :
-            : [a0] "v"(voffA[0]), [a1] "v"(voffA[1]), [a2] "v"(voffA[2]), [a3] "v"(voffA[3]), [b0] "v"(voffB[0]),
-              [b1] "v"(voffB[1]), [b2] "v"(voffB[2]), [b3] "v"(voffB[3]), [ap] "s"(ap), [bp] "s"(bp), [d] "s"(dst)
-            : "memory", "scc");
+        dma_ap = (const char*)tg_uni64((int64_t)((k < k1) ? fa1 + (int64_t)k * 128 : fa2 + (int64_t)(k - k1) * 128));
+        dma_bp = (const char*)tg_uni64((int64_t)((k < k1) ? fb1 + (int64_t)k * 128 : fb2 + (int64_t)(k - k1) * 128));
+        dma_dst = (unsigned)tg_uni((int)(lds0 + (unsigned)(stage * TG_STAGE + wave * 4096)));
     };
-    // One fetch step: the DMA batch of the cursor's step into `stage`.  When it is the last step of its tile the next tile is
-    // entered FIRST: its table loads are ordinary loads, and whatever wait hipcc attaches to them (a register it reuses may
-    // still be the target of the previous tile's loads as far as its path-insensitive bookkeeping knows) must not come behind
-    // the batch -- in front of it nothing is in flight, the step's barrier has just drained the queue.
-    int cj_started = 0;   // (0 during the prologue)
-    auto fetch_step = [&](int stage) {
+#define TG_DMA(Q)                                                                                                        \
+    asm volatile("s_nop %c[nop]\n\ts_add_u32 m0, %[d], %[off]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[p]"         \
+                 :                                                                                                       \
+                 : [v] "v"((Q) < 4 ? voffA[(Q) & 3] : voffB[(Q) & 3]), [p] "s"((Q) < 4 ? dma_ap : dma_bp), [d] "s"(dma_dst), \
+                   [off] "i"(((Q) < 4 ? 0 : TG_BIMG) + ((Q) & 3) * 1024), [nop] "i"((Q) == 0 ? 4 : 0)                    \
+                 : "memory", "scc")
+    // The cursor moves on one step.  When the step is the last one of its tile the next tile is entered BEFORE the step's own
+    // transfers are issued (its table transfers are then the older ones; everything is waited for at the step's barrier).
+    auto fetch_begin = [&](int stage) {
         const bool last = fkt + 1 == fnk;
         if (last && fj + 1 < ntl) enter_tile(fj + 1);
-        if (!(a.dbg & 2) || cj_started == 0) dma(stage);
+        dma_setup(stage);
         fkt = last ? 0 : fkt + 1;   // (written as selects: an if/else of increments made hipcc keep the two counters in scratch memory)
         fj += last ? 1 : 0;
     };
@@ -208,27 +196,13 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
     v2d fa0[4], fb0[4], fa1_[4], fb1_[4];
-    auto frag = [&](v2d (&fa)[4], v2d (&fb)[4], unsigned ra, unsigned rb) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v2d*>(lds + ra + i * 2048);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const v2d*>(lds + rb + j * 2048);
-    };
-    auto mfma = [&](const v2d (&fa)[4], const v2d (&fb)[4]) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    };
     // C(m0 + 64 wm + 16 i + (l >> 4) + 4 r, n0 + 64 wn + 16 j + (l & 15)) = acc[i][j][r]; offsets from the tile's slot
-    auto store_tile = [&](int slot, bool full) {
-        const int64_t* sc = reinterpret_cast<const int64_t*>(lds + TG_SIDE + slot * 2048);
+    auto store_tile = [&](int slot, int mrem, int nrem) {
+        const int64_t* sc = reinterpret_cast<const int64_t*>(lds + TG_SIDE + slot * TG_SLOT);
         int64_t cn[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) cn[j] = sc[128 + wn * 64 + 16 * j + fm];
-        if (full) {
+        if (mrem >= TG_BM && nrem >= TG_BN) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -242,61 +216,120 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int64_t cm = sc[wm * 64 + 16 * i + 4 * r + ff];
-                    if (cm == TG_NONE) continue;
+                    const int ml = wm * 64 + 16 * i + 4 * r + ff;
+                    if (ml >= mrem) continue;
+                    const int64_t cm = sc[ml];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (cn[j] != TG_NONE) p.C[cm + cn[j]] = acc[i][j][r];
+                        if (wn * 64 + 16 * j + fm < nrem) p.C[cm + cn[j]] = acc[i][j][r];
                 }
         }
     };
 
+    // MFMA number x of a half step: k element x >> 4 of the fragment pairs, accumulator ((x >> 2) & 3, x & 3)
+#define TG_MF(FA, FB, X)                                                                                                 \
+    acc[((X) >> 2) & 3][(X) & 3] =                                                                                       \
+        __builtin_amdgcn_mfma_f64_16x16x4f64(FA[((X) >> 2) & 3][(X) >> 4], FB[(X) & 3][(X) >> 4], acc[((X) >> 2) & 3][(X) & 3], 0, 0, 0)
+#define TG_SB __builtin_amdgcn_sched_barrier(0)
+    // fragment number q of a half step: q < 4 the A rows 16 q .., else the B columns 16 (q - 4) ..
+#define TG_FRAG(FA, FB, RA, RB, Q)                                                                                       \
+    if ((Q) < 4) FA[(Q) & 3] = *reinterpret_cast<const v2d*>(lds + RA + ((Q) & 3) * 2048);                               \
+    else FB[(Q) & 3] = *reinterpret_cast<const v2d*>(lds + RB + ((Q) & 3) * 2048)
+
     // ---- prologue: tile 0, steps 0 and 1 (every group has nk >= 2)
     enter_tile(0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     commit_tile(0);
-    int kt = 0, cj = 0, cur = 0, nk_cur = fnk;
-    bool full_cur = ffull;
-    fetch_step(0);
-    fetch_step(1);
-    cj_started = 1;
+    int kt = 0, cj = 0, cur = 0, nk_cur = fnk, mrem_cur = fmrem, nrem_cur = fnrem;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        fetch_begin(st);
+        TG_DMA(0); TG_DMA(1); TG_DMA(2); TG_DMA(3); TG_DMA(4); TG_DMA(5); TG_DMA(6); TG_DMA(7);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    frag(fa0, fb0, rdA0, rdB0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { TG_FRAG(fa0, fb0, rdA0, rdB0, q); }
+#ifdef TG_STAMPS
+    unsigned long long st_bar = 0, st_epi = 0, st_steps = 0, st_tiles = 0, st_max = 0;
+    const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
-    // ---- stream of steps
+    // ---- stream of steps.  Everything that is not an MFMA is issued in the gaps between MFMAs (a 64-cycle MFMA leaves its wave
+    // free to issue other instructions meanwhile): a wave whose partner on the SIMD is parked -- at its barrier, in its tile
+    // epilogue -- then keeps the matrix pipe busy by itself.  sched_barrier pins the order written here.
     for (;;) {
-        frag(fa1_, fb1_, rdA1, rdB1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (a.dbg & 4) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // the stage just read is free; the other one holds the next step
+        // first half: the second half's fragments are requested in the first eight gaps
+#define TG_A(Q) TG_FRAG(fa1_, fb1_, rdA1, rdB1, Q); TG_SB; TG_MF(fa0, fb0, Q); TG_SB;
+        TG_A(0) TG_A(1) TG_A(2) TG_A(3) TG_A(4) TG_A(5) TG_A(6) TG_A(7)
+#undef TG_A
+#pragma unroll
+        for (int x = 8; x < 32; ++x) TG_MF(fa0, fb0, x);
+        TG_SB;
+#ifdef TG_STAMPS
+        const unsigned long long st_b0 = __builtin_amdgcn_s_memtime();
+#endif
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef TG_STAMPS
+        {
+            const unsigned long long d = __builtin_amdgcn_s_memtime() - st_b0;
+            st_bar += d;
+            st_max = d > st_max ? d : st_max;
+            ++st_steps;
+        }
+#endif
+        TG_SB;
+        // the stage just read is free; the other one holds the next step, whose first-half fragments are requested in the first
+        // eight gaps of the second half
         const int freed = cur;
         cur ^= 1;
         rdA0 ^= TG_STAGE; rdA1 ^= TG_STAGE; rdB0 ^= TG_STAGE; rdB1 ^= TG_STAGE;
-        frag(fa0, fb0, rdA0, rdB0);
+#define TG_B(Q) TG_FRAG(fa0, fb0, rdA0, rdB0, Q); TG_SB; TG_MF(fa1_, fb1_, Q); TG_SB;
+        TG_B(0) TG_B(1) TG_B(2) TG_B(3) TG_B(4) TG_B(5) TG_B(6) TG_B(7)
+#undef TG_B
         if (pending) commit_tile(fj);
-        if (fj < ntl) {
-            fetch_step(freed);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma(fa1_, fb1_);
-        __builtin_amdgcn_sched_barrier(0);
+        // (the MFMAs stay outside the branch: two copies of them in the two arms cost hipcc 26 registers and made it spill)
+        const bool do_dma = fj < ntl;
+        if (do_dma) fetch_begin(freed);
+        TG_SB;
+#define TG_C(Q) if (do_dma) TG_DMA(Q); TG_SB; TG_MF(fa1_, fb1_, 8 + (Q)); TG_SB;
+        TG_C(0) TG_C(1) TG_C(2) TG_C(3) TG_C(4) TG_C(5) TG_C(6) TG_C(7)
+#undef TG_C
+#pragma unroll
+        for (int x = 16; x < 32; ++x) TG_MF(fa1_, fb1_, x);
+        TG_SB;
         if (++kt == nk_cur) {
-            if (!(a.dbg & 1)) store_tile(cj & 1, full_cur);
+#ifdef TG_STAMPS
+            const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+#endif
+            if (!(a.dbg & 1)) store_tile(cj & 1, mrem_cur, nrem_cur);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+#ifdef TG_STAMPS
+            st_epi += __builtin_amdgcn_s_memtime() - st_e0;
+            ++st_tiles;
+#endif
             kt = 0;
             if (++cj == ntl) break;
             // every group has nk >= 2: the next tile was committed one step ago at the latest, and the one after it
             // (entered in this very step if the next tile has two steps) is not committed before the next step
             nk_cur = fnk;
-            full_cur = ffull;
+            mrem_cur = fmrem;
+            nrem_cur = fnrem;
         }
     }
+#ifdef TG_STAMPS
+    if (lane == 0 && blockIdx.x < 512) {
+        unsigned long long* d = g_tg_stamp + ((size_t)blockIdx.x * 4 + wave) * 8;
+        d[0] = __builtin_amdgcn_s_memtime() - st_t0;
+        d[1] = st_bar; d[2] = st_epi; d[3] = st_steps; d[4] = st_tiles; d[5] = st_max;
+    }
+#endif
+#undef TG_MF
+#undef TG_SB
+#undef TG_FRAG
+#undef TG_DMA
 }
 
 // floor(x / d) == umulhi(x, tgemm_inverse(d)) for x * d < 2^32 (tile ids inside a group and patch widths are far below);

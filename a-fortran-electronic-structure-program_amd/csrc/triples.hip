@@ -591,6 +591,7 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
             for (int C = B; C < nt8; ++C) orb.push_back(A | (B << 10) | (C << 20));
     p->norb = (int)orb.size();
     if (metas.empty()) metas.push_back(TripleMeta());
+    tab.resize(tab.size() + 128, 0);   // (as tab32 below)
     p->tables = (int64_t*)cx.scratch("t_tables", (int64_t)tab.size());
     p->meta = (TripleMeta*)cx.scratch("t_meta", (int64_t)(metas.size() * sizeof(TripleMeta) / sizeof(double) + 1));
     p->orbits = (int*)cx.scratch("t_orbits", (int64_t)orb.size() / 2 + 1);
@@ -635,6 +636,7 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
     AFESP_HIP(hipMemcpyAsync(p->gdesc, gd.data(), gd.size() * sizeof(GettGroup), hipMemcpyHostToDevice, cx.stream));
     std::vector<TgGroup> tg;
     if (use_tg) {
+        tab32.resize(tab32.size() + 256, 0u);   // the kernel's table transfers read whole 1-KiB pieces (tgemm.h)
         p->tables32 = (uint32_t*)cx.scratch("t_tables32", (int64_t)(tab32.size() / 2 + 1));
         AFESP_HIP(hipMemcpyAsync(p->tables32, tab32.data(), tab32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, cx.stream));
         const int mt = (int)((v2 + TG_BM - 1) / TG_BM);

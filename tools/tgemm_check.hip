@@ -1,12 +1,80 @@
-// tgemm_check.hip -- tgemm_kernel on a small random grouped problem against a host loop (diagnostic).
-// build: hipcc -O2 --offload-arch=gfx950 tools/tgemm_check.hip -o tools/tgemm_check_bin     usage: tgemm_check_bin [M Kc N0 N1]
+// tgemm_check.hip -- tgemm_kernel on a random grouped problem against a host loop, or (-DTG_STAMPS, `big`) where its waves spend
+// their cycles on config-5-like extents (diagnostic).
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/tgemm_check.hip -o tools/tgemm_check_bin   [-DTG_STAMPS -o tools/tgemm_stamps_bin]
+// usage: tgemm_check_bin [M Kc N0 N1]        tgemm_stamps_bin big [M Kc N ngroups]
 #include "../a-fortran-electronic-structure-program_amd/csrc/tgemm.hip"
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 using namespace afesp;
+
+static int run_big(int argc, char** argv)
+{
+    const int M = argc > 2 ? atoi(argv[2]) : 40000, Kc = argc > 3 ? atoi(argv[3]) : 224, N = argc > 4 ? atoi(argv[4]) : 1000;
+    const int ng = argc > 5 ? atoi(argv[5]) : 12;
+    const int nk1 = Kc / 16, mt = (M + 127) / 128, nt = (N + 127) / 128;
+    const size_t na = (size_t)2 * M * Kc, nb = (size_t)2 * ng * N * Kc, nc = (size_t)M * N * ng;
+    double *dA, *dB, *dC; uint32_t* d32; int64_t* d64; TgGroup* dg;
+    hipMalloc(&dA, na * 8); hipMalloc(&dB, nb * 8); hipMalloc(&dC, nc * 8);
+    hipMalloc(&d32, ((size_t)M + (size_t)ng * N + 256) * 4); hipMalloc(&d64, ((size_t)M + (size_t)ng * N + 128) * 8); hipMalloc(&dg, (ng + 1) * sizeof(TgGroup));
+    std::vector<double> h(1 << 20);
+    for (auto& x : h) x = (rand() % 2001 - 1000) / 1000.0;
+    for (size_t o = 0; o < na; o += h.size()) hipMemcpy(dA + o, h.data(), std::min(h.size(), na - o) * 8, hipMemcpyHostToDevice);
+    for (size_t o = 0; o < nb; o += h.size()) hipMemcpy(dB + o, h.data(), std::min(h.size(), nb - o) * 8, hipMemcpyHostToDevice);
+    std::vector<uint32_t> t32((size_t)M + (size_t)ng * N);
+    std::vector<int64_t> t64((size_t)M + (size_t)ng * N);
+    for (int m = 0; m < M; ++m) { t32[m] = (uint32_t)((size_t)8 * Kc * m); t64[m] = m; }
+    for (int n = 0; n < ng * N; ++n) { t32[(size_t)M + n] = (uint32_t)((size_t)8 * Kc * n); t64[(size_t)M + n] = (int64_t)M * n; }
+    hipMemcpy(d32, t32.data(), t32.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d64, t64.data(), t64.size() * 8, hipMemcpyHostToDevice);
+    std::vector<TgGroup> g(ng + 1);
+    const int gm = tgemm_group_m(M, nt);
+    int tile = 0;
+    for (int q = 0; q < ng; ++q) {
+        g[q].a1 = 0; g[q].a2 = (int64_t)M * Kc; g[q].b2 = (int64_t)ng * N * Kc;
+        g[q].colB = d32 + M + (size_t)q * N; g[q].offCn = d64 + M + (size_t)q * N;
+        g[q].N = N; g[q].ntiles = nt; g[q].tile_start = tile; g[q].nk1 = nk1; g[q].nk = (q % 6 == 5) ? nk1 : 2 * nk1;
+        g[q].inv_width = tgemm_inverse(gm * nt);
+        tile += mt * nt;
+    }
+    g[ng].tile_start = tile;
+    hipMemcpy(dg, g.data(), (ng + 1) * sizeof(TgGroup), hipMemcpyHostToDevice);
+    TgProblem p{dA, dB, dC, d32, d64, M};
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double flop = 0.0;
+    for (int q = 0; q < ng; ++q) flop += 2.0 * M * N * 16.0 * g[q].nk;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0, 0);
+        hipError_t e = tgemm_launch(p, dg, ng, tile, nt, 0);
+        hipEventRecord(e1, 0);
+        hipError_t e2 = hipDeviceSynchronize();
+        float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+        printf("launch %s sync %s: %d tiles, %.3f ms, %.2f TF (executed, unpadded)\n", hipGetErrorString(e), hipGetErrorString(e2), tile, ms, flop / ms / 1e9);
+    }
+#ifdef TG_STAMPS
+    std::vector<unsigned long long> st(512 * 4 * 8);
+    hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_tg_stamp), st.size() * 8);
+    double tot = 0, bar = 0, epi = 0, steps = 0, tiles = 0, mx = 0; int n = 0;
+    for (int b = 0; b < 512; ++b) for (int w = 0; w < 4; ++w) {
+        const unsigned long long* d = &st[((size_t)b * 4 + w) * 8];
+        if (!d[3]) continue;
+        tot += d[0]; bar += d[1]; epi += d[2]; steps += d[3]; tiles += d[4]; mx = std::max(mx, (double)d[5]); ++n;
+    }
+    printf("stamps over %d waves: cycles per step %.0f (MFMA floor 8192 at two waves per SIMD), of which barrier %.0f; per tile: epilogue %.0f; longest barrier %.0f\n",
+           n, tot / steps, bar / steps, epi / tiles, mx);
+    // distribution of per-wave barrier share
+    for (int w = 0; w < 4; ++w) {
+        double b2 = 0, s2 = 0;
+        for (int b = 0; b < 512; ++b) { const unsigned long long* d = &st[((size_t)b * 4 + w) * 8]; b2 += d[1]; s2 += d[3]; }
+        printf("  wave %d: barrier cycles per step %.0f\n", w, s2 ? b2 / s2 : 0.0);
+    }
+#endif
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "big")) return run_big(argc, argv);
     const int M = argc > 1 ? atoi(argv[1]) : 300, Kc = argc > 2 ? atoi(argv[2]) : 48;
     const int Ns[2] = {argc > 3 ? atoi(argv[3]) : 200, argc > 4 ? atoi(argv[4]) : 70};
     const int nk1 = Kc / 16, ncol = Ns[0] + Ns[1];
@@ -20,7 +88,7 @@ int main(int argc, char** argv)
     for (int n = 0; n < ncol; ++n) { colB[n] = (uint32_t)(8 * Kc * ((n * 7) % ncol)); offCn[n] = (int64_t)M * n; }   // 7 coprime to ncol assumed
     const int mt = (M + 127) / 128;
     uint32_t* d32; int64_t* d64; double *dA, *dB, *dC; TgGroup* dg;
-    hipMalloc(&d32, (M + ncol) * 4); hipMalloc(&d64, (M + ncol) * 8);
+    hipMalloc(&d32, (M + ncol + 256) * 4); hipMalloc(&d64, (M + ncol + 128) * 8);
     hipMalloc(&dA, A.size() * 8); hipMalloc(&dB, B.size() * 8); hipMalloc(&dC, C.size() * 8); hipMalloc(&dg, 3 * sizeof(TgGroup));
     hipMemcpy(d32, rowA.data(), M * 4, hipMemcpyHostToDevice); hipMemcpy(d32 + M, colB.data(), ncol * 4, hipMemcpyHostToDevice);
     hipMemcpy(d64, offCm.data(), M * 8, hipMemcpyHostToDevice); hipMemcpy(d64 + M, offCn.data(), ncol * 8, hipMemcpyHostToDevice);
@@ -71,8 +139,6 @@ int main(int argc, char** argv)
             }
             putchar('\n');
         }
-        int shown = 0;
-        for (size_t i = 0; i < C.size() && shown < 8; ++i) if (fabs(C[i] - R[i]) > 1e-10) { printf("  C[%zu] (m %zu n %zu) = %.6f ref %.6f\n", i, i % M, i / M, C[i], R[i]); ++shown; }
     }
     return bad ? 1 : 0;
 }
