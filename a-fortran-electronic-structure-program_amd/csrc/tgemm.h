@@ -33,6 +33,9 @@ struct TgProblem {
     const uint32_t* rowA;    // [M] byte offsets of the rows of A inside a panel
     const int64_t* offCm;    // [M] element offsets of the rows of C
     int M;
+    // columns 2k and 2k + 1 of every group are adjacent in C (offCn[2k + 1] == offCn[2k] + 1) and offCm[m] + offCn[2k] is even,
+    // C 16-byte aligned: whole tiles are then stored 16 bytes per lane
+    bool c_pairs = false;
 };
 
 constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 16;

@@ -14,6 +14,10 @@
 // Fragments: lane (m = l & 15, f = l >> 4) reads chunk f + 4h of its row in half h = 0, 1 of a step: two consecutive k.  The
 // first doubles of the four f feed one MFMA (k = 2(f + 4h)), the second doubles the next (k + 1); A and B use the same map, so
 // every k of the step is summed exactly once.
+// Columns: row 16 j + f' of the B image holds tile column col(j, f') = 32 (j >> 1) + 2 f' + (j & 1), so that a lane's
+// accumulators (i, 2jj) and (i, 2jj + 1) hold two ADJACENT columns of C: where those are adjacent in memory too
+// (TgProblem::c_pairs) the tile is stored with 32 global_store_dwordx4 per wave instead of 64 dwordx2 -- the store tail is
+// bound by the number of store instructions, ~270 cycles each for a wave whatever their width (tools/tgemm_check.hip big).
 //
 // One stream step (stage `cur` holds this step's data, F0 its first-half fragments):
 //     32 MFMA on F0, F1(cur) requested in their first gaps | s_waitcnt vmcnt(0) lgkmcnt(0), s_barrier |
@@ -156,8 +160,9 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = drow + 8 * q;
+            const int c = 32 * (r >> 5) + 2 * (r & 15) + ((r >> 4) & 1);   // tile column of B image row r (header: Columns)
             voffA[q] = sr[min(r, lm)] + ((q & 1) ? dch1 : dch0);
-            voffB[q] = sr[256 + min(r, ln)] + ((q & 1) ? dch1 : dch0);
+            voffB[q] = sr[256 + min(c, ln)] + ((q & 1) ? dch1 : dch0);
         }
         fnk = pnk; fnk1 = pnk1; fa1 = pa1; fa2 = pa2; fb1 = pb1; fb2 = pb2; fmrem = pmrem; fnrem = pnrem;
         pending = false;
@@ -196,22 +201,30 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
     v2d fa0[4], fb0[4], fa1_[4], fb1_[4];
-    // C(m0 + 64 wm + 16 i + (l >> 4) + 4 r, n0 + 64 wn + 16 j + (l & 15)) = acc[i][j][r]; offsets from the tile's slot
+    // acc[i][j][r] = C(m0 + 64 wm + 16 i + (l >> 4) + 4 r, n0 + 64 wn + col(j, l & 15)); offsets from the tile's slot
     auto store_tile = [&](int slot, int mrem, int nrem) {
         const int64_t* sc = reinterpret_cast<const int64_t*>(lds + TG_SIDE + slot * TG_SLOT);
-        int64_t cn[4];
+        if (mrem >= TG_BM && nrem >= TG_BN && p.c_pairs) {
+            int64_t cn[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cn[j] = sc[128 + wn * 64 + 16 * j + fm];
-        if (mrem >= TG_BM && nrem >= TG_BN) {
+            for (int jj = 0; jj < 2; ++jj) cn[jj] = sc[128 + wn * 64 + 32 * jj + 2 * fm];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t cm = sc[wm * 64 + 16 * i + 4 * r + ff];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) p.C[cm + cn[j]] = acc[i][j][r];
+                    for (int jj = 0; jj < 2; ++jj)
+                        *reinterpret_cast<v2d*>(p.C + cm + cn[jj]) = (v2d){acc[i][2 * jj][r], acc[i][2 * jj + 1][r]};
                 }
         } else {
+            int64_t cn[4];
+            int nl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                nl[j] = wn * 64 + 32 * (j >> 1) + 2 * fm + (j & 1);
+                cn[j] = sc[128 + nl[j]];
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -221,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
                     const int64_t cm = sc[ml];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (wn * 64 + 16 * j + fm < nrem) p.C[cm + cn[j]] = acc[i][j][r];
+                        if (nl[j] < nrem) p.C[cm + cn[j]] = acc[i][j][r];
                 }
         }
     };
@@ -339,7 +352,8 @@ unsigned tgemm_inverse(int d) { return d <= 1 ? 0u : (unsigned)(((uint64_t)1 << 
 int tgemm_group_m(int M, int max_ntiles)
 {
     const int mtiles = (M + TG_BM - 1) / TG_BM;
-    return std::min(mtiles, std::max(1, (64 + max_ntiles / 2) / std::max(1, max_ntiles)));
+    static const int patch = getenv("AFESP_TG_PATCH") ? atoi(getenv("AFESP_TG_PATCH")) : 64;   // tuning knob: tiles per patch
+    return std::min(mtiles, std::max(1, (patch + max_ntiles / 2) / std::max(1, max_ntiles)));
 }
 
 void preload_tgemm()

@@ -223,6 +223,7 @@ struct TriplesPlan {
     bool use_tg = false;           // fused scheme: the products run on tgemm_kernel (tgemm.h) instead of the grouped gett_kernel
     TgGroup* tgdesc = nullptr;
     uint32_t* tables32 = nullptr;  // [rowA (v^2) | per chunk: colB]  byte offsets
+    bool c_pairs = false;          // columns (x, x + 1), x even, of a block are adjacent in the cube-blocked layout: v even (tgemm.h)
     double* pool0 = nullptr;       // fused scheme, not completely renormalised: base the block offsets refer to (assemble_pool)
 };
 
@@ -448,6 +449,8 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
     const int64_t O = o, V = v, v2 = V * V, Kc = (V + O + 15) / 16 * 16;
     const int64_t nt8 = (V + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;
     p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = cr; p->mode = 0; p->use_tg = use_tg;
+    // a group's columns are (x, block) with x fastest: column 2k is an even x iff v is even; rows and blocks start at multiples of 8
+    p->c_pairs = (v % 2) == 0;
     const int nk1 = (int)(Kc / TG_BK);
     std::vector<uint32_t> tab32;
     if (use_tg)
@@ -871,10 +874,10 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             gm.B = tt2.d;
             gm.C = Mpool;
             if (p->use_tg) {
-                TgProblem tp{vt.d, tt.d, Xpool, p->tables32, p->tables + p->off_Cm, (int)v2};
+                TgProblem tp{vt.d, tt.d, Xpool, p->tables32, p->tables + p->off_Cm, (int)v2, p->c_pairs};
                 AFESP_HIP(tgemm_launch(tp, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream));
                 if (cr) {
-                    TgProblem tm{vt2.d, tt2.d, Mpool, p->tables32, p->tables + p->off_Cm, (int)v2};
+                    TgProblem tm{vt2.d, tt2.d, Mpool, p->tables32, p->tables + p->off_Cm, (int)v2, p->c_pairs};
                     AFESP_HIP(tgemm_launch(tm, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream));
                 }
             } else {

@@ -24,8 +24,9 @@ static int run_big(int argc, char** argv)
     for (size_t o = 0; o < nb; o += h.size()) hipMemcpy(dB + o, h.data(), std::min(h.size(), nb - o) * 8, hipMemcpyHostToDevice);
     std::vector<uint32_t> t32((size_t)M + (size_t)ng * N);
     std::vector<int64_t> t64((size_t)M + (size_t)ng * N);
-    for (int m = 0; m < M; ++m) { t32[m] = (uint32_t)((size_t)8 * Kc * m); t64[m] = m; }
-    for (int n = 0; n < ng * N; ++n) { t32[(size_t)M + n] = (uint32_t)((size_t)8 * Kc * n); t64[(size_t)M + n] = (int64_t)M * n; }
+    // C: pairs of columns interleaved (tgemm.h c_pairs): C(m, n) at 2 m + (n & 1) + 2 M (n >> 1)
+    for (int m = 0; m < M; ++m) { t32[m] = (uint32_t)((size_t)8 * Kc * m); t64[m] = 2 * m; }
+    for (int n = 0; n < ng * N; ++n) { t32[(size_t)M + n] = (uint32_t)((size_t)8 * Kc * n); t64[(size_t)M + n] = (n & 1) + (int64_t)2 * M * (n >> 1); }
     hipMemcpy(d32, t32.data(), t32.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d64, t64.data(), t64.size() * 8, hipMemcpyHostToDevice);
     std::vector<TgGroup> g(ng + 1);
     const int gm = tgemm_group_m(M, nt);
@@ -39,7 +40,7 @@ static int run_big(int argc, char** argv)
     }
     g[ng].tile_start = tile;
     hipMemcpy(dg, g.data(), (ng + 1) * sizeof(TgGroup), hipMemcpyHostToDevice);
-    TgProblem p{dA, dB, dC, d32, d64, M};
+    TgProblem p{dA, dB, dC, d32, d64, M, getenv("TG_NOPAIRS") == nullptr};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     double flop = 0.0;
     for (int q = 0; q < ng; ++q) flop += 2.0 * M * N * 16.0 * g[q].nk;
@@ -85,7 +86,10 @@ int main(int argc, char** argv)
     std::vector<uint32_t> rowA(M), colB(ncol);
     std::vector<int64_t> offCm(M), offCn(ncol);
     for (int m = 0; m < M; ++m) { rowA[m] = (uint32_t)(8 * Kc * m); offCm[m] = m; }
-    for (int n = 0; n < ncol; ++n) { colB[n] = (uint32_t)(8 * Kc * ((n * 7) % ncol)); offCn[n] = (int64_t)M * n; }   // 7 coprime to ncol assumed
+    // C layout: plain column-major, or (TG_PAIRS=1; needs even N0, N1) pairs of columns interleaved: C(m, n) at 2 m + (n & 1) + 2 M (n >> 1)
+    const bool pairs = getenv("TG_PAIRS") != nullptr;
+    if (pairs) for (int m = 0; m < M; ++m) offCm[m] = 2 * m;
+    for (int n = 0; n < ncol; ++n) { colB[n] = (uint32_t)(8 * Kc * ((n * 7) % ncol)); offCn[n] = pairs ? (n & 1) + (int64_t)2 * M * (n >> 1) : (int64_t)M * n; }   // 7 coprime to ncol assumed
     const int mt = (M + 127) / 128;
     uint32_t* d32; int64_t* d64; double *dA, *dB, *dC; TgGroup* dg;
     hipMalloc(&d32, (M + ncol + 256) * 4); hipMalloc(&d64, (M + ncol + 128) * 8);
@@ -107,7 +111,8 @@ int main(int argc, char** argv)
     }
     g[2].tile_start = tile;
     hipMemcpy(dg, g, sizeof(g), hipMemcpyHostToDevice);
-    TgProblem p{dA, dB, dC, d32, d64, M};
+    // (offCn[n] = M n: columns are adjacent only when M == 1; pairs are exercised with TG_PAIRS=1, which lays C out column-pair-major)
+    TgProblem p{dA, dB, dC, d32, d64, M, pairs};
     hipError_t e = tgemm_launch(p, dg, 2, tile, mx, 0);
     hipError_t e2 = hipDeviceSynchronize();
     printf("launch %s sync %s tiles %d gm %d\n", hipGetErrorString(e), hipGetErrorString(e2), tile, gm);
@@ -120,7 +125,7 @@ int main(int argc, char** argv)
                 for (int k = 0; k < Kc; ++k) s += A[(size_t)m * Kc + k] * b1[k];
                 if (g[q].nk == 2 * nk1)
                     for (int k = 0; k < Kc; ++k) s += A[(size_t)M * Kc + (size_t)m * Kc + k] * b1[(size_t)ncol * Kc + k];
-                R[(size_t)m + (size_t)M * n] = s;
+                R[(size_t)(offCm[m] + offCn[n])] = s;
             }
     double mxe = 0.0; long bad = 0, untouched = 0;
     for (size_t i = 0; i < C.size(); ++i) { double d = fabs(C[i] - R[i]); if (d > mxe) mxe = d; if (d > 1e-10) ++bad; if (C[i] == -7.0) ++untouched; }
@@ -132,7 +137,7 @@ int main(int argc, char** argv)
                 int w = 0, u = 0;
                 for (int m = mb * 16; m < std::min(M, mb * 16 + 16); ++m)
                     for (int n = nb * 16; n < std::min(ncol, nb * 16 + 16); ++n) {
-                        size_t i = (size_t)m + (size_t)M * n;
+                        size_t i = (size_t)(offCm[m] + offCn[n]);
                         if (C[i] == -7.0) ++u; else if (fabs(C[i] - R[i]) > 1e-10) ++w;
                     }
                 putchar(u ? 'u' : w ? 'x' : '.');
