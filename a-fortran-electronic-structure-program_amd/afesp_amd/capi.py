@@ -420,10 +420,10 @@ class Engine:
         return ms.value
 
     def profile(self, enable):
-        out = np.zeros(6)
+        out = np.zeros(8)
         self._chk(self.L.afesp_profile(self.h, 1 if enable else 0, out))
         return dict(gemm_ms=out[0], gemm_launches=int(out[1]), gemm_flop=out[2], orbit_ms=out[3], orbit_launches=int(out[4]),
-                    orbit_bytes=out[5])
+                    orbit_bytes=out[5], gemm_flop_padded=out[6], gemm_kernel="tgemm_kernel" if out[7] else "gett_kernel")
 
     def bench_stream(self, n, reps=5):
         ms = dbl()

@@ -118,6 +118,8 @@ struct Context {
     // optional HIP-event timing of the (T) launches (bench.py roofline): enabled by afesp_profile
     bool prof = false;
     double prof_gemm_ms = 0.0, prof_gemm_flop = 0.0, prof_orbit_ms = 0.0, prof_orbit_bytes = 0.0;
+    double prof_gemm_flop_padded = 0.0;   // ... including the zero padding the tiles execute (tile edges, K steps)
+    int prof_gemm_kind = 0;               // 1: the LDS-DMA kernel (tgemm.h), 0: the grouped gather kernel (gett.h)
     int64_t prof_gemm_launches = 0, prof_orbit_launches = 0;
 
     double* alloc(int64_t n);             // zero-initialised doubles

@@ -1010,16 +1010,17 @@ int afesp_bench_stream(afesp_ctx* ctx, int64_t n, int reps, double* ms_per_launc
     });
 }
 
-int afesp_profile(afesp_ctx* ctx, int enable, double out[6])
+int afesp_profile(afesp_ctx* ctx, int enable, double out[8])
 {
     return guarded(ctx, [&] {
         Context& cx = ctx->cx;
         if (out) {
             out[0] = cx.prof_gemm_ms; out[1] = (double)cx.prof_gemm_launches; out[2] = cx.prof_gemm_flop;
             out[3] = cx.prof_orbit_ms; out[4] = (double)cx.prof_orbit_launches; out[5] = cx.prof_orbit_bytes;
+            out[6] = cx.prof_gemm_flop_padded; out[7] = (double)cx.prof_gemm_kind;
         }
         cx.prof = enable != 0;
-        cx.prof_gemm_ms = cx.prof_gemm_flop = cx.prof_orbit_ms = cx.prof_orbit_bytes = 0.0;
+        cx.prof_gemm_ms = cx.prof_gemm_flop = cx.prof_gemm_flop_padded = cx.prof_orbit_ms = cx.prof_orbit_bytes = 0.0;
         cx.prof_gemm_launches = cx.prof_orbit_launches = 0;
     });
 }

@@ -36,6 +36,8 @@ struct TgProblem {
     // columns 2k and 2k + 1 of every group are adjacent in C (offCn[2k + 1] == offCn[2k] + 1) and offCm[m] + offCn[2k] is even,
     // C 16-byte aligned: whole tiles are then stored 16 bytes per lane
     bool c_pairs = false;
+    // groups of four valid k in the last K step of each of a group's two runs (1..4; the rest of that step is zero padding)
+    int ktail4 = 4;
 };
 
 constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 16;

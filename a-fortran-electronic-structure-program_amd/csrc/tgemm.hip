@@ -19,6 +19,11 @@
 // (TgProblem::c_pairs) the tile is stored with 32 global_store_dwordx4 per wave instead of 64 dwordx2 -- the store tail is
 // bound by the number of store instructions, ~270 cycles each for a wave whatever their width (tools/tgemm_check.hip big).
 //
+// K tails: the last step of each of the two runs of the summation index carries only TgProblem::ktail4 groups of four valid k
+// (the rest is zero padding).  The second MFMA pass of that step's second half is skipped; with three groups the second half's
+// fragments are read as single doubles, lane f taking k = 8 + f, so that the first pass holds all of them (with fewer the second
+// half is all zeros).
+//
 // One stream step (stage `cur` holds this step's data, F0 its first-half fragments):
 //     32 MFMA on F0, F1(cur) requested in their first gaps | s_waitcnt vmcnt(0) lgkmcnt(0), s_barrier |
 //     32 MFMA on F1, in their gaps: F0(cur^1) of the next step requested, the DMA of step + 2 into stage cur issued |
@@ -112,6 +117,9 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     unsigned rdA1 = (unsigned)((wm * 64 + fm) * 128 + (((ff + 4) ^ fs) & 7) * 16);
     unsigned rdB0 = (unsigned)(TG_BIMG + (wn * 64 + fm) * 128 + ((ff ^ fs) & 7) * 16);
     unsigned rdB1 = (unsigned)(TG_BIMG + (wn * 64 + fm) * 128 + (((ff + 4) ^ fs) & 7) * 16);
+    // (K tail of three groups: lane f reads the single double k = 8 + f = element f & 1 of chunk 4 + (f >> 1))
+    unsigned rdA1t = (unsigned)((wm * 64 + fm) * 128 + (((4 + (ff >> 1)) ^ fs) & 7) * 16 + (ff & 1) * 8);
+    unsigned rdB1t = (unsigned)(TG_BIMG + (wn * 64 + fm) * 128 + (((4 + (ff >> 1)) ^ fs) & 7) * 16 + (ff & 1) * 8);
 
     // ---- fetch cursor (two steps ahead of the MFMAs) and the tile entered but not yet committed
     int fj = 0, fkt = 0, fnk = 0, fnk1 = 0;
@@ -188,10 +196,10 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     // The cursor moves on one step.  When the step is the last one of its tile the next tile is entered BEFORE the step's own
     // transfers are issued (its table transfers are then the older ones; everything is waited for at the step's barrier).
     auto fetch_begin = [&](int stage) {
-        const bool last = fkt + 1 == fnk;
+        const bool live = fj < ntl, last = live && fkt + 1 == fnk;
         if (last && fj + 1 < ntl) enter_tile(fj + 1);
         dma_setup(stage);
-        fkt = last ? 0 : fkt + 1;   // (written as selects: an if/else of increments made hipcc keep the two counters in scratch memory)
+        fkt = last ? 0 : live ? fkt + 1 : fkt;   // (written as selects: an if/else of increments made hipcc keep the counters in scratch memory)
         fj += last ? 1 : 0;
     };
 
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     enter_tile(0);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     commit_tile(0);
-    int kt = 0, cj = 0, cur = 0, nk_cur = fnk, mrem_cur = fmrem, nrem_cur = fnrem;
+    int kt = 0, cj = 0, cur = 0, nk_cur = fnk, nk1_cur = fnk1, mrem_cur = fmrem, nrem_cur = fnrem;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         fetch_begin(st);
@@ -271,10 +279,23 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     // free to issue other instructions meanwhile): a wave whose partner on the SIMD is parked -- at its barrier, in its tile
     // epilogue -- then keeps the matrix pipe busy by itself.  sched_barrier pins the order written here.
     for (;;) {
+        // K tail of this step (header): t3 = its second half has one pass of single-double fragments, t2 = no second half
+        const bool ktl = (kt + 1 == nk1_cur || kt + 1 == nk_cur) && p.ktail4 < 4;
+        const bool t3 = ktl && p.ktail4 == 3;   // (fewer groups: the second half is all zeros, its first pass then runs on them)
         // first half: the second half's fragments are requested in the first eight gaps
 #define TG_A(Q) TG_FRAG(fa1_, fb1_, rdA1, rdB1, Q); TG_SB; TG_MF(fa0, fb0, Q); TG_SB;
         TG_A(0) TG_A(1) TG_A(2) TG_A(3) TG_A(4) TG_A(5) TG_A(6) TG_A(7)
 #undef TG_A
+        // (a scalar branch between two MFMAs costs the matrix pipe tens of cycles -- sixteen of them in these gaps took the kernel
+        // from 67 to 55 TFLOP/s -- so the rare cases get ONE branch each per step)
+        if (t3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                fa1_[q][0] = *reinterpret_cast<const double*>(lds + rdA1t + q * 2048);
+                fb1_[q][0] = *reinterpret_cast<const double*>(lds + rdB1t + q * 2048);
+            }
+        }
+        TG_SB;
 #pragma unroll
         for (int x = 8; x < 32; ++x) TG_MF(fa0, fb0, x);
         TG_SB;
@@ -295,20 +316,22 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         // eight gaps of the second half
         const int freed = cur;
         cur ^= 1;
-        rdA0 ^= TG_STAGE; rdA1 ^= TG_STAGE; rdB0 ^= TG_STAGE; rdB1 ^= TG_STAGE;
+        rdA0 ^= TG_STAGE; rdA1 ^= TG_STAGE; rdB0 ^= TG_STAGE; rdB1 ^= TG_STAGE; rdA1t ^= TG_STAGE; rdB1t ^= TG_STAGE;
 #define TG_B(Q) TG_FRAG(fa0, fb0, rdA0, rdB0, Q); TG_SB; TG_MF(fa1_, fb1_, Q); TG_SB;
         TG_B(0) TG_B(1) TG_B(2) TG_B(3) TG_B(4) TG_B(5) TG_B(6) TG_B(7)
 #undef TG_B
         if (pending) commit_tile(fj);
-        // (the MFMAs stay outside the branch: two copies of them in the two arms cost hipcc 26 registers and made it spill)
-        const bool do_dma = fj < ntl;
-        if (do_dma) fetch_begin(freed);
+        // (behind the last step of the stream the transfers are issued all the same -- the first step of the last tile once more,
+        // into a stage nobody reads again: cheaper than eight branches per step; they are waited for before the kernel ends)
+        fetch_begin(freed);
         TG_SB;
-#define TG_C(Q) if (do_dma) TG_DMA(Q); TG_SB; TG_MF(fa1_, fb1_, 8 + (Q)); TG_SB;
+#define TG_C(Q) TG_DMA(Q); TG_SB; TG_MF(fa1_, fb1_, 8 + (Q)); TG_SB;
         TG_C(0) TG_C(1) TG_C(2) TG_C(3) TG_C(4) TG_C(5) TG_C(6) TG_C(7)
 #undef TG_C
+        if (!ktl) {
 #pragma unroll
-        for (int x = 16; x < 32; ++x) TG_MF(fa1_, fb1_, x);
+            for (int x = 16; x < 32; ++x) TG_MF(fa1_, fb1_, x);
+        }
         TG_SB;
         if (++kt == nk_cur) {
 #ifdef TG_STAMPS
@@ -328,10 +351,12 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
             // every group has nk >= 2: the next tile was committed one step ago at the latest, and the one after it
             // (entered in this very step if the next tile has two steps) is not committed before the next step
             nk_cur = fnk;
+            nk1_cur = fnk1;
             mrem_cur = fmrem;
             nrem_cur = fnrem;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no transfer may land in LDS that belongs to the next workgroup
 #ifdef TG_STAMPS
     if (lane == 0 && blockIdx.x < 512) {
         unsigned long long* d = g_tg_stamp + ((size_t)blockIdx.x * 4 + wave) * 8;

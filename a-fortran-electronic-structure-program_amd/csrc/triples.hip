@@ -874,10 +874,10 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             gm.B = tt2.d;
             gm.C = Mpool;
             if (p->use_tg) {
-                TgProblem tp{vt.d, tt.d, Xpool, p->tables32, p->tables + p->off_Cm, (int)v2, p->c_pairs};
+                TgProblem tp{vt.d, tt.d, Xpool, p->tables32, p->tables + p->off_Cm, (int)v2, p->c_pairs, (int)((V + O - (Kc - TG_BK) + 3) / 4)};
                 AFESP_HIP(tgemm_launch(tp, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream));
                 if (cr) {
-                    TgProblem tm{vt2.d, tt2.d, Mpool, p->tables32, p->tables + p->off_Cm, (int)v2, p->c_pairs};
+                    TgProblem tm{vt2.d, tt2.d, Mpool, p->tables32, p->tables + p->off_Cm, (int)v2, p->c_pairs, (int)((V + O - (Kc - TG_BK) + 3) / 4)};
                     AFESP_HIP(tgemm_launch(tm, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream));
                 }
             } else {
@@ -894,6 +894,22 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             }
             }
             if (cx.prof) {
+                cx.prof_gemm_kind = p->use_tg ? 1 : 0;
+                // what the tiles execute, zero padding included: whole tiles along both edges, whole K steps -- the LDS-DMA
+                // kernel skips the last quarter of a run's last step when it is all padding (tgemm.h, ktail4)
+                for (const TriplesPlan::Group& g : ch.groups) {
+                    const bool half = ch.split_diag && g.q == g.r;
+                    if (p->use_tg) {
+                        const double kexec = (double)(Kc - TG_BK) + ((V + O - (Kc - TG_BK) + 3) / 4 < 4 ? 12.0 : 16.0);
+                        cx.prof_gemm_flop_padded += 2.0 * (double)((v2 + TG_BM - 1) / TG_BM * TG_BM) * (double)((g.N + TG_BN - 1) / TG_BN * TG_BN) *
+                                                    kexec * (half ? 1.0 : 2.0);
+                    } else {
+                        int tm_, tn_, BM_, BN_;
+                        gett_grouped_tile((int)v2, true, &tm_, &tn_, &BM_, &BN_);
+                        cx.prof_gemm_flop_padded += 2.0 * (double)((v2 + BM_ - 1) / BM_ * BM_) * (double)((g.N + BN_ - 1) / BN_ * BN_) *
+                                                    (double)Kc * (half ? 1.0 : 2.0);
+                    }
+                }
                 cx.prof_gemm_launches += p->use_tg ? 1 : (ch.ngroups_off > 0) + (ch.ngroups_diag > 0);
                 cx.prof_gemm_flop += 2.0 * (double)gp.M * (double)(2 * ch.ncol_off + ch.ncol_diag) * (double)(V + O);
             }

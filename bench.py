@@ -372,7 +372,8 @@ def live_pmc(workload, timeout_s=240.0):
     if any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
         return None   # this process is being profiled itself: no profiler inside a profiler
     t_end = time.time() + timeout_s
-    grouped = lambda name: "gett_kernel" in name and ", true, false>" in name   # <..., GRP = true, RAG = false>
+    # the (T) GEMM launches: tgemm_kernel (LDS-DMA kernel), or gett_kernel<..., GRP = true, RAG = false> under AFESP_T_GEMM=gett
+    grouped = lambda name: "tgemm_kernel" in name or ("gett_kernel" in name and ", true, false>" in name)
     mean = {}
     with tempfile.TemporaryDirectory(prefix="afesp_pmc_", dir="/tmp") as td:
         for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
@@ -504,12 +505,21 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
                     "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s"}
             roof["frac"] = roof["achieved"] / roof["peak"]
             roof["traffic"] = None
-            roof["kernel"] = ("gett_kernel<..., GRP = true>, the grouped (T) launches (one per chunk): Y(a;b,c|i;jk) = sum over "
-                              "kappa = [d + l ; d + l] of tt(kappa;a,.)*vt(kappa;b,c,.), K = 2(v+o); "
-                              "pairs j == k in a second launch per chunk over K = v+o (the orbit kernel adds the transpose)")
+            if prof.get("gemm_kernel") == "tgemm_kernel":
+                roof["kernel"] = ("tgemm_kernel (csrc/tgemm.hip: LDS-DMA staged, two 4-wave workgroups per CU on 128x128 tiles), the grouped "
+                                  "(T) launches, one per chunk: Y(a;b,c|i;jk) = sum over kappa = [d + l ; d + l] of tt(kappa;a,.)*vt(kappa;b,c,.), "
+                                  "K = 2(v+o); the groups with j == k run over K = v+o in the same launch (the orbit kernel adds the transpose)")
+            else:
+                roof["kernel"] = ("gett_kernel<..., GRP = true>, the grouped (T) launches (one per chunk): Y(a;b,c|i;jk) = sum over "
+                                  "kappa = [d + l ; d + l] of tt(kappa;a,.)*vt(kappa;b,c,.), K = 2(v+o); "
+                                  "pairs j == k in a second launch per chunk over K = v+o (the orbit kernel adds the transpose)")
             roof["launches"] = prof["gemm_launches"]
             roof["ms_per_launch"] = prof["gemm_ms"] / nl
             roof["flop_per_launch"] = prof["gemm_flop"] / nl
+            # ... and what the tiles execute with their zero padding (tile edges in M and N, the K steps' tails): the rate of the
+            # matrix pipe itself
+            roof["flop_per_launch_padded"] = prof.get("gemm_flop_padded", 0.0) / nl
+            roof["achieved_padded"] = prof.get("gemm_flop_padded", 0.0) / max(prof["gemm_ms"], 1e-9) / 1e9
             roof["share_of_step_time"] = prof["gemm_ms"] * 1e-3 / elapsed
             tfile = latest_profile("traffic.json")
             live = live_pmc(workload) if (args.live_pmc and world == 1 and workload == args.workload) else None

@@ -215,9 +215,10 @@ int afesp_bench_stream(afesp_ctx* ctx, int64_t n, int reps, double* ms_per_launc
 int afesp_bench_contract(afesp_ctx* ctx, const char* la, const int64_t* dimsA, const char* lb, const int64_t* dimsB,
                          const char* lc, const int64_t* dimsC, int reps, double* ms_per_launch);
 /* HIP-event timing of the (T) launches on the context stream.  Returns the totals accumulated since the previous call
- * (out = {GEMM ms, GEMM launches, GEMM flop, orbit-kernel ms, orbit launches, orbit algorithmic bytes}), clears them and
- * switches the instrumentation on/off for the following afesp_ccsd_t calls. */
-int afesp_profile(afesp_ctx* ctx, int enable, double out[6]);
+ * (out = {GEMM ms, GEMM launches, GEMM flop, orbit-kernel ms, orbit launches, orbit algorithmic bytes, GEMM flop including the
+ * zero padding its tiles execute, GEMM kernel: 1 LDS-DMA kernel / 0 gather kernel}), clears them and switches the
+ * instrumentation on/off for the following afesp_ccsd_t calls. */
+int afesp_profile(afesp_ctx* ctx, int enable, double out[8]);
 /* Process-wide tuning overrides of the GEMM launcher (0 = heuristic): tile-walk group, tile shape (1|2|4), split-K. */
 int afesp_set_tuning(int group_m, int force_tm, int force_tn, int force_split);
 

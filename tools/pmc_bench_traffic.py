@@ -6,7 +6,7 @@ wl, fdir, wdir, outp = sys.argv[1:5]
 def avg(d, counter):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if "gett_kernel" in r["Kernel_Name"] and ", true, false>" in r["Kernel_Name"] and r["Counter_Name"] == counter]   # <..., GRP = true, RAG = false>: the grouped (T) launches
+            if ("tgemm_kernel" in r["Kernel_Name"] or ("gett_kernel" in r["Kernel_Name"] and ", true, false>" in r["Kernel_Name"])) and r["Counter_Name"] == counter]   # <..., GRP = true, RAG = false>: the grouped (T) launches
     return sum(vals) / len(vals), len(vals)
 fetch, nf = avg(fdir, "FETCH_SIZE")
 write, nw = avg(wdir, "WRITE_SIZE")

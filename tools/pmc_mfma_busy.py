@@ -13,7 +13,7 @@ for wl in ("cfg5", "h2o_tz"):
         act = json.load(open(os.path.join(d, f"{tag}_pmc_GRBM_GUI_ACTIVE_{wl}.json")))["counters"]
     except (OSError, KeyError):
         continue
-    grp = lambda rows: [r for r in rows if "gett_kernel" in r["name"] and ", true, false>" in r["name"]]   # GRP = true, RAG = false
+    grp = lambda rows: [r for r in rows if ("tgemm_kernel" in r["name"] or ("gett_kernel" in r["name"] and ", true, false>" in r["name"]))]   # GRP = true, RAG = false
     b, a = grp(busy), grp(act)
     if not b or not a or (wl + "_t_gemm") not in out:
         continue

@@ -40,7 +40,7 @@ static int run_big(int argc, char** argv)
     }
     g[ng].tile_start = tile;
     hipMemcpy(dg, g.data(), (ng + 1) * sizeof(TgGroup), hipMemcpyHostToDevice);
-    TgProblem p{dA, dB, dC, d32, d64, M, getenv("TG_NOPAIRS") == nullptr};
+    TgProblem p{dA, dB, dC, d32, d64, M, getenv("TG_NOPAIRS") == nullptr, getenv("TG_KT4") ? atoi(getenv("TG_KT4")) : 4};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     double flop = 0.0;
     for (int q = 0; q < ng; ++q) flop += 2.0 * M * N * 16.0 * g[q].nk;
@@ -83,6 +83,10 @@ int main(int argc, char** argv)
     srand(3);
     for (auto& x : A) x = (rand() % 2001 - 1000) / 1000.0;
     for (auto& x : B) x = (rand() % 2001 - 1000) / 1000.0;
+    // valid summation length Kv <= Kc of each run (TG_KV): zero padding behind it, as the (T) operands have
+    const int Kv = getenv("TG_KV") ? atoi(getenv("TG_KV")) : Kc;
+    for (size_t r = 0; r < A.size() / Kc; ++r) for (int k = Kv; k < Kc; ++k) A[r * Kc + k] = 0.0;
+    for (size_t r = 0; r < B.size() / Kc; ++r) for (int k = Kv; k < Kc; ++k) B[r * Kc + k] = 0.0;
     std::vector<uint32_t> rowA(M), colB(ncol);
     std::vector<int64_t> offCm(M), offCn(ncol);
     for (int m = 0; m < M; ++m) { rowA[m] = (uint32_t)(8 * Kc * m); offCm[m] = m; }
@@ -112,7 +116,7 @@ int main(int argc, char** argv)
     g[2].tile_start = tile;
     hipMemcpy(dg, g, sizeof(g), hipMemcpyHostToDevice);
     // (offCn[n] = M n: columns are adjacent only when M == 1; pairs are exercised with TG_PAIRS=1, which lays C out column-pair-major)
-    TgProblem p{dA, dB, dC, d32, d64, M, pairs};
+    TgProblem p{dA, dB, dC, d32, d64, M, pairs, (Kv - (Kc - 16) + 3) / 4};
     hipError_t e = tgemm_launch(p, dg, 2, tile, mx, 0);
     hipError_t e2 = hipDeviceSynchronize();
     printf("launch %s sync %s tiles %d gm %d\n", hipGetErrorString(e), hipGetErrorString(e2), tile, gm);
