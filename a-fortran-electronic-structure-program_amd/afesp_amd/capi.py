@@ -30,7 +30,7 @@ EXPORTS = [
     "afesp_read_eri_text", "afesp_write_fcidump", "afesp_set_eri", "afesp_build_fock", "afesp_ccsd_t_plain",
     "afesp_synthetic_ao", "afesp_ccsd_pp_ladder_flop", "afesp_ccsd_iteration_flop",
     "afesp_device_count", "afesp_comm_unique_id", "afesp_comm_init", "afesp_comm_destroy", "afesp_allreduce_sum",
-    "afesp_ccsd_t_block_size", "afesp_test_inject", "afesp_ccsd_is_split", "afesp_debug_stamps", "afesp_arena_stats",
+    "afesp_ccsd_t_block_size", "afesp_test_inject", "afesp_ccsd_is_split", "afesp_ccsd_set_split", "afesp_debug_stamps", "afesp_arena_stats",
 ]
 COMM_RCCL, COMM_HOST = 0, 1
 
@@ -113,6 +113,7 @@ def load_library():
     L.afesp_test_inject.argtypes = [C.c_void_p, C.c_int]
     L.afesp_arena_stats.argtypes = [C.c_void_p, _dp]
     L.afesp_ccsd_is_split.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.afesp_ccsd_set_split.argtypes = [C.c_void_p, C.c_int]
     L.afesp_debug_stamps.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L
@@ -129,6 +130,11 @@ TENSOR_SHAPES = {
     "I_oooo": "oooo", "I_ovov": "ovov", "I_voov": "voov", "I_vovv_p": "vovv", "I_ooov_p": "ooov", "r1": "ov",
     "r2": "oovv", "D1": "ov", "D2": "oovv", "t1": "ov", "t2": "oovv",
 }
+
+
+def device_count():
+    """Number of HIP devices this process sees (afesp_device_count; 0 without a GPU)."""
+    return int(load_library().afesp_device_count())
 
 
 class Engine:
@@ -275,6 +281,10 @@ class Engine:
         out = np.zeros(4)
         self._chk(self.L.afesp_arena_stats(self.h, out))
         return dict(driver_calls=int(out[0]), reuse_hits=int(out[1]), idle_gb=out[2] / 1e9, live_gb=out[3] / 1e9)
+
+    def ccsd_set_split(self, mode):
+        """1: split the CCSD iteration over the ranks, 0: replicas, -1: as AFESP_CC_SHARD says (default replicas)."""
+        self._chk(self.L.afesp_ccsd_set_split(self.h, int(mode)))
 
     def ccsd_is_split(self):
         f = C.c_int()

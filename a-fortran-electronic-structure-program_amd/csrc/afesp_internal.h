@@ -69,6 +69,7 @@ struct Arena {
 struct Context {
     int device = 0;
     Comm* comm = nullptr;                 // rank-to-rank sums (comm.h); null = single rank
+    int cc_split_mode = -1;               // afesp_ccsd_set_split: 1 split the CCSD iteration over the ranks, 0 replicas, -1 environment (default off)
     int test_throw = 0;                   // test hook (afesp_test_inject): the next laned amplitude update throws
     hipStream_t stream = nullptr;
     Arena arena;                          // every device allocation of the context goes through it
@@ -132,6 +133,7 @@ struct Context {
     int64_t scratch_epoch = 0;            // bumped whenever cached scratch buffers are freed (captured graphs go stale)
     Tensor tensor(std::initializer_list<int64_t> dims);
     void sync();
+    void quiesce();                       // every lane and the main stream idle (before memory returns to the arena, after an error)
     ~Context();
 };
 

@@ -47,14 +47,26 @@ template <class F>
 int guarded(afesp_ctx* c, F&& f)
 {
     if (!c) return 1;
+    // A body that threw may have forked lanes without joining them: before the caller can free or re-initialise anything, every
+    // lane is idle and lane 0 is the one in use again.
+    auto settle = [&]() {
+        Context& cx = c->cx;
+        if (!cx.lanes.empty()) {
+            cx.quiesce();
+            cx.use_lane(0);
+            cx.marks_used = 0;
+        }
+    };
     try {
         f();
         return 0;
     } catch (const Error& e) {
         c->cx.last_error = e.what();
+        settle();
         return e.code ? e.code : 1;
     } catch (const std::exception& e) {
         c->cx.last_error = e.what();
+        settle();
         return 1;
     }
 }
@@ -1148,6 +1160,14 @@ int afesp_ccsd_is_split(afesp_ctx* ctx, int* split)
         if (!ctx->cc.ready || !split) throw Error(1, "afesp_ccsd_is_split: no CCSD state");
         ccsd_refresh_sharding(ctx->cx, ctx->cc);
         *split = ctx->cc.sharded ? 1 : 0;
+    });
+}
+
+int afesp_ccsd_set_split(afesp_ctx* ctx, int mode)
+{
+    return guarded(ctx, [&] {
+        if (mode < -1 || mode > 1) throw Error(1, "afesp_ccsd_set_split: mode is -1 (environment), 0 (replicas) or 1 (split)");
+        ctx->cx.cc_split_mode = mode;
     });
 }
 

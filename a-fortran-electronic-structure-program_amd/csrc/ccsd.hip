@@ -176,15 +176,19 @@ static bool lanes_pay(const CCState& s)
 // index only, into buffers that start from zero; ONE all-reduce of [PP | r2_sh] then gives every rank the same residual
 // and every rank applies the same update: amplitudes, DIIS history and energies stay replicated and identical.  The slice
 // index is external to both the intermediate and the product that consumes it, so a rank builds exactly the part of
-// I_ovov / I_voov it needs itself.  Everything else of the iteration (8 ms) is replicated.  Small systems stay
-// replicated (their iteration is launch-bound); AFESP_CC_SHARD=1 / 0 forces the split on / off.
+// I_ovov / I_voov it needs itself.  Everything else of the iteration (8 ms) is replicated.
+// The split is OPT-IN: afesp_ccsd_set_split(ctx, 1) or AFESP_CC_SHARD=1 (0 / AFESP_CC_SHARD=0: replicas, whatever the other
+// says).  A communicator alone does not change the algorithm of the iteration -- the 192 MB in-place all-reduce on the engine
+// stream is a different path from the scalar sum of (T), and a caller should have checked it on its nodes (bench.py does: one
+// iteration both ways from the same amplitudes) before timing or trusting it.
 void ccsd_refresh_sharding(Context& cx, CCState& s)
 {
-    static const int force = [] { const char* e = getenv("AFESP_CC_SHARD"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    static const int env = [] { const char* e = getenv("AFESP_CC_SHARD"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     const int world = cx.comm ? cx.comm->world : 1;
     s.sh_world = world;
     s.sh_rank = cx.comm ? cx.comm->rank : 0;
-    s.sharded = world > 1 && (force == 1 || (force != 0 && s.t2.size() > ((int64_t)1 << 20)));
+    const bool on = cx.cc_split_mode >= 0 ? cx.cc_split_mode == 1 : env == 1;
+    s.sharded = world > 1 && on && env != 0;
 }
 
 static Tensor slice_axis(Tensor t, int axis, int64_t lo, int64_t hi)

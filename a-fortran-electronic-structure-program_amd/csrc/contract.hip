@@ -110,10 +110,19 @@ double* Context::scratch(const std::string& name, int64_t n)
     cache[name] = {p, bytes};
     return (double*)p;
 }
+// Blocks given back to the arena are handed out again at once (and alloc() memsets them asynchronously), so nothing queued on
+// ANY lane may still touch them: a laned body that threw has forked its lanes without joining them.  These are cold paths.
+void Context::quiesce()
+{
+    for (Lane& l : lanes)
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+    if (stream) (void)hipStreamSynchronize(stream);
+    (void)hipGetLastError();
+}
 void Context::drop_scratch()
 {
     ++scratch_epoch;
-    if (stream) (void)hipStreamSynchronize(stream);
+    quiesce();
     for (auto& kv : cache) arena.put(kv.second.first);
     cache.clear();
 }
@@ -122,7 +131,7 @@ void Context::drop_scratch(const std::string& prefix)
     bool any = false;
     for (auto it = cache.begin(); it != cache.end();) {
         if (it->first.compare(0, prefix.size(), prefix) == 0) {
-            if (!any && stream) (void)hipStreamSynchronize(stream);
+            if (!any) quiesce();
             any = true;
             arena.put(it->second.first);
             it = cache.erase(it);
@@ -138,7 +147,7 @@ void Context::release(void* p)
     auto it = std::find(owned.begin(), owned.end(), p);
     if (it != owned.end()) {
         owned.erase(it);
-        (void)hipStreamSynchronize(stream);
+        quiesce();
         arena.put(p);
     }
 }

@@ -362,6 +362,8 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         unsigned long long* d = g_tg_stamp + ((size_t)blockIdx.x * 4 + wave) * 8;
         d[0] = __builtin_amdgcn_s_memtime() - st_t0;
         d[1] = st_bar; d[2] = st_epi; d[3] = st_steps; d[4] = st_tiles; d[5] = st_max;
+        d[6] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID[3:0]
+        d[7] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);    // HW_REG_HW_ID[15:0]: wave, simd, pipe, cu, sh, se
     }
 #endif
 #undef TG_MF

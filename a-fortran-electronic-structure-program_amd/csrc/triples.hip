@@ -493,6 +493,21 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
     }
     // where block b of the pool lives (element offset from the pool base): one allocation for the completely renormalised
     // variant (its second pool mirrors the first), pieces of idle memory otherwise
+    // The plain evaluation keeps its pool as the pieces "t_xpool0..", the completely renormalised one as "t_xpool" + "t_mpool":
+    // whichever this plan does not use goes back to the arena (a plain (T) followed by a CR one held three pools, ~72 GB at
+    // o = 20, v = 200, and more where the arena has nothing idle left to trim).
+    if (cr) {
+        if (cx.cache.count("t_xpool0")) cx.drop_scratch("t_xpool");
+    } else {
+        cx.drop_scratch("t_mpool");
+        if (cx.cache.count("t_xpool")) {
+            // (exactly that name: the prefix would take the pieces along)
+            cx.quiesce();
+            cx.arena.put(cx.cache["t_xpool"].first);
+            cx.cache.erase("t_xpool");
+            ++cx.scratch_epoch;
+        }
+    }
     std::vector<int64_t> blk_off;
     if (cr || getenv("AFESP_T_ONE_POOL")) {
         for (int64_t b = 0; b < max_blocks; ++b) blk_off.push_back(b * vp3);

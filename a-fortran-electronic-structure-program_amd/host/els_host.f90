@@ -399,7 +399,9 @@ program els_amd
    integer :: iter, device, rank, world, transport, sb
    integer(c_int64_t), allocatable :: bounds(:)
    integer(c_int64_t) :: t_lo, t_hi
-   real(dp) :: red(8)
+   real(dp) :: red(9)
+   character(256) :: my_error
+   integer :: rc_mine
    character(len=512) :: comm_file
    logical :: scf_ok, cc_ok, compat, have_ctx
    integer(c_int64_t) :: nlines
@@ -428,6 +430,9 @@ program els_amd
    write (out, '(1X, A)') 'A Fortran Electronic Structure Programme (AFESP) -- MI355X engine host'
    write (out, '(1X, 64("="))')
    call read_config(cfg)
+   if (rank > 0) then   ! every rank runs the replicated stages in the same directory: the files are rank 0's to write
+      cfg%scf_write_guess = .false.; cfg%write_fcidump = .false.
+   end if
    ! Post-HF levels: the engine context exists from the start, and the engine reads eri.dat (the packed AO integrals
    ! then stay on the device for the AO->MO transform; the host copy feeds the SCF)
    have_ctx = cfg%level >= LEVEL_MP2
@@ -537,7 +542,16 @@ program els_amd
             t_hi = afesp_ccsd_so_t_ntriples(int(mol%nel, c_int64_t))     ! i<j<k triples, an even split over the ranks
             t_lo = (int(rank, c_int64_t)*t_hi)/world; t_hi = (int(rank + 1, c_int64_t)*t_hi)/world
             rc = afesp_ccsd_so_t(ctx, t_lo, t_hi, tq(1))
-            if (rc == 0 .and. world > 1) rc = afesp_allreduce_sum(ctx, tq, 1_c_int64_t)
+            if (world > 1) then
+               ! a rank whose shard failed still enters the sum -- with a flag in it -- so that every rank leaves the collective
+               ! and all of them stop together (a rank that stopped before the all-reduce would leave the others in it for ever)
+               rc_mine = rc; my_error = ''
+               if (rc_mine /= 0) then; my_error = afesp_error_text(ctx); tq(1) = 0.0_dp; end if
+               tq(2) = merge(1.0_dp, 0.0_dp, rc_mine /= 0)
+               rc = afesp_allreduce_sum(ctx, tq, 2_c_int64_t)
+               if (rc_mine /= 0) call fail('ccsd::do_ccsd_t_spinorb', trim(my_error))
+               if (rc == 0 .and. tq(2) > 0.5_dp) call fail('ccsd::do_ccsd_t_spinorb', 'the (T) shard of another rank failed')
+            end if
             if (rc /= 0) call fail('ccsd::do_ccsd_t_spinorb', afesp_error_text(ctx))
             e_pt = e_ccsd + tq(1)
             e_highest = e_pt
@@ -614,11 +628,19 @@ program els_amd
             else                               ! plain types: no y, no D sums (reference src/ccsd.f90:2181-2185)
                rc = afesp_ccsd_t_plain(ctx, t_lo, t_hi, tq(1:2))
             end if
-            if (rc == 0 .and. world > 1) then  ! the reference's reduction(+: ...) over threads, src/ccsd.f90:2091
-               rc = afesp_ccsd_t_block_size(ctx, int(mol%nocc, c_int64_t), int(mol%nvirt, c_int64_t), &
-                                            merge(1_c_int, 0_c_int, cfg%comp_renorm), sb)
-               red(1:6) = tq; red(7) = real(sb, dp); red(8) = real(sb, dp)**2
-               if (rc == 0) rc = afesp_allreduce_sum(ctx, red, 8_c_int64_t)
+            if (world > 1) then                ! the reference's reduction(+: ...) over threads, src/ccsd.f90:2091
+               ! Every rank enters the sum, also one whose shard failed: its failure rides along as a flag, so that all ranks
+               ! leave the collective and stop together (ncclAllReduce has no time-out: ranks left waiting would wait for ever).
+               rc_mine = rc; my_error = ''
+               if (rc_mine /= 0) then; my_error = afesp_error_text(ctx); tq = 0.0_dp; end if
+               sb = 0
+               if (rc_mine == 0) rc_mine = afesp_ccsd_t_block_size(ctx, int(mol%nocc, c_int64_t), int(mol%nvirt, c_int64_t), &
+                                                                   merge(1_c_int, 0_c_int, cfg%comp_renorm), sb)
+               if (rc_mine /= 0 .and. len_trim(my_error) == 0) my_error = afesp_error_text(ctx)
+               red(1:6) = tq; red(7) = real(sb, dp); red(8) = real(sb, dp)**2; red(9) = merge(1.0_dp, 0.0_dp, rc_mine /= 0)
+               rc = afesp_allreduce_sum(ctx, red, 9_c_int64_t)
+               if (rc_mine /= 0) call fail('ccsd::do_ccsd_t_spatial', trim(my_error))
+               if (rc == 0 .and. red(9) > 0.5_dp) call fail('ccsd::do_ccsd_t_spatial', 'the (T) shard of another rank failed')
                if (rc == 0 .and. abs(red(8)*world - red(7)**2) > 0.5_dp) &
                   call fail('ccsd::do_ccsd_t_spatial', 'the ranks enumerate the triples in different block sizes (unequal devices or AFESP_T_* settings)')
                tq = red(1:6)

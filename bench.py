@@ -197,7 +197,7 @@ PUBLISHED = {
 }
 
 
-def spinorb_h2o_tz(rank, world, local, dist, cdev, torch):
+def spinorb_h2o_tz(rank, world, local, dist, cdev, torch, backend, jobdir):
     """The configuration of the reference's only published H2O/cc-pVTZ timings: CCSD(T)_spinorb, 10 electrons in 58 spatial
     orbitals (o = 10, v = 106 spin orbitals), here on synthetic integrals of that shape (its eri.dat is not bundled).  The
     i<j<k triples of (T) are split evenly over the ranks, one all-reduce of the scalar."""
@@ -208,6 +208,7 @@ def spinorb_h2o_tz(rank, world, local, dist, cdev, torch):
     e = np.concatenate([-2.0 + np.arange(o) / (o - 1), 1.0 + 2.0 * np.arange(n - o) / (n - o - 1)])
     eri = 0.02 * (2.0 * np.random.default_rng(1).random(inputs.neri(n)) - 1.0)
     eng = Engine(local)
+    red = Reducer(eng, rank, world, dist, cdev, torch, backend, jobdir)   # the product's own all-reduce (afesp_allreduce_sum)
     eng.init_cc_spinorb(n, nel, e, eri, 8)
     eng.so_energy()
     per_iter = []
@@ -221,18 +222,16 @@ def spinorb_h2o_tz(rank, world, local, dist, cdev, torch):
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    et = np.array([eng.do_ccsd_t_spinorb(lo, hi)])
-    if dist is not None:
-        red = torch.from_numpy(et).to(cdev)
-        dist.all_reduce(red)
-        et = red.cpu().numpy()
+    et = red.sum(np.array([eng.do_ccsd_t_spinorb(lo, hi)]))
     t_t = time.perf_counter() - t0
+    red.close()
     eng.close()
     return {"nocc_spin": nel, "nvirt_spin": 2 * n - nel, "ccsd_iter_s": float(np.median(per_iter)), "t_s": t_t, "e_t": float(et[0]),
+            "t_allreduce": red.kind, "integrals": "synthetic (the reference tree has no eri.dat for H2O/cc-pVTZ: .MISSING_LARGE_BLOBS)",
             "published_reference_s": PUBLISHED["h2o-cc-pvtz_spinorb"]}
 
 
-def real_molecule(name, rank, world, local, dist, cdev, torch):
+def real_molecule(name, rank, world, local, dist, cdev, torch, backend, jobdir):
     """BASELINE configs 3 / 4: the bundled N2 / F2 cc-pVDZ inputs (tests/golden, copies of the reference's sample_data) through
     the whole path -- RHF on the host, AO->MO + MP2, CCSD to convergence, (T) with the (i<=j<=k) triples sharded over the
     ranks and one all-reduce -- with the energies checked against the reference's own outputs."""
@@ -243,6 +242,7 @@ def real_molecule(name, rank, world, local, dist, cdev, torch):
     n, o = ints.nbasis, ints.nel // 2
     v = n - o
     eng = Engine(local)
+    red = Reducer(eng, rank, world, dist, cdev, torch, backend, jobdir)   # the product's own all-reduce (afesp_allreduce_sum)
     t0 = time.perf_counter()
     e_mp2, _ = eng.do_mp2_spatial(n, o, res.canon_coeff, res.canon_levels, ints.eri, want_eri_mo=False)
     t_ao = time.perf_counter() - t0
@@ -267,11 +267,7 @@ def real_molecule(name, rank, world, local, dist, cdev, torch):
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    part = np.asarray(eng.do_ccsd_t_spatial(lo, hi), dtype=np.float64)
-    if dist is not None:
-        red = torch.from_numpy(part.copy()).to(cdev)
-        dist.all_reduce(red)
-        part = red.cpu().numpy()
+    part = red.sum(np.asarray(eng.do_ccsd_t_spatial(lo, hi), dtype=np.float64))
     t_t = time.perf_counter() - t0
     # the bundled outputs are CRCCSD(T)_spatial runs: also time what they timed (moments + the completely renormalised (T))
     clo, chi = eng.shard_bounds(world, cr=True)[rank:rank + 2]
@@ -281,12 +277,9 @@ def real_molecule(name, rank, world, local, dist, cdev, torch):
         dist.barrier()
     t0 = time.perf_counter()
     eng.build_cr_intermediates()
-    crp = np.asarray(eng.do_ccsd_t_spatial_cr(clo, chi), dtype=np.float64)
-    if dist is not None:
-        red = torch.from_numpy(crp.copy()).to(cdev)
-        dist.all_reduce(red)
-        crp = red.cpu().numpy()
+    crp = red.sum(np.asarray(eng.do_ccsd_t_spatial_cr(clo, chi), dtype=np.float64))
     t_cr = time.perf_counter() - t0
+    red.close()
     eng.close()
     ec = float(en[nit])
     got = {"mp2_corr": e_mp2, "ccsd_corr": ec, "ccsd_bt_corr": ec + part[0], "ccsd_pt_corr": ec + part[1],
@@ -294,6 +287,7 @@ def real_molecule(name, rank, world, local, dist, cdev, torch):
     return {"nocc": o, "nvirt": v, "ao2mo_mp2_s": t_ao, "ccsd_iterations": int(nit), "ccsd_solve_s": t_cc,
             "ccsd_iter_s": float(np.median(per_iter)), "ccsd_iter_s_first_three": [float(x) for x in per_iter[:3]],
             "t_s": t_t, "cr_t_s": t_cr, "cr_t_vs_t_max_abs_diff": float(np.max(np.abs(crp[:4] - part[:4]))),
+            "t_allreduce": red.kind, "t_shard": [int(lo), int(hi)],
             "published_reference_s": PUBLISHED[name], "energies": {k: float(x) for k, x in got.items()},
             "max_abs_error_vs_reference_Eh": max(abs(float(got[k]) - gold[k]) for k in got)}
 
@@ -440,7 +434,39 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             dist.barrier()
         torch.cuda.synchronize()
 
-    acc = {"iter": 0.0, "trip": 0.0, "last": None}
+    # The CCSD iteration split over the ranks (ring products + pp-ladder, one all-reduce of [PP | residual]) is opt-in in the
+    # library.  Here it is switched on for systems whose iteration is not launch-bound -- AFTER one iteration has been run both
+    # ways from the same amplitudes on these very ranks and the two energies agree; otherwise the iterations stay replicas
+    # and the line says why.
+    split_check = "not applicable (one rank)" if world == 1 else "not attempted"
+    if world > 1 and red.own and o * o * v * v > (1 << 20) and os.environ.get("AFESP_CC_SHARD", "1") != "0":
+        ok, why = 1.0, ""
+        try:
+            t1s, t2s = eng.amplitudes()
+            eng.ccsd_set_split(1)
+            e_split = eng.ccsd_iterate()[0]
+            eng.ccsd_set_split(0)
+            eng.set_amplitudes(t1s, t2s)
+            e_repl = eng.ccsd_iterate()[0]
+            eng.set_amplitudes(t1s, t2s)
+            if not abs(e_split - e_repl) <= 1e-10 * max(1.0, abs(e_repl)):
+                ok, why = 0.0, f"energies differ: split {e_split!r}, replicas {e_repl!r}"
+        except Exception as exc:   # noqa: BLE001 -- a failing split must not lose the measurement
+            ok, why = 0.0, f"{type(exc).__name__}: {exc}"
+        agree = red.sum([ok])
+        if int(round(agree[0])) == world:
+            eng.ccsd_set_split(1)
+            split_check = "one iteration split == replicas to 1e-10 on every rank: split enabled"
+        else:
+            try:
+                eng.ccsd_set_split(0)
+            except Exception:   # noqa: BLE001
+                pass
+            split_check = f"failed on {world - int(round(agree[0]))} rank(s), iterations stay replicas" + (f" (this rank: {why})" if why else "")
+    elif world > 1:
+        split_check = "not attempted (launch-bound system, no product communicator, or AFESP_CC_SHARD=0)"
+
+    acc = {"iter": 0.0, "trip": 0.0, "shard": 0.0, "allred": 0.0, "last": None}
 
     def step(timed):
         t0 = time.perf_counter()
@@ -448,12 +474,15 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
         eng.ccsd_diis()
         t1 = time.perf_counter()
         # the benchmark configurations are CCSD(T)_spatial: E[T] and E(T) (the renormalised types' y / D sums are extra)
-        part = eng.do_ccsd_t_spatial_plain(lo, hi)
+        part = eng.do_ccsd_t_spatial_plain(lo, hi)      # returns the partial sums to the host: this rank's shard is finished
+        t1b = time.perf_counter()
         acc["last"] = red.sum(part)                     # the only collective of the path: 2 doubles over xGMI
         t2 = time.perf_counter()
         if timed:
             acc["iter"] += t1 - t0
             acc["trip"] += t2 - t1
+            acc["shard"] += t1b - t1                    # (the all-reduce also absorbs the wait for the slowest rank)
+            acc["allred"] += t2 - t1b
 
     for _ in range(warmup):
         step(False)
@@ -465,6 +494,13 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
     barrier()
     elapsed = time.perf_counter() - t0
     prof = eng.profile(False)
+    # per rank, for the record of an N > 1 run: this rank's CCSD iteration, its (T) shard and the all-reduce behind it
+    mine = [acc["iter"] / steps * 1e3, acc["shard"] / steps * 1e3, acc["allred"] / steps * 1e6, float(hi - lo)]
+    per_rank = None
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
     tt = torch.tensor([elapsed, acc["iter"], acc["trip"]], dtype=torch.float64, device=cdev)
     ex = torch.tensor([prof["gemm_flop"]], dtype=torch.float64, device=cdev)   # executed (T) multiply-adds of this rank's shard
     if dist is not None:
@@ -495,7 +531,15 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             "rates_note": "value / fraction_of_mfma_peak: SURVEY 8(d) algorithmic count ((T) = [o(o+1)(o+2)/6] 12 v^3 (v+o)); "
                           "value_executed / fraction_of_mfma_peak_executed: multiply-adds the kernels issue, all ranks",
             "e_t": [float(x) for x in acc["last"]], "rccl_ranks": rccl_ranks, "t_allreduce": red.kind,
+            "ccsd_split": bool(split), "ccsd_split_check": split_check,
         }
+        if per_rank:
+            res["per_rank"] = {"ccsd_iter_ms": [round(r[0], 4) for r in per_rank], "t_shard_ms": [round(r[1], 4) for r in per_rank],
+                               "allreduce_us_incl_wait_for_slowest_rank": [round(r[2], 1) for r in per_rank],
+                               "t_shard_triples": [int(r[3]) for r in per_rank]}
+            res["t_shard_ms_min"] = min(r[1] for r in per_rank)
+            res["t_shard_ms_max"] = max(r[1] for r in per_rank)
+            res["allreduce_us_min_over_ranks"] = min(r[2] for r in per_rank)   # the last rank to arrive waits for nobody: ~ the collective itself
         if with_roofline:
             # Dominant kernel: the (T) GEMM (gett_kernel, X = tt^T vt over kappa = d + l, K = v+o), timed over the timed
             # region with HIP events on the engine's stream (csrc/triples.hip).  achieved = EXECUTED flop per launch
@@ -640,9 +684,9 @@ def main():
             # for the engine to have captured the iteration's graph (it waits for 40 calls: a real solve is shorter)
             others["h2o_tz_same_run"] = measure(args, "h2o_tz", 50, 45, rank, world, local, dist, cdev, torch, jobdir,
                                                 with_roofline=True, with_cpu=True)
-        others["real_molecules_same_run"] = {name: real_molecule(name, rank, world, local, dist, cdev, torch)
+        others["real_molecules_same_run"] = {name: real_molecule(name, rank, world, local, dist, cdev, torch, args.backend, jobdir)
                                              for name in ("n2-cc-pvdz", "f2-cc-pvdz")}
-        others["spinorb_h2o_tz_same_run"] = spinorb_h2o_tz(rank, world, local, dist, cdev, torch)
+        others["spinorb_h2o_tz_same_run"] = spinorb_h2o_tz(rank, world, local, dist, cdev, torch, args.backend, jobdir)
     if rank == 0:
         line = {"metric": "CCSD iter wall-time (s) + (T) wall-time (s); fp64 TFLOP/s vs MFMA peak",
                 "value": res.pop("value"), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -651,7 +695,9 @@ def main():
         line.update(res)
         for key, val in others.items():
             if key == "h2o_tz_same_run" and val is not None:
-                val = dict(val, unit="TFLOP/s", steps=50, warmup=45)
+                val = dict(val, unit="TFLOP/s", steps=50, warmup=45,
+                           integrals="synthetic hashed ERIs of the H2O/cc-pVTZ shape: the reference tree has no eri.dat for BASELINE "
+                                     "config 2 (.MISSING_LARGE_BLOBS), so its shipped energies cannot be reproduced")
             line[key] = val
         print(json.dumps(line))
     if dist is not None:

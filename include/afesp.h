@@ -165,8 +165,11 @@ int afesp_comm_init(afesp_ctx* ctx, int rank, int world, int transport, const ch
 int afesp_comm_destroy(afesp_ctx* ctx);
 /* in-place sum over the ranks of n host doubles (every rank passes the same n) */
 int afesp_allreduce_sum(afesp_ctx* ctx, double* inout, int64_t n);
-/* *split = 1 if the CCSD iterations of this context run split over the ranks (world > 1 and o^2 v^2 > 2^20 elements, or
- * AFESP_CC_SHARD=1; AFESP_CC_SHARD=0 keeps replicas) */
+/* The CCSD iteration's o^3 v^3 ring products and pp-ladder split over the ranks of the communicator, one all-reduce of
+ * [PP | partial residual] per iteration (replaces nothing in the reference: its iteration is one process, src/ccsd.f90:340-395).
+ * Opt-in: mode 1 = split, 0 = replicas, -1 = as the environment says (AFESP_CC_SHARD=1 splits; default replicas;
+ * AFESP_CC_SHARD=0 keeps replicas whatever mode says).  *split of afesp_ccsd_is_split = what the next iteration will do. */
+int afesp_ccsd_set_split(afesp_ctx* ctx, int mode);
 int afesp_ccsd_is_split(afesp_ctx* ctx, int* split);
 /* Occupied block size of the (T) triple enumeration on this rank's device (it depends on the device memory size and on the
  * AFESP_T_POOL_GIB / AFESP_T_SPLIT_TILES environment): ranks whose values differ would enumerate different flat orders, so

@@ -22,7 +22,8 @@ def main():
     si, ints, res, gold = molecules.load(name)
     n, o = ints.nbasis, ints.nel // 2
     v = n - o
-    eng = capi.Engine(0)
+    # one GPU per rank under RCCL (it refuses two ranks on one device); the host transport's ranks share device 0
+    eng = capi.Engine(rank % max(1, capi.device_count()) if transport == "rccl" else 0)
     eng.comm_init(rank, world, capi.COMM_HOST if transport == "host" else capi.COMM_RCCL, boot)
     ones = eng.allreduce_sum([1.0, float(rank)])
     e_mp2, _ = eng.do_mp2_spatial(n, o, res.canon_coeff, res.canon_levels, ints.eri, want_eri_mo=False)

@@ -477,6 +477,31 @@ def test_block_pool_in_pieces_of_idle_memory_equals_one_allocation(monkeypatch):
     assert np.max(np.abs(out["pieces"] - ref)) < 1e-10 * max(1.0, np.max(np.abs(ref)))
 
 
+def test_plain_and_renormalised_triples_do_not_keep_both_block_pools():
+    """A plain (T) followed by a completely renormalised one on the same state (what bench.py and the rank tests do) must not keep
+    the plain pool's pieces beside the two CR pools, and going back gives the CR pools back: the memory the context holds
+    handed out stays that of the variant in use."""
+    from afesp_amd.capi import Engine
+    o, v = 8, 64
+    with Engine(0) as eng:
+        eng.synthetic_init(o, v, 0.02, 4711, 6)
+        eng.ccsd_energy()
+        for _ in range(2):
+            eng.ccsd_iterate(); eng.ccsd_diis()
+        plain = eng.do_ccsd_t_spatial()
+        live_plain = eng.arena_stats()["live_gb"]
+        eng.build_cr_intermediates()
+        live_cr_state = eng.arena_stats()["live_gb"]          # (the CR intermediates themselves)
+        cr = eng.do_ccsd_t_spatial_cr()
+        live_cr = eng.arena_stats()["live_gb"]
+        pool_gb = 8 * 8 * 9 // 2 * (8 ** 3 * 512) * 8 / 1e9   # o x o(o+1)/2 blocks of 8^3 cubes: one pool of this system
+        assert live_cr - live_cr_state < 1.25 * pool_gb + 0.05, (live_plain, live_cr_state, live_cr)   # two pools instead of one, not three
+        again = eng.do_ccsd_t_spatial()
+        assert np.array_equal(again, plain)
+        assert eng.arena_stats()["live_gb"] <= live_cr_state + 0.05
+        assert np.max(np.abs(cr[:4] - plain[:4])) < 1e-12 * max(1.0, np.max(np.abs(plain)))
+
+
 def test_iteration_graph_survives_other_work_in_the_same_context(eng):
     """The small-system iteration is replayed as a captured graph; (T) calls, tensor downloads and a spin-orbital solve in
     the same context (which frees cached scratch buffers) must not leave it replaying stale buffers."""

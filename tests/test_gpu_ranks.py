@@ -28,11 +28,23 @@ def _run_ranks(tmp_path, world, name, transport="host", env=None):
                                         boot, name, str(out)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                                        env=dict(os.environ, **(env or {}))), out))
     res = []
-    for p, out in procs:
-        log, _ = p.communicate(timeout=600)
-        assert p.returncode == 0, log
-        res.append(json.load(open(out)))
+    try:
+        for p, out in procs:
+            log, _ = p.communicate(timeout=600)
+            assert p.returncode == 0, log
+            res.append(json.load(open(out)))
+    finally:
+        # a rank that failed (or timed out) leaves the others waiting for it in a collective: none may outlive the test
+        for p, _ in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
     return res
+
+
+def _gpus():
+    from afesp_amd import capi
+    return capi.device_count()
 
 
 @pytest.mark.parametrize("name,world", [("f2-cc-pvdz", 2), ("n2-cc-pvdz", 3)])
@@ -78,6 +90,50 @@ def test_ccsd_iteration_split_over_ranks(tmp_path, name, world, pp_sym):
     plain = _run_ranks(tmp_path, world, name, env={"AFESP_CC_SHARD": "0", "AFESP_PP_SYM": pp_sym})
     assert plain[0]["split"] is False
     assert np.max(np.abs(np.array(plain[0]["en"]) - np.array(res[0]["en"]))) < 1e-11   # split == replicas
+
+
+@pytest.mark.parametrize("name,world", [("f2-cc-pvdz", 2)])
+def test_engine_ranks_over_rccl(tmp_path, name, world):
+    """The same two-rank run over the RCCL transport (bootstrap file for the unique id, ncclCommInitRank, ncclAllReduce on the
+    engine stream), one GPU per rank: needs a box with at least two GPUs, skipped on the one-GPU test box."""
+    if _gpus() < world:
+        pytest.skip(f"needs {world} GPUs for RCCL ranks (this box has {_gpus()})")
+    res = _run_ranks(tmp_path, world, name, transport="rccl")
+    g = molecules.SURVEY_GOLD[name]
+    for r in res:
+        assert r["ones"] == [float(world), float(sum(range(world)))]
+        assert r["total"] == res[0]["total"]
+        assert abs(r["e_ccsd"] + r["total"][1] - g["ccsd_pt_corr"]) < 1e-8
+    split = _run_ranks(tmp_path, world, name, transport="rccl", env={"AFESP_CC_SHARD": "1"})
+    _, _, _, gold = molecules.load(name)
+    for r in split:
+        assert r["split"] is True
+        for (git, ge, gde, grms) in gold["cc_iters"]:
+            assert abs(r["en"][git] - ge) < 1e-10
+        assert r["en"] == split[0]["en"]
+
+
+def test_bench_two_gpus_over_rccl():
+    """`python bench.py --gpus 2` (nccl backend = RCCL) on a box with two GPUs: the product's all-reduce carries every leg, the
+    line records the per-rank shard times and whether the iteration was split.  Skipped on the one-GPU test box."""
+    if _gpus() < 2:
+        pytest.skip(f"needs 2 GPUs (this box has {_gpus()})")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "n2", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500)
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    assert "ncclAllReduce" in line["t_allreduce"]
+    assert len(line["per_rank"]["t_shard_ms"]) == 2
+    for leg in line["real_molecules_same_run"].values():
+        assert "ncclAllReduce" in leg["t_allreduce"] and leg["max_abs_error_vs_reference_Eh"] < 1e-8
+
+
+def test_split_is_opt_in(tmp_path):
+    """A communicator alone does not change the algorithm of the CCSD iteration: without AFESP_CC_SHARD=1 (or
+    afesp_ccsd_set_split) two ranks run replicas."""
+    res = _run_ranks(tmp_path, 2, "f2-cc-pvdz")
+    assert all(r["split"] is False for r in res)
 
 
 def test_rccl_transport_with_one_rank():
@@ -136,6 +192,10 @@ def test_bench_gpus_flag_spawns_ranks(tmp_path):
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
     assert "afesp_allreduce_sum" in line["t_allreduce"]
     assert line["value"] > 0 and line["value_executed"] > 0
+    # the record of a multi-rank run can be audited per rank
+    assert len(line["per_rank"]["t_shard_ms"]) == 2 and len(line["per_rank"]["allreduce_us_incl_wait_for_slowest_rank"]) == 2
+    assert line["t_shard_ms_min"] <= line["t_shard_ms_max"] and sum(line["per_rank"]["t_shard_triples"]) == line["config"]["triples"]
+    assert line["ccsd_split"] is False and "launch-bound" in line["ccsd_split_check"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "n2", "--steps", "3", "--warmup", "1", "--no-extra",
                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stdout + one.stderr

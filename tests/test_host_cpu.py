@@ -119,3 +119,23 @@ def test_bench_flop_counts_match_the_survey_table():
     assert abs(bench.flops_t_sym(20, 200) - 3.25e13) < 2e-3 * 3.25e13
     # the two cheaper evaluations of the ladder are counted as what they execute
     assert bench.flops_iter(20, 200) < ref_iter(20, 200)
+
+
+def test_multi_rank_launcher_ends_the_job_when_a_rank_fails(tmp_path):
+    """host/els_mgpu.sh: a failing rank ends the job -- the other ranks are terminated, the exit status is non-zero, nothing
+    is left running (here every rank fails at once: there is no eri.dat)."""
+    import shutil
+    import subprocess
+    import time
+    host = os.path.join(ROOT, "a-fortran-electronic-structure-program_amd", "host")
+    if not os.path.exists(os.path.join(host, "els_amd")):
+        pytest.skip("els_amd not built")
+    src = os.path.join(ROOT, "tests", "golden", "f2-cc-pvdz")
+    for f in ("s.dat", "t.dat", "v.dat", "geom.dat", "els.in"):
+        shutil.copy(os.path.join(src, f), tmp_path)
+    t0 = time.time()
+    res = subprocess.run([os.path.join(host, "els_mgpu.sh"), "3", "host"], cwd=tmp_path, capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, AFESP_JOB_TIMEOUT="60"))
+    assert res.returncode != 0
+    assert "a rank failed" in res.stderr
+    assert time.time() - t0 < 60

@@ -63,6 +63,10 @@ static int run_big(int argc, char** argv)
     }
     printf("stamps over %d waves: cycles per step %.0f (MFMA floor 8192 at two waves per SIMD), of which barrier %.0f; per tile: epilogue %.0f; longest barrier %.0f\n",
            n, tot / steps, bar / steps, epi / tiles, mx);
+    printf("  workgroup -> XCC_ID (HW_ID >> 8):");
+    for (int b = 0; b < 24; ++b) printf(" %d:%llu(%llx)", b, st[((size_t)b * 4) * 8 + 6], st[((size_t)b * 4) * 8 + 7] >> 8);
+    printf(" ... 256:%llu 257:%llu 264:%llu\n", st[((size_t)256 * 4) * 8 + 6], st[((size_t)257 * 4) * 8 + 6], st[((size_t)264 * 4) * 8 + 6]);
+    { int bad = 0; for (int b = 0; b < 512; ++b) if (st[((size_t)b * 4) * 8 + 3] && st[((size_t)b * 4) * 8 + 6] != st[((size_t)(b & 7) * 4) * 8 + 6]) ++bad; printf("  workgroups whose XCC differs from that of workgroup b & 7: %d\n", bad); }
     // distribution of per-wave barrier share
     for (int w = 0; w < 4; ++w) {
         double b2 = 0, s2 = 0;
