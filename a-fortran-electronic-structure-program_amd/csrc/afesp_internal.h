@@ -131,6 +131,12 @@ struct Context {
     void drop_scratch();
     void drop_scratch(const std::string& prefix);   // only the cached buffers whose name starts with `prefix`
     int64_t scratch_epoch = 0;            // bumped whenever cached scratch buffers are freed (captured graphs go stale)
+    // what the (T) operand copies in the cached buffers t_vt / t_tt / t_vs / t_ts (/ t_vt2 / t_tt2) were built from: state, its
+    // amplitude epoch, the scratch epoch, whether ts is there, the CR epoch (-1: not built)
+    int64_t amp_clock = 0;                // source of CCState::amp_epoch / cr_epoch
+    const void* t_ops_owner = nullptr;
+    int64_t t_ops_amp = -1, t_ops_scratch = -1, t_ops_cr = -1;
+    bool t_ops_ts = false;
     Tensor tensor(std::initializer_list<int64_t> dims);
     void sync();
     void quiesce();                       // every lane and the main stream idle (before memory returns to the arena, after an error)

@@ -387,6 +387,7 @@ int afesp_ccsd_update_intermediates(afesp_ctx* ctx)
 int afesp_ccsd_update_amplitudes(afesp_ctx* ctx)
 {
     return guarded(ctx, [&] {
+        ctx->cc.amp_epoch = ++ctx->cx.amp_clock;   // (the amplitudes may change: derived copies go stale)
         if (!ctx->cc.ready) throw Error(1, "call afesp_ccsd_init first");
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         ccsd_amplitudes(ctx->cx, ctx->cc);
@@ -397,6 +398,7 @@ int afesp_ccsd_update_amplitudes(afesp_ctx* ctx)
 int afesp_ccsd_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* energy, double* rms_sq, int* converged)
 {
     return guarded(ctx, [&] {
+        ctx->cc.amp_epoch = ++ctx->cx.amp_clock;   // (the amplitudes may change: derived copies go stale)
         if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_iterate: call afesp_ccsd_init first");
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         ccsd_refresh_sharding(ctx->cx, ctx->cc);
@@ -416,6 +418,7 @@ int afesp_ccsd_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* energ
 int afesp_ccsd_diis(afesp_ctx* ctx)
 {
     return guarded(ctx, [&] {
+        ctx->cc.amp_epoch = ++ctx->cx.amp_clock;   // (the amplitudes may change: derived copies go stale)
         if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_diis: call afesp_ccsd_init first");
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         ccsd_diis_update(ctx->cx, ctx->cc);
@@ -425,6 +428,7 @@ int afesp_ccsd_diis(afesp_ctx* ctx)
 int afesp_ccsd_solve(afesp_ctx* ctx, int maxiter, double e_tol, double t_tol, double* iter_energy, double* iter_rms_sq, int* niter)
 {
     return guarded(ctx, [&] {
+        ctx->cc.amp_epoch = ++ctx->cx.amp_clock;   // (the amplitudes may change: derived copies go stale)
         if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_solve: call afesp_ccsd_init first");
         Context& cx = ctx->cx;
         CCState& s = ctx->cc;
@@ -473,6 +477,7 @@ int afesp_ccsd_get_amplitudes(afesp_ctx* ctx, double* t1, double* t2)
 int afesp_ccsd_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2)
 {
     return guarded(ctx, [&] {
+        ctx->cc.amp_epoch = ++ctx->cx.amp_clock;   // (the amplitudes may change: derived copies go stale)
         if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_set_amplitudes: no CCSD state");
         Context& cx = ctx->cx;
         AFESP_HIP(hipSetDevice(cx.device));
@@ -556,6 +561,7 @@ int afesp_ccsd_t_plain(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double ou
 int afesp_ccsd_cr_intermediates(afesp_ctx* ctx)
 {
     return guarded(ctx, [&] {
+        ctx->cc.cr_epoch = ++ctx->cx.amp_clock;
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         ccsd_cr_intermediates(ctx->cx, ctx->cc);
         ctx->cx.sync();

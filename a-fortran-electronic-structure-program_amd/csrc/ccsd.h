@@ -50,6 +50,9 @@ struct CCState : DiisRing {
     const double* eri_src = nullptr;
     double* eri_own = nullptr;
     bool have_cr = false;
+    // bumped by every entry point that may change t1 / t2 (resp. the CR intermediates): what is derived from them -- the (T)
+    // operand copies, triples.hip -- is rebuilt only when these have moved on
+    int64_t amp_epoch = 0, cr_epoch = 0;
 };
 void triples_plan_free(CCState& s);
 

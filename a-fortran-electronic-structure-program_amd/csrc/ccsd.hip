@@ -106,6 +106,8 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     // ccsd.f90:577-615
     diis_alloc(cx, s, diis_nerr);
     s.energy = s.energy_old = s.rms = 0.0;
+    s.amp_epoch = ++cx.amp_clock;   // (a clock of the context: a re-initialised state never repeats an epoch)
+    s.cr_epoch = ++cx.amp_clock;
     s.ready = true;
     cx.sync();
 }

@@ -811,8 +811,13 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     Tensor vtT = vt;
     vtT.d = vt.d + Kc * v2 * O;
     auto blocks = [](int64_t n) { return dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)); };
+    // The operand copies depend on the amplitudes only (and the CR ones on the CR intermediates): a call on unchanged amplitudes
+    // -- the next shard of the same (T), the CR evaluation after the plain one, every timed repetition -- finds them in the
+    // cached buffers and skips the 3-4 ms of rebuilding them (every shard of a multi-GPU (T) used to pay that).
+    const bool ops_valid = cx.t_ops_owner == (const void*)&s && cx.t_ops_amp == s.amp_epoch && cx.t_ops_scratch == cx.scratch_epoch;
+    if (!ops_valid) { cx.t_ops_ts = false; cx.t_ops_cr = -1; }
     // v_vvov(c,b,k,d): strides of (b,c,k,d) = (V, 1, V^2, V^2 O);  v_oovo(i,j,a,l): (1, O, O^2, O^2 V)
-    {
+    if (!ops_valid) {
         const int64_t nblk = ((Kc + 31) / 32) * ((V + 31) / 32) * V * O;
         if (nblk < ((int64_t)1 << 31))
             hipLaunchKernelGGL(triples_build_vt_tiled_kernel, dim3((unsigned)nblk), dim3(256), 0, cx.stream, vt.d, vtT.d, s.v_vvov.d, V, v2,
@@ -820,15 +825,18 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         else
             hipLaunchKernelGGL(triples_build_vt_kernel, blocks(Kc * v2 * O), dim3(256), 0, cx.stream, vt.d, vtT.d, s.v_vvov.d, V,
                                (int64_t)1, v2, v2 * O, s.t2.d, o, v, (int)Kc);
+        AFESP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(triples_build_tt_kernel, blocks(Kc * V * O * O), dim3(256), 0, cx.stream, tt.d, s.t2.d, s.v_oovo.d, (int64_t)1, O,
+                           O * O, O * O * V, o, v, (int)Kc);
+        AFESP_HIP(hipGetLastError());
     }
-    AFESP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(triples_build_tt_kernel, blocks(Kc * V * O * O), dim3(256), 0, cx.stream, tt.d, s.t2.d, s.v_oovo.d, (int64_t)1, O,
-                       O * O, O * O * V, o, v, (int)Kc);
-    AFESP_HIP(hipGetLastError());
     Tensor vs = view(cx.scratch("t_vs", v2 * O * O), {V, V, O, O});    // vs(x,y,p,q)  = v_oovv(p,q,x,y)
     Tensor ts = view(cx.scratch("t_ts", v2 * O * O), {V, V, O, O});    // ts(x,y,p,q)  = t2(p,q,x,y)
-    permute_add(cx, 1.0, s.v_oovv, "pqxy", 0.0, vs, "xypq");
-    if (want_d) permute_add(cx, 1.0, s.t2, "pqxy", 0.0, ts, "xypq");   // only y needs the t2 patches
+    if (!ops_valid) permute_add(cx, 1.0, s.v_oovv, "pqxy", 0.0, vs, "xypq");
+    if (want_d && !cx.t_ops_ts) {                                      // only y needs the t2 patches
+        permute_add(cx, 1.0, s.t2, "pqxy", 0.0, ts, "xypq");
+        cx.t_ops_ts = true;
+    }
     // completely renormalised mode: the same GEMMs with I_vovv_pp / -I_ooov_pp in place of <cb|kd> / -<ij|al>
     //   vt2(kappa,b,c,k): kappa<v: I_vovv_pp(d,k,b,c);  kappa=v+l: t2(l,k,b,c)
     //   tt2(kappa,a,j,i): kappa<v: t2(i,j,a,d);         kappa=v+l: -I_ooov_pp(j,i,l,a)      (ccsd.f90:2188-2193)
@@ -839,15 +847,22 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         tt2 = view(cx.scratch("t_tt2", Kc * V * O * O), {Kc, V, O, O});
         Tensor vt2T = vt2;
         vt2T.d = vt2.d + Kc * v2 * O;
-        // I_vovv_pp(d,k,b,c): strides of (b,c,k,d) = (V O, V^2 O, V, 1);  I_ooov_pp(j,i,l,a): (i,j,a,l) = (O, 1, O^3, O^2)
-        hipLaunchKernelGGL(triples_build_vt_kernel, blocks(Kc * v2 * O), dim3(256), 0, cx.stream, vt2.d, vt2T.d, s.I_vovv_pp.d, V * O,
-                           v2 * O, V, (int64_t)1, s.t2.d, o, v, (int)Kc);
-        AFESP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(triples_build_tt_kernel, blocks(Kc * V * O * O), dim3(256), 0, cx.stream, tt2.d, s.t2.d, s.I_ooov_pp.d, O,
-                           (int64_t)1, O * O * O, O * O, o, v, (int)Kc);
-        AFESP_HIP(hipGetLastError());
+        if (cx.t_ops_cr != s.cr_epoch) {
+            // I_vovv_pp(d,k,b,c): strides of (b,c,k,d) = (V O, V^2 O, V, 1);  I_ooov_pp(j,i,l,a): (i,j,a,l) = (O, 1, O^3, O^2)
+            hipLaunchKernelGGL(triples_build_vt_kernel, blocks(Kc * v2 * O), dim3(256), 0, cx.stream, vt2.d, vt2T.d, s.I_vovv_pp.d, V * O,
+                               v2 * O, V, (int64_t)1, s.t2.d, o, v, (int)Kc);
+            AFESP_HIP(hipGetLastError());
+            hipLaunchKernelGGL(triples_build_tt_kernel, blocks(Kc * V * O * O), dim3(256), 0, cx.stream, tt2.d, s.t2.d, s.I_ooov_pp.d, O,
+                               (int64_t)1, O * O * O, O * O, o, v, (int)Kc);
+            AFESP_HIP(hipGetLastError());
+            cx.t_ops_cr = s.cr_epoch;
+        }
         Mpool = cx.scratch("t_mpool", p->nb * vp3);
     }
+    // (the buffers above may have been allocated just now, which does not move the scratch epoch; dropping any of them does)
+    cx.t_ops_owner = (const void*)&s;
+    cx.t_ops_amp = s.amp_epoch;
+    cx.t_ops_scratch = cx.scratch_epoch;
     const int nq = cr ? 6 : want_d ? 4 : 2;
     k_fill(cx, cx.scal, 6, 0.0);
     TriplesIn in{s.e, s.t1.d, vs.d, ts.d, s.t2.d, o, v};
@@ -1001,6 +1016,7 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
     k_fill(cx, cx.scal, 1, 0.0);
     if (t_end <= t_begin) return 0.0;
     TriplesPlan* p = plan_for(cx, s.tplan, o, v, t_begin, t_end);
+    cx.t_ops_owner = nullptr;   // (this path fills the same cached buffers: the spin-free copies are gone)
     Tensor vt = view(cx.scratch("t_vt", Kc * v2 * O), {Kc, V, V, O}), tt = view(cx.scratch("t_tt", Kc * V * O * O), {Kc, V, O, O});
     auto sub = [&](const Tensor& full, int64_t row0, int64_t nrows) {
         Tensor t = full;
