@@ -44,9 +44,11 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int TG_STAGE = 32768;             // bytes per stage
 constexpr int TG_BIMG = 16384;              // B image inside a stage
-constexpr int TG_SIDE = 2 * TG_STAGE;       // table slots of the tile being fetched / computed, 4 KiB each:
+constexpr int TG_SIDE = 2 * TG_STAGE;       // table slots of the tiles being fetched / computed, 4 KiB each:
 constexpr int TG_SLOT = 4096;               //   [C row offsets 128 x int64 | C column offsets 128 x int64 | rowA 256 x u32 | colB 256 x u32]
-constexpr int TG_LDS = TG_SIDE + 2 * TG_SLOT;
+constexpr int TG_NSLOT = 3;                 // (three: with two-step tiles the tile entered now is two behind the one whose epilogue still reads its slot)
+constexpr int TG_TKT = TG_SIDE + TG_NSLOT * TG_SLOT;   // two ticket words (dynamic tile assignment)
+constexpr int TG_LDS = TG_TKT + 64;
 
 struct TgArgs {
     TgProblem p;
@@ -54,6 +56,15 @@ struct TgArgs {
     int mtiles, gm, total_tiles;
     unsigned inv_gm, inv_gl;   // reciprocals (tgemm_inverse) of gm and of the size of the last, partial group of m-tiles
     int dbg;                   // measurement only (AFESP_TG_DBG): 1 no C stores
+    // Dynamic tile assignment (large launches).  The matrix pipe of a SIMD goes to the older of its two waves, so of the two
+    // workgroups of a CU one runs at up to twice the other's speed: with tiles dealt statically the workgroups of an XCD end up
+    // hundreds of microseconds apart (their common operand lines are long gone from the L2 when the slow ones ask for them) and
+    // the fast ones idle at the end of the launch.  Instead each XCD has a ticket counter (tickets[xcd], zeroed before the
+    // launch): ticket k of XCD x is tile (k / chunk) * grid + chunk * x + k % chunk -- the tiles of that XCD's patches in order --
+    // and a workgroup draws its next ticket one tile ahead.  nullptr: tiles dealt statically.
+    unsigned* tickets;
+    int chunk;                 // grid / 8
+    unsigned inv_chunk;
 };
 
 #ifdef TG_STAMPS
@@ -89,10 +100,19 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     const cgptr G = (cgptr)(uintptr_t)a.groups;
     const int nwg = (int)gridDim.x;
     const int ntl = (a.total_tiles - (int)blockIdx.x + nwg - 1) / nwg;
+    const bool dyn = a.tickets != nullptr;
+    const int xcd = (int)blockIdx.x & 7;
+    unsigned* tslot = reinterpret_cast<unsigned*>(lds + TG_TKT);
+    // tile number n of this workgroup's stream -> tile id, or -1 behind the last one
+    auto tile_static = [&](int n) { return n < ntl ? n * nwg + tg_xcd_remap((int)blockIdx.x, min(nwg, a.total_tiles - n * nwg)) : -1; };
+    auto tile_ticket = [&](unsigned k) {
+        const unsigned q = a.inv_chunk ? __umulhi(k, a.inv_chunk) : k;
+        const int64_t tile = (int64_t)q * nwg + (int64_t)a.chunk * xcd + (k - q * (unsigned)a.chunk);
+        return tile < a.total_tiles ? (int)tile : -1;
+    };
     int cursor = 0;
-    auto origin = [&](int j, int& m0, int& n0) {
-        const int r0 = j * nwg;
-        int tile = r0 + tg_xcd_remap((int)blockIdx.x, min(nwg, a.total_tiles - r0));
+    auto origin = [&](int tile, int& m0, int& n0) {
+        // (tile ids only grow along a workgroup's stream, statically dealt or drawn)
         while (tile >= G[cursor + 1].tile_start) ++cursor;
         tile -= G[cursor].tile_start;
         const int nt = G[cursor].ntiles;
@@ -122,7 +142,10 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     unsigned rdB1t = (unsigned)(TG_BIMG + (wn * 64 + fm) * 128 + (((4 + (ff >> 1)) ^ fs) & 7) * 16 + (ff & 1) * 8);
 
     // ---- fetch cursor (two steps ahead of the MFMAs) and the tile entered but not yet committed
-    int fj = 0, fkt = 0, fnk = 0, fnk1 = 0;
+    int entered = 0, fkt = 0, fnk = 0, fnk1 = 0;   // tiles entered so far; the cursor's step inside the last of them
+    bool f_live = true;                             // the cursor points at a tile (false behind the last one)
+    unsigned tk = 0;                                // the ticket drawn for the tile after the next (lane 0 of wave 0)
+    bool tk_pending = false;
     int fmrem = 0, fnrem = 0;   // rows / columns of C from the tile's origin to M / N
     const char *fa1 = nullptr, *fa2 = nullptr, *fb1 = nullptr, *fb2 = nullptr;
     unsigned voffA[4], voffB[4];
@@ -131,10 +154,11 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     bool pending = false;
 
     // A tile is entered one step before its first transfer: its group's scalars are read (scalar loads) and its four tables go
-    // to table slot j & 1, one per wave, 1 KiB each (the row tables are read 128 entries beyond the tile: the host pads them).
-    auto enter_tile = [&](int j) {
+    // to table slot j % 3, one per wave, 1 KiB each (the row tables are read 128 entries beyond the tile: the host pads them).
+    auto enter_tile = [&](int tile) {
+        const int j = entered;
         int m0, n0;
-        origin(j, m0, n0);
+        origin(tile, m0, n0);
         const cgptr g = G + cursor;
         const int N = g->N;
         pnk = g->nk;
@@ -150,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
                           : wave == 2 ? (const char*)(p.rowA + m0)
                                       : (const char*)((const uint32_t*)(uintptr_t)g->colB + n0);
         src = (const char*)tg_uni64((int64_t)src);
-        const unsigned dst = (unsigned)tg_uni((int)(lds0 + (unsigned)(TG_SIDE + (j & 1) * TG_SLOT + wave * 1024)));
+        const unsigned dst = (unsigned)tg_uni((int)(lds0 + (unsigned)(TG_SIDE + (j % TG_NSLOT) * TG_SLOT + wave * 1024)));
         // (the instruction offset moves the source and the LDS address alike; s_nop 4: a scalar register fresh from a
         // readfirstlane must not be read by a vector-memory instruction in the next five states)
         asm volatile("s_nop 4\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
@@ -160,10 +184,11 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
                      : [v] "v"(lane4), [p] "s"(src), [d] "s"(dst)
                      : "memory");
         pending = true;
+        ++entered;
     };
     // ... and committed after the next barrier (its tables are in LDS): row / column byte offsets of this thread's transfers
     auto commit_tile = [&](int j) {
-        const unsigned* sr = reinterpret_cast<const unsigned*>(lds + TG_SIDE + (j & 1) * TG_SLOT + 2048);
+        const unsigned* sr = reinterpret_cast<const unsigned*>(lds + TG_SIDE + (j % TG_NSLOT) * TG_SLOT + 2048);
         const int lm = min(TG_BM, pmrem) - 1, ln = min(TG_BN, pnrem) - 1;   // rows / columns beyond M / N fetch the last valid one
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -178,7 +203,9 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     // The eight 1-KiB transfers of this wave for the cursor's step (A image rows 32w .. 32w+31, then B image rows 32w .. 32w+31 of
     // the stage) are issued one by one between MFMAs (TG_DMA below); dma_setup computes their scalar operands.
     // (readfirstlane: the values are uniform, but hipcc is free to compute a select of them in vector registers, and the asm
-    // needs scalar ones; the s_nop 4 that opens the first piece covers the VALU-write -> VMEM-read hazard of such a register)
+    // needs scalar ones.  Every piece opens with s_nop 4: a scalar register written by the vector unit -- a readfirstlane, or the
+    // v_readlane with which hipcc reloads a SPILLED scalar register right in front of the statement -- must not be read by a
+    // vector-memory instruction in the next five states, and hipcc pads no hazard of an asm statement)
     const char *dma_ap = nullptr, *dma_bp = nullptr;
     unsigned dma_dst = 0;
     auto dma_setup = [&](int stage) {
@@ -191,16 +218,30 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     asm volatile("s_nop %c[nop]\n\ts_add_u32 m0, %[d], %[off]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[p]"         \
                  :                                                                                                       \
                  : [v] "v"((Q) < 4 ? voffA[(Q) & 3] : voffB[(Q) & 3]), [p] "s"((Q) < 4 ? dma_ap : dma_bp), [d] "s"(dma_dst), \
-                   [off] "i"(((Q) < 4 ? 0 : TG_BIMG) + ((Q) & 3) * 1024), [nop] "i"((Q) == 0 ? 4 : 0)                    \
+                   [off] "i"(((Q) < 4 ? 0 : TG_BIMG) + ((Q) & 3) * 1024), [nop] "i"(4)                    \
                  : "memory", "scc")
     // The cursor moves on one step.  When the step is the last one of its tile the next tile is entered BEFORE the step's own
     // transfers are issued (its table transfers are then the older ones; everything is waited for at the step's barrier).
+    // the tile after the last one entered: dealt statically, or the ticket drawn for it one tile ago -- and the next draw
+    auto acquire = [&]() {
+        if (!dyn) return tile_static(entered);
+        const unsigned k = (unsigned)tg_uni((int)tslot[entered & 1]);
+        if (t == 0)   // (one lane; returns the counter's previous value; waited for at the step's barrier like every transfer)
+            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(tk) : "v"(0u), "v"(1u), "s"(a.tickets + xcd) : "memory");
+        tk_pending = true;
+        return tile_ticket(k);
+    };
     auto fetch_begin = [&](int stage) {
-        const bool live = fj < ntl, last = live && fkt + 1 == fnk;
-        if (last && fj + 1 < ntl) enter_tile(fj + 1);
+        const bool last = f_live && fkt + 1 == fnk;
+        bool more = true;
+        if (last) {
+            const int nt = acquire();
+            more = nt >= 0;
+            if (more) enter_tile(nt);
+        }
         dma_setup(stage);
-        fkt = last ? 0 : live ? fkt + 1 : fkt;   // (written as selects: an if/else of increments made hipcc keep the counters in scratch memory)
-        fj += last ? 1 : 0;
+        fkt = last ? 0 : f_live ? fkt + 1 : fkt;   // (written as selects: an if/else of increments made hipcc keep the counters in scratch memory)
+        f_live = f_live && more;
     };
 
     v4d acc[4][4];
@@ -258,7 +299,19 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     else FB[(Q) & 3] = *reinterpret_cast<const v2d*>(lds + RB + ((Q) & 3) * 2048)
 
     // ---- prologue: tile 0, steps 0 and 1 (every group has nk >= 2)
-    enter_tile(0);
+    int tile0;
+    if (dyn) {
+        if (t == 0) {   // the tickets of this workgroup's first two tiles
+            tslot[0] = atomicAdd(a.tickets + xcd, 1u);
+            tslot[1] = atomicAdd(a.tickets + xcd, 1u);
+        }
+        __syncthreads();
+        tile0 = tile_ticket((unsigned)tg_uni((int)tslot[0]));
+        if (tile0 < 0) return;   // (more workgroups than this XCD has tiles)
+    } else {
+        tile0 = tile_static(0);
+    }
+    enter_tile(tile0);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     commit_tile(0);
     int kt = 0, cj = 0, cur = 0, nk_cur = fnk, nk1_cur = fnk1, mrem_cur = fmrem, nrem_cur = fnrem;
@@ -271,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
 #pragma unroll
     for (int q = 0; q < 8; ++q) { TG_FRAG(fa0, fb0, rdA0, rdB0, q); }
 #ifdef TG_STAMPS
-    unsigned long long st_bar = 0, st_epi = 0, st_steps = 0, st_tiles = 0, st_max = 0;
+    unsigned long long st_bar = 0, st_epi = 0, st_steps = 0, st_tiles = 0, st_max = 0, st_t8 = 0;
     const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -320,7 +373,12 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
 #define TG_B(Q) TG_FRAG(fa0, fb0, rdA0, rdB0, Q); TG_SB; TG_MF(fa1_, fb1_, Q); TG_SB;
         TG_B(0) TG_B(1) TG_B(2) TG_B(3) TG_B(4) TG_B(5) TG_B(6) TG_B(7)
 #undef TG_B
-        if (pending) commit_tile(fj);
+        if (tk_pending) {   // the ticket drawn in the previous step has landed (this step's barrier): publish it to the other waves
+            asm volatile("" : "+v"(tk));
+            if (t == 0) tslot[entered & 1] = tk;
+            tk_pending = false;
+        }
+        if (pending) commit_tile(entered - 1);
         // (behind the last step of the stream the transfers are issued all the same -- the first step of the last tile once more,
         // into a stage nobody reads again: cheaper than eight branches per step; they are waited for before the kernel ends)
         fetch_begin(freed);
@@ -337,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
 #ifdef TG_STAMPS
             const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
 #endif
-            if (!(a.dbg & 1)) store_tile(cj & 1, mrem_cur, nrem_cur);
+            if (!(a.dbg & 1)) store_tile(cj % TG_NSLOT, mrem_cur, nrem_cur);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -345,9 +403,10 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
 #ifdef TG_STAMPS
             st_epi += __builtin_amdgcn_s_memtime() - st_e0;
             ++st_tiles;
+            if (st_tiles == 8) st_t8 = __builtin_amdgcn_s_memrealtime();   // (100 MHz) when this workgroup finished its 8th tile
 #endif
             kt = 0;
-            if (++cj == ntl) break;
+            if (++cj == entered) break;   // (the tile after this one, if there is one, was entered steps ago)
             // every group has nk >= 2: the next tile was committed one step ago at the latest, and the one after it
             // (entered in this very step if the next tile has two steps) is not committed before the next step
             nk_cur = fnk;
@@ -362,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         unsigned long long* d = g_tg_stamp + ((size_t)blockIdx.x * 4 + wave) * 8;
         d[0] = __builtin_amdgcn_s_memtime() - st_t0;
         d[1] = st_bar; d[2] = st_epi; d[3] = st_steps; d[4] = st_tiles; d[5] = st_max;
-        d[6] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // HW_REG_XCC_ID[3:0]
+        d[6] = st_t8;
         d[7] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);    // HW_REG_HW_ID[15:0]: wave, simd, pipe, cu, sh, se
     }
 #endif
@@ -414,6 +473,22 @@ hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngrou
     a.inv_gl = tgemm_inverse(std::max(1, a.mtiles % a.gm));
     static const int grid_env = getenv("AFESP_TG_GRID") ? atoi(getenv("AFESP_TG_GRID")) : 0;   // diagnostic: fewer workgroups, longer tile streams
     const unsigned grid = (unsigned)std::min(total_tiles, grid_env > 0 ? grid_env : cap);
+    // tickets: launches of many rounds of tiles whose grid splits evenly over the XCDs (AFESP_TG_DYNAMIC=0: always static)
+    static const bool dyn_env = !(getenv("AFESP_TG_DYNAMIC") && getenv("AFESP_TG_DYNAMIC")[0] == '0');
+    static const bool dyn_force = getenv("AFESP_TG_DYNAMIC") && getenv("AFESP_TG_DYNAMIC")[0] == '2';   // tests: also for small launches
+    static unsigned* tickets[16] = {};
+    a.tickets = nullptr;
+    a.chunk = (int)(grid / 8);
+    a.inv_chunk = tgemm_inverse(a.chunk);
+    if (dyn_env && grid % 8 == 0 && ((int64_t)total_tiles >= (int64_t)4 * grid || dyn_force)) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 15;
+        if (!tickets[dev] && hipMalloc((void**)&tickets[dev], 64) != hipSuccess) return hipErrorOutOfMemory;
+        const hipError_t me = hipMemsetAsync(tickets[dev], 0, 64, stream);
+        if (me != hipSuccess) return me;
+        a.tickets = tickets[dev];
+    }
     hipLaunchKernelGGL(tgemm_kernel, dim3(grid), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

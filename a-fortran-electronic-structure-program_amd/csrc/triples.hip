@@ -665,7 +665,15 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
             for (const TriplesPlan::Group& g : ch.groups) mx = std::max(mx, (int)((g.N + TG_BN - 1) / TG_BN));
             const int gm = tgemm_group_m((int)v2, mx);
             int tile = 0;
+            // Order: the groups over the whole summation index first, the coinciding-pair groups (half the K steps) behind them.
+            // Every tile of a round of the persistent grid then takes the same time -- but for the one round where the two sections
+            // meet -- and the workgroups of an XCD keep walking their patch of C in step, i.e. keep finding each other's operand
+            // lines in that XCD's L2 (mixed in group order, short and long tiles put the workgroups out of step for good:
+            // 56 GB fetched past L2 per launch instead of 13).
+            for (int pass = 0; pass < 2; ++pass)
             for (const TriplesPlan::Group& g : ch.groups) {
+                const bool half = ch.split_diag && g.q == g.r;
+                if (half != (pass == 1)) continue;
                 TgGroup d;
                 d.a1 = Kc * v2 * g.r;                   // vt(:, ., ., r)
                 d.a2 = Kc * v2 * O + Kc * v2 * g.q;     // vtT(:, ., ., q)
@@ -676,7 +684,7 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
                 d.ntiles = (int)((g.N + TG_BN - 1) / TG_BN);
                 d.tile_start = tile;
                 d.nk1 = nk1;
-                d.nk = (ch.split_diag && g.q == g.r) ? nk1 : 2 * nk1;
+                d.nk = half ? nk1 : 2 * nk1;
                 d.inv_width = tgemm_inverse(gm * d.ntiles);
                 if ((int64_t)mt * d.ntiles * gm * d.ntiles >= ((int64_t)1 << 32)) throw Error(2, "triples plan: tile walk out of range");
                 tile += mt * d.ntiles;

@@ -135,19 +135,31 @@ def cpu_baseline(o, v, scale, seed, eng, budget_s=25.0):
         return {"value": t_iter + t_t, "unit": "s/step", "ccsd_iter_s": t_iter, "t_s": t_t, "t_s_loop_form": t_loops, "cores": threads,
                 "kind": "port", "blas": blas_note, "sample": sample,
                 "gflops": (flops_iter(o, v) + flops_t_ref(o, v)) / (t_iter + t_t) / 1e9}
-    # large system: the reference formulation cannot run here (n<=99); time slabs of the restatement
+    # large system: the reference formulation cannot run here (n<=99); time slabs of the restatement in the
+    # reference's own shape -- the dgemm sites through threaded OpenBLAS, the sites the reference leaves to OpenMP loop nests as
+    # those loop nests -- and scale each to its whole
     t1, t2 = eng.amplitudes()
     e = np.concatenate([-2.0 + np.arange(o) / max(o - 1, 1), 1.0 + 2.0 * np.arange(v) / max(v - 1, 1)])
     targs = (o, v, e, f(t1), f(t2), f(eng.tensor("v_vvov")), f(eng.tensor("v_oovo")), f(eng.tensor("v_oovv")))
     if LB is not None:
-        t_t, ns = time_triples(LB.orcb_ccsd_t, targs)
+        # at least 5 % of the ordered triples (whole rounds of `threads`), more if the budget allows
+        out = np.zeros(4)
+        t0 = time.perf_counter()
+        LB.orcb_ccsd_t(*targs, 0, threads, out)
+        per = max(time.perf_counter() - t0, 1e-6)
+        want = -(-int(0.05 * o**3) // threads) * threads
+        ns = int(min(o**3, max(want, threads * int(budget_s * 0.4 / per))))
+        t0 = time.perf_counter()
+        LB.orcb_ccsd_t(*targs, 0, ns, out)
+        t_t = (time.perf_counter() - t0) * (o**3 / ns)
     else:
         out = np.zeros(4)
         ns = threads
         t0 = time.perf_counter()
         L.orc_ccsd_t(*targs, 0, ns, out)
         t_t = (time.perf_counter() - t0) * (o**3 / ns)
-    # pp-ladder slab: ncol columns (a,b) of the o^2 x v^2 x v^2 product (ccsd.f90:1669)
+    # (1) dgemm sites.  The pp-ladder (ccsd.f90:1669) is one dgemm of o^2 x v^2 x v^2: a slab of its columns; the other dgemm
+    # sites (the I_voov products :1193-1230, I_oooo, the o v^3 and o^2 v^2 terms) at the same rate
     c = f(eng.tensor("c_oovv"))
     ncol = 1024 if LB is not None else 64
     vv = np.full(v * v * ncol, 0.01)
@@ -160,10 +172,32 @@ def cpu_baseline(o, v, scale, seed, eng, budget_s=25.0):
         t0 = time.perf_counter()
         L.orc_gemm(0, 0, o * o, ncol, v * v, 0.5, c, vv, 0.0, res)
     t_lad = (time.perf_counter() - t0) * (v * v / ncol)
-    t_iter = t_lad * flops_iter(o, v, 2 * o**2 * v**4) / (2 * o**2 * v**4)   # the reference's formulation: full dgemm
-    sample = (f"(T): {ns}/{o**3} ordered triples scaled to o^3; CCSD iteration: {ncol}/{v*v} columns of the pp-ladder dgemm scaled "
-              "to v^2 and to the iteration's full flop count (extrapolated)")
+    f_lad, f_loops = 2 * o**2 * v**4, 8 * o**3 * v**3       # ladder as the reference's full dgemm; the four o^3 v^3 products in loops
+    f_iter = flops_iter(o, v, f_lad)
+    t_blas = t_lad * (f_iter - f_loops) / f_lad
+    # (2) loop sites: I_ovov's c-term (ccsd.f90:1170-1182) and terms 6-8 of the T2 equation (:1680-1695, "seems hopeless, use
+    # OMP") are OpenMP loop nests in the reference, 8 o^3 v^3 flop of the iteration: slabs of their outermost index
+    t_loops, nsl = None, 0
+    if LB is not None:
+        tl = time.perf_counter()
+        asym, I_ovov, I_voov = f(eng.tensor("asym_t2")), f(eng.tensor("I_ovov")), f(eng.tensor("I_voov"))
+        v_oovv = targs[7]
+        buf = I_ovov.copy()
+        acc2 = np.zeros(o * o * v * v)
+        nsl = max(2, -(-v // 25))                          # >= 4 % of the outermost index of each nest
+        t0 = time.perf_counter()
+        LB.orcb_ring_I_ovov(o, v, v_oovv, c, buf, 0, nsl)
+        t_a = (time.perf_counter() - t0) * (v / nsl)
+        t0 = time.perf_counter()
+        LB.orcb_ring_t2(o, v, f(t2), asym, I_ovov, I_voov, acc2, 0, nsl)
+        t_b = (time.perf_counter() - t0) * (v / nsl)
+        t_loops = t_a + t_b
+    t_iter = t_blas + (t_loops if t_loops is not None else t_lad * f_loops / f_lad)
+    sample = (f"(T): {ns}/{o**3} ordered triples scaled to o^3; CCSD iteration: {ncol}/{v*v} columns of the pp-ladder dgemm scaled to v^2 "
+              f"and to the flop of all dgemm sites; {nsl}/{v} slabs of each of the reference's two o^3 v^3 OpenMP loop nests scaled to v")
     return {"value": t_iter + t_t, "unit": "s/step", "ccsd_iter_s": t_iter, "t_s": t_t, "cores": threads, "kind": "port",
+            "extrapolated": True, "ccsd_iter_s_blas_sites": t_blas, "ccsd_iter_s_loop_sites": t_loops,
+            "sample_fraction": {"t_ordered_triples": ns / o**3, "pp_ladder_columns": ncol / (v * v), "loop_nest_slabs": nsl / v},
             "blas": blas_note, "sample": sample, "gflops": (flops_iter(o, v) + flops_t_ref(o, v)) / (t_iter + t_t) / 1e9}
 
 

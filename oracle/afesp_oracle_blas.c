@@ -147,3 +147,45 @@ int orcb_gemm(i64 m, i64 n, i64 k, double alpha, const double *A, const double *
     g_dgemm(COL, NOT, NOT, m, n, k, alpha, A, m, B, k, beta, Cm, m);
     return 0;
 }
+
+/* ---- the loop sites of the reference's CCSD iteration (bench.py cpu_baseline: they are NOT dgemm calls in the reference, and an
+ * iteration's CPU time at config 5 is theirs, not the ladder's).  Same loop nests, same OpenMP clauses, restricted to a slab of
+ * the outermost index so that a bounded sample can be timed and scaled; arrays are the column-major ones of afesp_oracle.c. */
+
+/* ccsd.f90:1170-1182: I_ovov(j,b,i,a) -= 0.5 v_oovv(m,i,b,e) c_oovv(m,j,a,e) for a in [a0, a1) */
+int orcb_ring_I_ovov(i64 o, i64 v, const double *v_oovv, const double *c_oovv, double *I_ovov, i64 a0, i64 a1)
+{
+#define oovv4(X, p, q, r, s) X[(p) + o * ((q) + o * ((r) + v * (s)))]
+#define ovov4(X, p, q, r, s) X[(p) + o * ((q) + v * ((r) + o * (s)))]
+#pragma omp parallel for collapse(2) schedule(static, 10)
+    for (i64 a = a0; a < a1; ++a)
+        for (i64 i = 0; i < o; ++i)
+            for (i64 b = 0; b < v; ++b)
+                for (i64 j = 0; j < o; ++j)
+                    for (i64 e = 0; e < v; ++e)
+                        for (i64 m = 0; m < o; ++m)
+                            ovov4(I_ovov, j, b, i, a) -= 0.5 * oovv4(v_oovv, m, i, b, e) * oovv4(c_oovv, m, j, a, e);
+    return 0;
+}
+
+/* ccsd.f90:1680-1695 (Eq. 44, terms 6-8: "seems hopeless, use OMP"):
+ * tmp_t2(i,j,a,b) += sum_{e,m} [ -t2(m,j,a,e) I_ovov(i,e,m,b) - I_ovov(i,e,m,a) t2(m,j,e,b) + asym_t2(m,i,e,a) I_voov(e,j,m,b) ]
+ * for b in [b0, b1);  I_voov(e,j,m,b) is v x o x o x v */
+int orcb_ring_t2(i64 o, i64 v, const double *t2, const double *asym_t2, const double *I_ovov, const double *I_voov, double *tmp_t2,
+                 i64 b0, i64 b1)
+{
+#define voov4(X, p, q, r, s) X[(p) + v * ((q) + o * ((r) + o * (s)))]
+#pragma omp parallel for collapse(3) schedule(static, 10)
+    for (i64 b = b0; b < b1; ++b)
+        for (i64 a = 0; a < v; ++a)
+            for (i64 j = 0; j < o; ++j)
+                for (i64 i = 0; i < o; ++i) {
+                    double tmp = 0.0;
+                    for (i64 e = 0; e < v; ++e)
+                        for (i64 m = 0; m < o; ++m)
+                            tmp = tmp - oovv4(t2, m, j, a, e) * ovov4(I_ovov, i, e, m, b) - ovov4(I_ovov, i, e, m, a) * oovv4(t2, m, j, e, b) +
+                                  oovv4(asym_t2, m, i, e, a) * voov4(I_voov, e, j, m, b);
+                    oovv4(tmp_t2, i, j, a, b) += tmp;
+                }
+    return 0;
+}

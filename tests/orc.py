@@ -97,6 +97,8 @@ def lib():
     L.orcb_load.argtypes = [C.c_char_p]
     L.orcb_ccsd_t.argtypes = [i64, i64, dp, dp, dp, dp, dp, dp, i64, i64, dp]
     L.orcb_gemm.argtypes = [i64, i64, i64, dbl, dp, dp, dbl, dp, C.c_int]
+    L.orcb_ring_I_ovov.argtypes = [i64, i64, dp, dp, dp, i64, i64]
+    L.orcb_ring_t2.argtypes = [i64, i64, dp, dp, dp, dp, dp, i64, i64]
     _LIB = L
     return L
 

@@ -170,3 +170,25 @@ def test_spinorbital_triples_equal_spin_free_triples_on_the_same_amplitudes():
     e, _, _ = so.energy_step(1.0, 1.0)
     assert abs(e - cc.energy) < 1e-13
     assert abs(so.triples() - out[1]) < 1e-13
+
+
+def test_loop_sites_of_the_cpu_baseline_equal_their_defining_sums():
+    """oracle/afesp_oracle_blas.c, the two OpenMP loop nests of the reference's iteration (ccsd.f90:1170-1182, :1680-1695) that
+    bench.py times slab by slab as the CPU baseline's loop sites: slabs add up to the whole, and the whole is the defining sum."""
+    L = orc.lib()
+    o, v = 3, 5
+    rng = np.random.default_rng(11)
+    f = lambda a: np.ascontiguousarray(a.ravel(order="F"))
+    v_oovv, c_oovv, t2, asym = (rng.standard_normal((o, o, v, v)) for _ in range(4))
+    I_ovov = rng.standard_normal((o, v, o, v))
+    I_voov = rng.standard_normal((v, o, o, v))
+    got = f(I_ovov).copy()
+    assert L.orcb_ring_I_ovov(o, v, f(v_oovv), f(c_oovv), got, 0, 2) == 0 and L.orcb_ring_I_ovov(o, v, f(v_oovv), f(c_oovv), got, 2, v) == 0
+    ref = I_ovov - 0.5 * np.einsum("mibe,mjae->jbia", v_oovv, c_oovv)
+    assert np.max(np.abs(got - f(ref))) < 1e-13
+    out = np.zeros(o * o * v * v)
+    assert L.orcb_ring_t2(o, v, f(t2), f(asym), f(I_ovov), f(I_voov), out, 0, 1) == 0
+    assert L.orcb_ring_t2(o, v, f(t2), f(asym), f(I_ovov), f(I_voov), out, 1, v) == 0
+    ref = (-np.einsum("mjae,iemb->ijab", t2, I_ovov) - np.einsum("iema,mjeb->ijab", I_ovov, t2)
+           + np.einsum("miea,ejmb->ijab", asym, I_voov))
+    assert np.max(np.abs(out - f(ref))) < 1e-13

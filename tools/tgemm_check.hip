@@ -63,10 +63,12 @@ static int run_big(int argc, char** argv)
     }
     printf("stamps over %d waves: cycles per step %.0f (MFMA floor 8192 at two waves per SIMD), of which barrier %.0f; per tile: epilogue %.0f; longest barrier %.0f\n",
            n, tot / steps, bar / steps, epi / tiles, mx);
-    printf("  workgroup -> XCC_ID (HW_ID >> 8):");
-    for (int b = 0; b < 24; ++b) printf(" %d:%llu(%llx)", b, st[((size_t)b * 4) * 8 + 6], st[((size_t)b * 4) * 8 + 7] >> 8);
-    printf(" ... 256:%llu 257:%llu 264:%llu\n", st[((size_t)256 * 4) * 8 + 6], st[((size_t)257 * 4) * 8 + 6], st[((size_t)264 * 4) * 8 + 6]);
-    { int bad = 0; for (int b = 0; b < 512; ++b) if (st[((size_t)b * 4) * 8 + 3] && st[((size_t)b * 4) * 8 + 6] != st[((size_t)(b & 7) * 4) * 8 + 6]) ++bad; printf("  workgroups whose XCC differs from that of workgroup b & 7: %d\n", bad); }
+    // when did the workgroups of an XCD (b & 7) finish their 8th tile?  spread in units of 10 ns; a K step is ~370 units
+    for (int x = 0; x < 8; ++x) {
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int b = x; b < 512; b += 8) { const unsigned long long t8 = st[((size_t)b * 4) * 8 + 6]; if (t8) { lo = std::min(lo, t8); hi = std::max(hi, t8); } }
+        printf("  XCD %d: workgroups finish their 8th tile within %llu x 10 ns of each other\n", x, hi > lo ? hi - lo : 0ull);
+    }
     // distribution of per-wave barrier share
     for (int w = 0; w < 4; ++w) {
         double b2 = 0, s2 = 0;
