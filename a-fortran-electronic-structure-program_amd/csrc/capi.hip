@@ -9,6 +9,7 @@
 #include "../../include/afesp.h"
 #include "ccsd.h"
 #include "ccsd_so.h"
+#include "tgemm.h"
 #include "comm.h"
 
 using namespace afesp;
@@ -236,6 +237,142 @@ void afesp_ctx_destroy(afesp_ctx* ctx)
 
 const char* afesp_last_error(const afesp_ctx* ctx) { return ctx ? ctx->cx.last_error.c_str() : "null context"; }
 
+// ---- a quarter transform on the LDS-DMA GEMM (tgemm.h): out(x2, m, S) = sum_x1 C(m, x1) in(x1, x2, S)
+// The transformed index is the fastest one of `in`, so every column (x2, S) of the product is a contiguous run of n doubles: both
+// operands are contiguous along the summation index (C goes in as a zero-padded transpose), which is all that kernel asks for.
+// The result comes out with x2 fastest and the new index second -- the layout the NEXT quarter transform wants for its input
+// (and the one the old path produced after two of them: (p,q,K), (r,s,P)).  Needs an even n (16-byte chunks, pairs of columns).
+__global__ __launch_bounds__(256) void ao2mo_ct_kernel(double* ct, const double* c, int n, int Kc)
+{
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < n * Kc; x += gridDim.x * blockDim.x) {
+        const int m = x / Kc, k = x % Kc;
+        ct[x] = k < n ? c[m + n * k] : 0.0;
+    }
+}
+// rowA[m] = byte offset of row m of the padded transpose; colB[c] = byte offset of column c = x2 + n Sloc of a slab of `in`;
+// offCm[m] = n m; offCn[c] = x2 + n^2 Sloc (elements); the pads behind them (tgemm.h) are zero
+__global__ __launch_bounds__(256) void ao2mo_tables_kernel(uint32_t* rowA, uint32_t* colB, int64_t* offCm, int64_t* offCn, int n, int Kc, int64_t ncol)
+{
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < ncol + 256; x += (int64_t)gridDim.x * blockDim.x) {
+        if (x < n + 256) rowA[x] = x < n ? (uint32_t)(8 * Kc * x) : 0u;
+        if (x < n + 128) offCm[x] = x < n ? (int64_t)n * x : 0;
+        colB[x] = x < ncol ? (uint32_t)(8 * (int64_t)n * x) : 0u;
+        if (x < ncol + 128) offCn[x] = x < ncol ? (x % n) + (int64_t)n * n * (x / n) : 0;
+    }
+}
+
+// The second pair of transforms is only needed where the packed result has an entry: (rs|PQ) for RS <= PQ, i.e. r <= p(PQ).  The
+// last transform therefore runs over the columns (r, PQ) with r <= p only -- p + 1 of them per pair PQ = tri(p, q), rounded up to
+// an even count (pairs of columns are stored together) -- about half of all: colB / offCn list them pair by pair, relative to
+// the pair's slab (cstart[PQ] = first column of the pair).
+__global__ __launch_bounds__(256) void ao2mo_tables_tri_kernel(uint32_t* colB, int64_t* offCn, const int64_t* cstart, int n, int64_t np, int64_t sl)
+{
+    for (int64_t P = blockIdx.x; P < np; P += gridDim.x) {
+        const int64_t c0 = cstart[P], cnt = cstart[P + 1] - c0, rel = P % sl;
+        for (int64_t r = threadIdx.x; r < cnt; r += blockDim.x) {
+            colB[c0 + r] = (uint32_t)(8 * (int64_t)n * (r + (int64_t)n * rel));
+            offCn[c0 + r] = r + (int64_t)n * n * rel;
+        }
+    }
+}
+
+namespace {
+struct Ao2moTg {
+    int64_t n = 0, Kc = 0, sl = 0;   // basis size, padded summation length, (S) pairs per slab (one TgGroup each)
+    double* ct = nullptr;
+    uint32_t *rowA = nullptr, *colB = nullptr;
+    int64_t *offCm = nullptr, *offCn = nullptr;
+    TgGroup* groups = nullptr;
+    std::vector<TgGroup> host;
+    // columns (r, PQ), r <= p(PQ) only (ao2mo_tables_tri_kernel)
+    uint32_t* colB_tri = nullptr;
+    int64_t* offCn_tri = nullptr;
+    std::vector<int64_t> cstart;     // [np + 1], host copy
+    int64_t p_split = 0;             // first pair PQ with p >= TG_BM (the pairs below it need the first 128 rows only)
+};
+
+// tables and the padded transpose of the coefficient matrix for basis size n (cached scratch: rebuilt per call, microseconds)
+Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_t np)
+{
+    Ao2moTg t;
+    t.n = n;
+    t.Kc = (n + 15) / 16 * 16;
+    // a slab's columns are addressed with 32-bit byte offsets: n * sl columns of n doubles each below 4 GiB
+    t.sl = std::min<int64_t>(np, std::min<int64_t>(8192, (((int64_t)1 << 32) - 4096) / (8 * n * n)));
+    const int64_t ncol = n * t.sl;
+    t.ct = cx.scratch("ao2mo_ct", n * t.Kc);
+    t.rowA = (uint32_t*)cx.scratch("ao2mo_t32", (n + 256 + ncol + 256) / 2 + 2);
+    t.colB = t.rowA + n + 256;
+    t.offCm = (int64_t*)cx.scratch("ao2mo_t64", n + 128 + ncol + 128 + 2);
+    t.offCn = t.offCm + n + 128;
+    hipLaunchKernelGGL(ao2mo_ct_kernel, dim3((unsigned)((n * t.Kc + 255) / 256)), dim3(256), 0, cx.stream, t.ct, Cm, (int)n, (int)t.Kc);
+    AFESP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ao2mo_tables_kernel, dim3((unsigned)std::min<int64_t>((ncol + 256 + 255) / 256, 65536)), dim3(256), 0, cx.stream, t.rowA,
+                       t.colB, t.offCm, t.offCn, (int)n, (int)t.Kc, ncol);
+    AFESP_HIP(hipGetLastError());
+    const int64_t ng = (np + t.sl - 1) / t.sl;
+    t.groups = (TgGroup*)cx.scratch("ao2mo_tg", (int64_t)((ng + 2) * sizeof(TgGroup) / sizeof(double) + 1));
+    // the triangular column list of the last transform
+    t.cstart.assign((size_t)np + 1, 0);
+    for (int64_t pp = 0, P = 0; pp < n; ++pp)
+        for (int64_t q = 0; q <= pp; ++q, ++P) t.cstart[(size_t)P + 1] = t.cstart[(size_t)P] + ((pp + 2) & ~(int64_t)1);
+    t.p_split = std::min<int64_t>(np, (int64_t)TG_BM * (TG_BM + 1) / 2);
+    const int64_t ctot = t.cstart[(size_t)np];
+    t.colB_tri = (uint32_t*)cx.scratch("ao2mo_t32t", (ctot + 256) / 2 + 2);
+    t.offCn_tri = (int64_t*)cx.scratch("ao2mo_t64t", ctot + 128 + 2);
+    int64_t* cs_dev = (int64_t*)cx.scratch("ao2mo_cs", np + 2);
+    AFESP_HIP(hipMemcpyAsync(cs_dev, t.cstart.data(), (size_t)(np + 1) * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
+    AFESP_HIP(hipMemsetAsync(t.colB_tri + ctot, 0, 256 * sizeof(uint32_t), cx.stream));
+    AFESP_HIP(hipMemsetAsync(t.offCn_tri + ctot, 0, 128 * sizeof(int64_t), cx.stream));
+    hipLaunchKernelGGL(ao2mo_tables_tri_kernel, dim3((unsigned)std::min<int64_t>(np, 65536)), dim3(256), 0, cx.stream, t.colB_tri, t.offCn_tri,
+                       cs_dev, (int)n, np, t.sl);
+    AFESP_HIP(hipGetLastError());
+    return t;
+}
+
+// one quarter transform over the pairs S in [s_begin, s_end) of `in` (n x n x np), rows m < M of the result only; tri: only the
+// columns (x2, S) with x2 <= p(S) (the rest of `out` is left untouched)
+void ao2mo_tg_xform(Context& cx, Ao2moTg& t, const double* in, double* out, int64_t s_begin, int64_t s_end, int64_t M, bool tri)
+{
+    if (s_end <= s_begin) return;
+    const int64_t n = t.n, g_lo = s_begin / t.sl, g_hi = (s_end - 1) / t.sl;
+    const int mt = (int)((M + TG_BM - 1) / TG_BM);
+    t.host.clear();
+    int mx = 0, tile = 0;
+    auto ncols = [&](int64_t s0, int64_t s1) { return tri ? t.cstart[(size_t)s1] - t.cstart[(size_t)s0] : n * (s1 - s0); };
+    for (int64_t g = g_lo; g <= g_hi; ++g) {
+        const int64_t s0 = std::max(s_begin, g * t.sl), s1 = std::min(s_end, (g + 1) * t.sl);
+        mx = std::max(mx, (int)((ncols(s0, s1) + TG_BN - 1) / TG_BN));
+    }
+    const int gm = tgemm_group_m((int)M, mx);
+    for (int64_t g = g_lo; g <= g_hi; ++g) {
+        const int64_t s0 = std::max(s_begin, g * t.sl), s1 = std::min(s_end, (g + 1) * t.sl);
+        TgGroup d{};
+        d.a1 = d.a2 = 0;
+        d.b1 = d.b2 = n * n * g * t.sl;          // (the tables are relative to the slab's first pair)
+        d.c0 = n * n * g * t.sl;
+        d.colB = tri ? t.colB_tri + t.cstart[(size_t)s0] : t.colB + n * (s0 - g * t.sl);
+        d.offCn = tri ? t.offCn_tri + t.cstart[(size_t)s0] : t.offCn + n * (s0 - g * t.sl);
+        d.N = (int)ncols(s0, s1);
+        d.ntiles = (d.N + TG_BN - 1) / TG_BN;
+        d.tile_start = tile;
+        d.nk1 = d.nk = (int)(t.Kc / TG_BK);
+        d.inv_width = tgemm_inverse(gm * d.ntiles);
+        if ((int64_t)mt * d.ntiles * gm * d.ntiles >= ((int64_t)1 << 32)) throw Error(2, "ao2mo: tile walk out of range");
+        tile += mt * d.ntiles;
+        t.host.push_back(d);
+    }
+    TgGroup end{};
+    end.tile_start = tile;
+    t.host.push_back(end);
+    const int ng = (int)t.host.size() - 1;
+    AFESP_HIP(hipMemcpyAsync(t.groups, t.host.data(), t.host.size() * sizeof(TgGroup), hipMemcpyHostToDevice, cx.stream));
+    TgProblem p{t.ct, in, out, t.rowA, t.offCm, (int)M, true, (int)((n - (t.Kc - TG_BK) + 3) / 4)};
+    AFESP_HIP(tgemm_launch(p, t.groups, ng, tile, mx, cx.stream));
+    cx.sync();   // (t.host / t.groups are reused by the next transform; the launches are milliseconds)
+}
+}  // namespace
+
 // src/mp2.f90:261-449.  Four quarter transforms as MFMA GEMMs; each pass contracts the leading AO index with C(MO,AO) and
 // the planner writes the result with the new MO index in place.
 int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* canon_coeff, const double* canon_levels,
@@ -276,14 +413,37 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         if (!blocked) {
             // Small bases: the whole tensor at once, nine launches.  The two temporaries are cached scratch: a second transform in
             // the same context reuses them, the next afesp_ccsd_init / afesp_ccsd_so_init gives them back.
-            Tensor Ta = view(cx.scratch("ao2mo_a", n * n * np), {n, n, np}), Tb = view(cx.scratch("ao2mo_b", n * n * np), {n, n, np});
+            // (16 doubles of slack behind each: the LDS-DMA GEMM reads whole 16-element K steps, i.e. up to Kc - n elements past a
+            // column's end -- the next column's, finite, times the zero padding of C -- and past the tensor's end behind the last one)
+            Tensor Ta = view(cx.scratch("ao2mo_a", n * n * np + 16), {n, n, np}), Tb = view(cx.scratch("ao2mo_b", n * n * np + 16), {n, n, np});
             if (!have_u) k_unpack_half(cx, Ta.d, ao, (int)n);            // (ij|KL), ij squared up
             ctx->half_n = 0;                                             // the transform overwrites it
-            contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
-            contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348
-            k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                    // (kl|PQ), kl squared up, p >= q
-            contract(cx, 1.0, Cm, "rk", Tb, "klP", 0.0, Ta, "rlP");      // mp2.f90:357-367
-            contract(cx, 1.0, Cm, "sl", Ta, "rlP", 0.0, Tb, "rsP");      // mp2.f90:375-385
+            // the LDS-DMA GEMM: even n, and from n = 96 on (its tile has 128 rows: below that most of a tile is padding and
+            // the transform is launch-bound anyway); AFESP_AO2MO_TG=0 / 1: never / for every even n >= 16 (tests, A/B runs)
+            const char* tg_env = getenv("AFESP_AO2MO_TG");
+            const bool use_tg = n % 2 == 0 && n >= 16 && (tg_env ? tg_env[0] == '1' : n >= 96);
+            if (use_tg) {
+                AFESP_HIP(hipMemsetAsync(Ta.d + n * n * np, 0, 16 * sizeof(double), cx.stream));
+                AFESP_HIP(hipMemsetAsync(Tb.d + n * n * np, 0, 16 * sizeof(double), cx.stream));
+                Ao2moTg tg = ao2mo_tg_prepare(cx, Cm.d, n, np);
+                ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, 0, np, n, false);     // (ij|K) -> (j p|K)        mp2.f90:321-333
+                ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, 0, np, n, false);     // (jp|K) -> (p q|K)        mp2.f90:338-348
+                k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                // (kl|PQ), kl squared up, p >= q
+                // Second pair: only (rs|PQ) with RS <= PQ is packed (mp2.f90:388-410), i.e. r <= p and s <= r.  Rows beyond the
+                // first 128 are therefore skipped for the pairs with p < 128, and the last transform runs over the columns
+                // (r, PQ) with r <= p only -- 2.6 n^5 flop in 128-row tiles instead of 4 (the reference: 8).
+                const int64_t ps = tg.p_split, m_lo = std::min<int64_t>(n, TG_BM);
+                ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, 0, ps, m_lo, false);  // (kl|P) -> (l r|P)        mp2.f90:357-367
+                ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, ps, np, n, false);
+                ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, 0, ps, m_lo, true);   // (lr|P) -> (r s|P)        mp2.f90:375-385
+                ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, ps, np, n, true);
+            } else {
+                contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
+                contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348
+                k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                    // (kl|PQ), kl squared up, p >= q
+                contract(cx, 1.0, Cm, "rk", Tb, "klP", 0.0, Ta, "rlP");      // mp2.f90:357-367
+                contract(cx, 1.0, Cm, "sl", Ta, "rlP", 0.0, Tb, "rsP");      // mp2.f90:375-385
+            }
             k_pack_pairs(cx, packed, Tb.d, (int)n);                      // mp2.f90:388-410
         } else {
             // Large bases: slab by slab.  The first pair of transforms acts on every (kl) pair separately and the second on every
@@ -708,7 +868,7 @@ int afesp_build_fock(afesp_ctx* ctx, int64_t nbasis, const double* density, cons
         // the half-unpacked integrals (ij|KL) live in the scratch buffer the AO->MO transform starts from ("ao2mo_a"): built on
         // the first Fock build of an SCF, reused by every later one and by afesp_ao2mo_mp2
         const int64_t np = nbasis * (nbasis + 1) / 2;
-        double* u = cx.scratch("ao2mo_a", n2 * np);
+        double* u = cx.scratch("ao2mo_a", n2 * np + 16);   // (+16: the size afesp_ao2mo_mp2 asks for, so that it finds this very buffer)
         if (ctx->half_n != nbasis || ctx->half_epoch != cx.scratch_epoch) {
             k_unpack_half(cx, u, ctx->eri_ao_dev, (int)nbasis);
             ctx->half_n = nbasis;

@@ -19,7 +19,8 @@ namespace afesp {
 // column tables.  Device array of ngroups + 1 entries; the last one only carries tile_start.
 struct TgGroup {
     int64_t a1, a2;          // element offsets (from TgProblem::A) of the A panel in K steps [0, nk1) and [nk1, nk)
-    int64_t b2;              // element shift of every B column in K steps [nk1, nk)
+    int64_t b1, b2;          // element shifts of every B column in K steps [0, nk1) and [nk1, nk)
+    int64_t c0;              // element shift of every C element of the group (slabs of one tensor share their column tables)
     const uint32_t* colB;    // [N] byte offsets of the columns of B (from TgProblem::B)
     const int64_t* offCn;    // [N] element offsets of the columns of C
     int N, ntiles, tile_start, nk1, nk;

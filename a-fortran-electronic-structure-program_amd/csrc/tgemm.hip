@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     const char *fa1 = nullptr, *fa2 = nullptr, *fb1 = nullptr, *fb2 = nullptr;
     unsigned voffA[4], voffB[4];
     int pnk = 0, pnk1 = 0, pmrem = 0, pnrem = 0;
+    int64_t pc0 = 0, fc0 = 0;
     const char *pa1 = nullptr, *pa2 = nullptr, *pb1 = nullptr, *pb2 = nullptr;
     bool pending = false;
 
@@ -165,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         pnk1 = g->nk1;
         pa1 = (const char*)(p.A + g->a1);
         pa2 = (const char*)(p.A + g->a2);
-        pb1 = (const char*)p.B;
+        pb1 = (const char*)(p.B + g->b1);
+        pc0 = g->c0;
         pb2 = (const char*)(p.B + g->b2);
         pmrem = p.M - m0;
         pnrem = N - n0;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
             voffA[q] = sr[min(r, lm)] + ((q & 1) ? dch1 : dch0);
             voffB[q] = sr[256 + min(c, ln)] + ((q & 1) ? dch1 : dch0);
         }
-        fnk = pnk; fnk1 = pnk1; fa1 = pa1; fa2 = pa2; fb1 = pb1; fb2 = pb2; fmrem = pmrem; fnrem = pnrem;
+        fnk = pnk; fnk1 = pnk1; fa1 = pa1; fa2 = pa2; fb1 = pb1; fb2 = pb2; fmrem = pmrem; fnrem = pnrem; fc0 = pc0;
         pending = false;
     };
     // The eight 1-KiB transfers of this wave for the cursor's step (A image rows 32w .. 32w+31, then B image rows 32w .. 32w+31 of
@@ -251,7 +253,8 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
     v2d fa0[4], fb0[4], fa1_[4], fb1_[4];
     // acc[i][j][r] = C(m0 + 64 wm + 16 i + (l >> 4) + 4 r, n0 + 64 wn + col(j, l & 15)); offsets from the tile's slot
-    auto store_tile = [&](int slot, int mrem, int nrem) {
+    auto store_tile = [&](int slot, int mrem, int nrem, int64_t c0) {
+        double* const Cg = p.C + c0;
         const int64_t* sc = reinterpret_cast<const int64_t*>(lds + TG_SIDE + slot * TG_SLOT);
         if (mrem >= TG_BM && nrem >= TG_BN && p.c_pairs) {
             int64_t cn[2];
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
                     const int64_t cm = sc[wm * 64 + 16 * i + 4 * r + ff];
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj)
-                        *reinterpret_cast<v2d*>(p.C + cm + cn[jj]) = (v2d){acc[i][2 * jj][r], acc[i][2 * jj + 1][r]};
+                        *reinterpret_cast<v2d*>(Cg + cm + cn[jj]) = (v2d){acc[i][2 * jj][r], acc[i][2 * jj + 1][r]};
                 }
         } else {
             int64_t cn[4];
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
                     const int64_t cm = sc[ml];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (nl[j] < nrem) p.C[cm + cn[j]] = acc[i][j][r];
+                        if (nl[j] < nrem) Cg[cm + cn[j]] = acc[i][j][r];
                 }
         }
     };
@@ -315,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     commit_tile(0);
     int kt = 0, cj = 0, cur = 0, nk_cur = fnk, nk1_cur = fnk1, mrem_cur = fmrem, nrem_cur = fnrem;
+    int64_t c0_cur = fc0;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         fetch_begin(st);
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
 #ifdef TG_STAMPS
             const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
 #endif
-            if (!(a.dbg & 1)) store_tile(cj % TG_NSLOT, mrem_cur, nrem_cur);
+            if (!(a.dbg & 1)) store_tile(cj % TG_NSLOT, mrem_cur, nrem_cur, c0_cur);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -413,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
             nk1_cur = fnk1;
             mrem_cur = fmrem;
             nrem_cur = fnrem;
+            c0_cur = fc0;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no transfer may land in LDS that belongs to the next workgroup
@@ -438,6 +443,7 @@ unsigned tgemm_inverse(int d) { return d <= 1 ? 0u : (unsigned)(((uint64_t)1 << 
 int tgemm_group_m(int M, int max_ntiles)
 {
     const int mtiles = (M + TG_BM - 1) / TG_BM;
+    if (mtiles <= 4) return mtiles;   // few rows: the m-tiles of a column tile side by side (they share its B lines)
     static const int patch = getenv("AFESP_TG_PATCH") ? atoi(getenv("AFESP_TG_PATCH")) : 64;   // tuning knob: tiles per patch
     return std::min(mtiles, std::max(1, (patch + max_ntiles / 2) / std::max(1, max_ntiles)));
 }

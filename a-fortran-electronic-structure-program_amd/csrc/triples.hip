@@ -677,7 +677,9 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
                 TgGroup d;
                 d.a1 = Kc * v2 * g.r;                   // vt(:, ., ., r)
                 d.a2 = Kc * v2 * O + Kc * v2 * g.q;     // vtT(:, ., ., q)
+                d.b1 = 0;
                 d.b2 = Kc * V * ((int64_t)g.r - g.q);   // tt(:, x, r, p) instead of tt(:, x, q, p)
+                d.c0 = 0;
                 d.colB = p->tables32 + ch.tab32_off + g.start;
                 d.offCn = tabs + ch.ntab + g.start;
                 d.N = (int)g.N;

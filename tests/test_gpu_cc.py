@@ -178,6 +178,37 @@ def test_ao2mo_pair_symmetric_transform(eng, n, o, blocked, monkeypatch):
     assert np.array_equal(third, eri_mo) and e3 == e_mp2
 
 
+@pytest.mark.parametrize("n,o", [(16, 3), (24, 5), (58, 5), (130, 9)])
+def test_ao2mo_on_the_lds_dma_gemm(n, o, monkeypatch):
+    """The whole-tensor AO->MO with its four quarter transforms on tgemm_kernel (what even bases from n = 96 on run; forced here
+    for the small ones): K tails of 0, 8, 10 and 2 elements, one and two row tiles, the triangular column list of the last
+    transform, the first-128-rows shortcut for the pairs with p < 128 (n = 130) -- every packed MO integral against the
+    restatement (n <= 58) and against the gather-GEMM path (all n), also from the (ij|KL) copy of a Fock build."""
+    from afesp_amd import inputs
+    from afesp_amd.capi import Engine
+    rng = np.random.default_rng(7 * n + o)
+    eri = rng.standard_normal(inputs.neri(n))
+    c = rng.standard_normal((n, n))
+    e = np.concatenate([-2.0 - rng.random(o), 1.0 + rng.random(n - o)])
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AFESP_AO2MO_TG", mode)
+        monkeypatch.setenv("AFESP_AO2MO_BLOCKED", "0")
+        with Engine(0) as eng:
+            got[mode] = eng.do_mp2_spatial(n, o, c, e, eri)
+            if mode == "1":
+                eng.set_eri(n, eri)
+                eng.build_fock(n, np.eye(n), np.zeros((n, n)))
+                e3, third = eng.do_mp2_spatial(n, o, c, e, None)
+                assert np.array_equal(third, got[mode][1]) and e3 == got[mode][0]
+    scale = max(1.0, np.max(np.abs(got["0"][1])))
+    assert np.max(np.abs(got["1"][1] - got["0"][1])) < 1e-11 * scale
+    assert abs(got["1"][0] - got["0"][0]) < 1e-10 * max(1.0, abs(got["0"][0]))
+    if n <= 58:
+        ref = orc.ao2mo(n, c, eri)
+        assert np.max(np.abs(got["1"][1] - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref)))
+
+
 @pytest.mark.parametrize("device_from", ["1", "1000000000"])
 def test_offset_tables_built_on_the_device_equal_the_host_enumeration(device_from, monkeypatch):
     """The planner writes the big offset tables of a contraction with a kernel and derives the 16-byte-staging flags from the

@@ -32,7 +32,7 @@ static int run_big(int argc, char** argv)
     const int gm = tgemm_group_m(M, nt);
     int tile = 0;
     for (int q = 0; q < ng; ++q) {
-        g[q].a1 = 0; g[q].a2 = (int64_t)M * Kc; g[q].b2 = (int64_t)ng * N * Kc;
+        g[q].a1 = 0; g[q].a2 = (int64_t)M * Kc; g[q].b1 = 0; g[q].b2 = (int64_t)ng * N * Kc; g[q].c0 = 0;
         g[q].colB = d32 + M + (size_t)q * N; g[q].offCn = d64 + M + (size_t)q * N;
         g[q].N = N; g[q].ntiles = nt; g[q].tile_start = tile; g[q].nk1 = nk1; g[q].nk = (q % 6 == 5) ? nk1 : 2 * nk1;
         g[q].inv_width = tgemm_inverse(gm * nt);
@@ -113,7 +113,7 @@ int main(int argc, char** argv)
     for (int q = 0; q < 2; ++q) mx = std::max(mx, (Ns[q] + 127) / 128);
     const int gm = tgemm_group_m(M, mx);
     for (int q = 0; q < 2; ++q) {
-        g[q].a1 = 0; g[q].a2 = (int64_t)M * Kc; g[q].b2 = (int64_t)ncol * Kc;
+        g[q].a1 = 0; g[q].a2 = (int64_t)M * Kc; g[q].b1 = 0; g[q].b2 = (int64_t)ncol * Kc; g[q].c0 = 0;
         g[q].colB = d32 + M + (q ? Ns[0] : 0); g[q].offCn = d64 + M + (q ? Ns[0] : 0);
         g[q].N = Ns[q]; g[q].ntiles = (Ns[q] + 127) / 128; g[q].tile_start = tile; g[q].nk1 = nk1; g[q].nk = q ? (nk1 >= 2 ? nk1 : 2 * nk1) : 2 * nk1;
         g[q].inv_width = tgemm_inverse(gm * g[q].ntiles);
