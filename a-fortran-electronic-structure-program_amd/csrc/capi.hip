@@ -276,19 +276,33 @@ __global__ __launch_bounds__(256) void ao2mo_tables_tri_kernel(uint32_t* colB, i
     }
 }
 
+// columns (x2, S) with x2 < TG_BM only (the pair transposition behind the second transform reads its result (x2, m, S) for
+// x2 <= m only: the rows m < 128 are needed for these columns only), relative to a slab: column c = x2 + 128 Sloc
+__global__ __launch_bounds__(256) void ao2mo_tables_lo_kernel(uint32_t* colB, int64_t* offCn, int n, int cnt, int64_t ncol)
+{
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < ncol + 256; x += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t x2 = x % cnt, sloc = x / cnt;
+        colB[x] = x < ncol ? (uint32_t)(8 * (int64_t)n * (x2 + (int64_t)n * sloc)) : 0u;
+        if (x < ncol + 128) offCn[x] = x < ncol ? x2 + (int64_t)n * n * sloc : 0;
+    }
+}
+
 namespace {
 struct Ao2moTg {
     int64_t n = 0, Kc = 0, sl = 0;   // basis size, padded summation length, (S) pairs per slab (one TgGroup each)
     double* ct = nullptr;
     uint32_t *rowA = nullptr, *colB = nullptr;
     int64_t *offCm = nullptr, *offCn = nullptr;
-    TgGroup* groups = nullptr;
-    std::vector<TgGroup> host;
+    TgGroup* groups = nullptr;       // room for the descriptors of every transform of one call (no host synchronisation between them)
+    int64_t groups_cap = 0, groups_used = 0;
+    std::vector<std::vector<TgGroup>> host;   // ... whose host copies live until the call's final synchronisation
     // columns (r, PQ), r <= p(PQ) only (ao2mo_tables_tri_kernel)
     uint32_t* colB_tri = nullptr;
     int64_t* offCn_tri = nullptr;
     std::vector<int64_t> cstart;     // [np + 1], host copy
     int64_t p_split = 0;             // first pair PQ with p >= TG_BM (the pairs below it need the first 128 rows only)
+    uint32_t* colB_lo = nullptr;     // columns x2 < TG_BM (ao2mo_tables_lo_kernel)
+    int64_t* offCn_lo = nullptr;
 };
 
 // tables and the padded transpose of the coefficient matrix for basis size n (cached scratch: rebuilt per call, microseconds)
@@ -311,7 +325,8 @@ Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_t np)
                        t.colB, t.offCm, t.offCn, (int)n, (int)t.Kc, ncol);
     AFESP_HIP(hipGetLastError());
     const int64_t ng = (np + t.sl - 1) / t.sl;
-    t.groups = (TgGroup*)cx.scratch("ao2mo_tg", (int64_t)((ng + 2) * sizeof(TgGroup) / sizeof(double) + 1));
+    t.groups_cap = 8 * (ng + 2);
+    t.groups = (TgGroup*)cx.scratch("ao2mo_tg", (int64_t)(t.groups_cap * sizeof(TgGroup) / sizeof(double) + 1));
     // the triangular column list of the last transform
     t.cstart.assign((size_t)np + 1, 0);
     for (int64_t pp = 0, P = 0; pp < n; ++pp)
@@ -327,19 +342,31 @@ Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_t np)
     hipLaunchKernelGGL(ao2mo_tables_tri_kernel, dim3((unsigned)std::min<int64_t>(np, 65536)), dim3(256), 0, cx.stream, t.colB_tri, t.offCn_tri,
                        cs_dev, (int)n, np, t.sl);
     AFESP_HIP(hipGetLastError());
+    if (n > TG_BM) {
+        const int64_t nlo = (int64_t)TG_BM * t.sl;
+        t.colB_lo = (uint32_t*)cx.scratch("ao2mo_t32h", (nlo + 256) / 2 + 2);
+        t.offCn_lo = (int64_t*)cx.scratch("ao2mo_t64h", nlo + 128 + 2);
+        hipLaunchKernelGGL(ao2mo_tables_lo_kernel, dim3((unsigned)std::min<int64_t>((nlo + 256 + 255) / 256, 65536)), dim3(256), 0, cx.stream,
+                           t.colB_lo, t.offCn_lo, (int)n, (int)TG_BM, nlo);
+        AFESP_HIP(hipGetLastError());
+    }
     return t;
 }
 
-// one quarter transform over the pairs S in [s_begin, s_end) of `in` (n x n x np), rows m < M of the result only; tri: only the
-// columns (x2, S) with x2 <= p(S) (the rest of `out` is left untouched)
-void ao2mo_tg_xform(Context& cx, Ao2moTg& t, const double* in, double* out, int64_t s_begin, int64_t s_end, int64_t M, bool tri)
+// one quarter transform over the pairs S in [s_begin, s_end) of `in` (n x n x np), rows row0 <= m < row0 + M of the result only;
+// cols: 0 every column (x2, S), 1 only x2 <= p(S), 2 only x2 < 128 (the rest of `out` is left untouched)
+void ao2mo_tg_xform(Context& cx, Ao2moTg& t, const double* in, double* out, int64_t s_begin, int64_t s_end, int64_t M, int cols,
+                    int64_t row0 = 0)
 {
-    if (s_end <= s_begin) return;
+    if (s_end <= s_begin || M <= 0) return;
+    const bool tri = cols == 1, lo = cols == 2;
+    const int64_t nlo = TG_BM;
     const int64_t n = t.n, g_lo = s_begin / t.sl, g_hi = (s_end - 1) / t.sl;
     const int mt = (int)((M + TG_BM - 1) / TG_BM);
-    t.host.clear();
+    t.host.emplace_back();
+    std::vector<TgGroup>& hv = t.host.back();
     int mx = 0, tile = 0;
-    auto ncols = [&](int64_t s0, int64_t s1) { return tri ? t.cstart[(size_t)s1] - t.cstart[(size_t)s0] : n * (s1 - s0); };
+    auto ncols = [&](int64_t s0, int64_t s1) { return tri ? t.cstart[(size_t)s1] - t.cstart[(size_t)s0] : (lo ? nlo : n) * (s1 - s0); };
     for (int64_t g = g_lo; g <= g_hi; ++g) {
         const int64_t s0 = std::max(s_begin, g * t.sl), s1 = std::min(s_end, (g + 1) * t.sl);
         mx = std::max(mx, (int)((ncols(s0, s1) + TG_BN - 1) / TG_BN));
@@ -351,8 +378,8 @@ void ao2mo_tg_xform(Context& cx, Ao2moTg& t, const double* in, double* out, int6
         d.a1 = d.a2 = 0;
         d.b1 = d.b2 = n * n * g * t.sl;          // (the tables are relative to the slab's first pair)
         d.c0 = n * n * g * t.sl;
-        d.colB = tri ? t.colB_tri + t.cstart[(size_t)s0] : t.colB + n * (s0 - g * t.sl);
-        d.offCn = tri ? t.offCn_tri + t.cstart[(size_t)s0] : t.offCn + n * (s0 - g * t.sl);
+        d.colB = tri ? t.colB_tri + t.cstart[(size_t)s0] : lo ? t.colB_lo + nlo * (s0 - g * t.sl) : t.colB + n * (s0 - g * t.sl);
+        d.offCn = tri ? t.offCn_tri + t.cstart[(size_t)s0] : lo ? t.offCn_lo + nlo * (s0 - g * t.sl) : t.offCn + n * (s0 - g * t.sl);
         d.N = (int)ncols(s0, s1);
         d.ntiles = (d.N + TG_BN - 1) / TG_BN;
         d.tile_start = tile;
@@ -360,16 +387,18 @@ void ao2mo_tg_xform(Context& cx, Ao2moTg& t, const double* in, double* out, int6
         d.inv_width = tgemm_inverse(gm * d.ntiles);
         if ((int64_t)mt * d.ntiles * gm * d.ntiles >= ((int64_t)1 << 32)) throw Error(2, "ao2mo: tile walk out of range");
         tile += mt * d.ntiles;
-        t.host.push_back(d);
+        hv.push_back(d);
     }
     TgGroup end{};
     end.tile_start = tile;
-    t.host.push_back(end);
-    const int ng = (int)t.host.size() - 1;
-    AFESP_HIP(hipMemcpyAsync(t.groups, t.host.data(), t.host.size() * sizeof(TgGroup), hipMemcpyHostToDevice, cx.stream));
-    TgProblem p{t.ct, in, out, t.rowA, t.offCm, (int)M, true, (int)((n - (t.Kc - TG_BK) + 3) / 4)};
-    AFESP_HIP(tgemm_launch(p, t.groups, ng, tile, mx, cx.stream));
-    cx.sync();   // (t.host / t.groups are reused by the next transform; the launches are milliseconds)
+    hv.push_back(end);
+    const int ng = (int)hv.size() - 1;
+    if (t.groups_used + (int64_t)hv.size() > t.groups_cap) throw Error(2, "ao2mo: descriptor buffer too small");
+    TgGroup* dev = t.groups + t.groups_used;
+    t.groups_used += (int64_t)hv.size();
+    AFESP_HIP(hipMemcpyAsync(dev, hv.data(), hv.size() * sizeof(TgGroup), hipMemcpyHostToDevice, cx.stream));
+    TgProblem p{t.ct, in, out, t.rowA + row0, t.offCm + row0, (int)M, true, (int)((n - (t.Kc - TG_BK) + 3) / 4)};
+    AFESP_HIP(tgemm_launch(p, dev, ng, tile, mx, cx.stream));
 }
 }  // namespace
 
@@ -426,25 +455,34 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
                 AFESP_HIP(hipMemsetAsync(Ta.d + n * n * np, 0, 16 * sizeof(double), cx.stream));
                 AFESP_HIP(hipMemsetAsync(Tb.d + n * n * np, 0, 16 * sizeof(double), cx.stream));
                 Ao2moTg tg = ao2mo_tg_prepare(cx, Cm.d, n, np);
-                ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, 0, np, n, false);     // (ij|K) -> (j p|K)        mp2.f90:321-333
-                ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, 0, np, n, false);     // (jp|K) -> (p q|K)        mp2.f90:338-348
+                ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, 0, np, n, 0);         // (ij|K) -> (j p|K)        mp2.f90:321-333
+                // (jp|K) -> (x2 m|K), mp2.f90:338-348: the transposition below reads x2 <= m only -- the rows m < 128 are computed
+                // for the columns x2 < 128 only
+                if (n > TG_BM) {
+                    ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, 0, np, n - TG_BM, 0, TG_BM);
+                    ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, 0, np, TG_BM, 2);
+                } else {
+                    ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, 0, np, n, 0);
+                }
                 k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                // (kl|PQ), kl squared up, p >= q
                 // Second pair: only (rs|PQ) with RS <= PQ is packed (mp2.f90:388-410), i.e. r <= p and s <= r.  Rows beyond the
                 // first 128 are therefore skipped for the pairs with p < 128, and the last transform runs over the columns
                 // (r, PQ) with r <= p only -- 2.6 n^5 flop in 128-row tiles instead of 4 (the reference: 8).
                 const int64_t ps = tg.p_split, m_lo = std::min<int64_t>(n, TG_BM);
-                ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, 0, ps, m_lo, false);  // (kl|P) -> (l r|P)        mp2.f90:357-367
-                ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, ps, np, n, false);
-                ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, 0, ps, m_lo, true);   // (lr|P) -> (r s|P)        mp2.f90:375-385
-                ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, ps, np, n, true);
+                ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, 0, ps, m_lo, 0);      // (kl|P) -> (l r|P)        mp2.f90:357-367
+                ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, ps, np, n, 0);
+                ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, 0, ps, m_lo, 1);      // (lr|P) -> (r s|P)        mp2.f90:375-385
+                ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, ps, np, n, 1);
+                k_pack_pairs(cx, packed, Tb.d, (int)n);                  // mp2.f90:388-410
+                cx.sync();                                               // (the descriptors' host copies die with tg)
             } else {
                 contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
                 contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348
                 k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                    // (kl|PQ), kl squared up, p >= q
                 contract(cx, 1.0, Cm, "rk", Tb, "klP", 0.0, Ta, "rlP");      // mp2.f90:357-367
                 contract(cx, 1.0, Cm, "sl", Ta, "rlP", 0.0, Tb, "rsP");      // mp2.f90:375-385
+                k_pack_pairs(cx, packed, Tb.d, (int)n);                  // mp2.f90:388-410
             }
-            k_pack_pairs(cx, packed, Tb.d, (int)n);                      // mp2.f90:388-410
         } else {
             // Large bases: slab by slab.  The first pair of transforms acts on every (kl) pair separately and the second on every
             // (pq) pair, so only the half-transformed integrals have to exist as a whole -- pair-packed, g(PQ,K), np^2 doubles
