@@ -1,7 +1,10 @@
-"""Multi-GPU layout of the path: only (T) shards.
+"""Helpers for the multi-GPU layout of the path: equal-count shard ranges.
 
-Each rank owns a contiguous slice of the (i<=j<=k) triple list; the four partial scalars E[T], E(T), D[T], D(T) are
-combined with ONE all-reduce (RCCL over xGMI on the GPU box, gloo in the CPU tests).  CCSD itself runs as replicas.
+Each rank owns a contiguous slice of the triple list -- (i<=j<=k) for the spin-free (T), where the engine's own cost-balanced
+bounds (Engine.shard_bounds) are what bench.py and els_amd use, (i<j<k) for the spin-orbital one, which uses shard_range below --
+and the partial scalars are combined with ONE all-reduce: the product's afesp_allreduce_sum (ncclAllReduce on the engine stream, or
+the host segment when rehearsing ranks share a GPU); gloo only in the CPU tests.  The CCSD iteration runs as replicas unless the
+caller opts into the rank split (Engine.ccsd_set_split / AFESP_CC_SHARD=1): bench.py does after checking it on its ranks.
 """
 from __future__ import annotations
 

@@ -15,6 +15,8 @@
 // result register r of lane l is C[m = (l>>4) + 4r][n = l&15]  (cdna_hip_programming.md section 3).
 #include "gett.h"
 
+#include <cstdlib>
+
 namespace afesp {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -614,6 +616,8 @@ extern int g_group_m, g_allow_wide;
 #else
 int g_group_m = 0;   // >0 overrides the tile-walk group size (tuning knob, see afesp_set_tuning)
 int g_force_tm = 0, g_force_tn = 0, g_force_split = 0, g_allow_wide = 1;
+// K is sliced when a product has fewer tiles than this (tuning knob AFESP_SPLIT_BELOW)
+static const int g_split_below = getenv("AFESP_SPLIT_BELOW") ? atoi(getenv("AFESP_SPLIT_BELOW")) : 192;
 
 // Block tile extent (rows or columns) for a requested code: 1 -> 32, 2 -> 64, 4 -> 128; 8 = 128 with 8 waves.
 static int pick_t(int extent)
@@ -667,7 +671,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
         split = force_split;
     } else if (wq_split > 1) {
         split = wq_split;
-    } else if (tiles < 192 && ksteps >= 8) {
+    } else if (tiles < g_split_below && ksteps >= 8) {
         // too few tiles to fill 256 CUs: slice K, at least 4 K steps per slice, aim for ~2 blocks per CU
         split = (int)((512 + tiles - 1) / tiles);
         if (split > ksteps / 4) split = ksteps / 4;

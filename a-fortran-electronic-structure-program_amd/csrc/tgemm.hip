@@ -65,6 +65,12 @@ struct TgArgs {
     unsigned* tickets;
     int chunk;                 // grid / 8
     unsigned inv_chunk;
+    // Time-sliced priority.  At equal priority the older wave of a SIMD wins the matrix pipe, i.e. the workgroup dispatched first
+    // on a CU runs at up to twice the speed of the second (tools/tgemm_check.hip, stamps: the first half of the grid ends its 8th
+    // tile 0.07 ms after the earliest, the second half 0.26 ms; with s_setprio 3 on the second half it is the other way round).
+    // So the halves of the grid take turns: in slices of 2^prio_shift x 10 ns of the device-wide clock (s_memrealtime) one half
+    // runs at priority 1, then the other -- no communication, and the two workgroups of a CU stay level.  0: off.
+    int prio_shift;
 };
 
 #ifdef TG_STAMPS
@@ -335,7 +341,10 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     // ---- stream of steps.  Everything that is not an MFMA is issued in the gaps between MFMAs (a 64-cycle MFMA leaves its wave
     // free to issue other instructions meanwhile): a wave whose partner on the SIMD is parked -- at its barrier, in its tile
     // epilogue -- then keeps the matrix pipe busy by itself.  sched_barrier pins the order written here.
+    const unsigned my_half = (int)blockIdx.x >= nwg / 2 ? 1u : 0u;
+    bool prio_hi = false;
     for (;;) {
+        const unsigned long long rt = a.prio_shift ? __builtin_amdgcn_s_memrealtime() : 0ull;   // (consumed behind the barrier)
         // K tail of this step (header): t3 = its second half has one pass of single-double fragments, t2 = no second half
         const bool ktl = (kt + 1 == nk1_cur || kt + 1 == nk_cur) && p.ktail4 < 4;
         const bool t3 = ktl && p.ktail4 == 3;   // (fewer groups: the second half is all zeros, its first pass then runs on them)
@@ -369,6 +378,14 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         }
 #endif
         TG_SB;
+        if (a.prio_shift) {
+            const bool hi = (((unsigned)(rt >> a.prio_shift)) & 1u) == my_half;
+            if (hi != prio_hi) {
+                if (hi) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+                prio_hi = hi;
+            }
+        }
         // the stage just read is free; the other one holds the next step, whose first-half fragments are requested in the first
         // eight gaps of the second half
         const int freed = cur;
@@ -480,6 +497,8 @@ hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngrou
     static const int grid_env = getenv("AFESP_TG_GRID") ? atoi(getenv("AFESP_TG_GRID")) : 0;   // diagnostic: fewer workgroups, longer tile streams
     const unsigned grid = (unsigned)std::min(total_tiles, grid_env > 0 ? grid_env : cap);
     // tickets: launches of many rounds of tiles whose grid splits evenly over the XCDs (AFESP_TG_DYNAMIC=0: always static)
+    static const int prio_env = getenv("AFESP_TG_PRIO_SHIFT") ? atoi(getenv("AFESP_TG_PRIO_SHIFT")) : 11;   // 2^11 x 10 ns = 20 us slices
+    a.prio_shift = (int64_t)total_tiles >= (int64_t)2 * grid ? prio_env : 0;
     static const bool dyn_env = !(getenv("AFESP_TG_DYNAMIC") && getenv("AFESP_TG_DYNAMIC")[0] == '0');
     static const bool dyn_force = getenv("AFESP_TG_DYNAMIC") && getenv("AFESP_TG_DYNAMIC")[0] == '2';   // tests: also for small launches
     static unsigned* tickets[16] = {};

@@ -14,7 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 - "$O/${TAG}_pmc_ao2mo_fock.json" <<'PY'
 import collections, csv, glob, json, sys
-out = {"note": "mean per dispatch; FETCH_SIZE [KB] x 1024 x 2 (gfx950 correction, DESIGN.md section 5), WRITE_SIZE [KB] x 1024; "
+out = {"note": "mean per dispatch (and *_per_call: summed over the dispatches of one transform / one Fock build); FETCH_SIZE [KB] x 1024 x 2 (gfx950 correction, DESIGN.md section 5), WRITE_SIZE [KB] x 1024; "
                "durations from the kernel trace of the same pass; n = 220 (npair = 24310)", "kernels": {}}
 for tag in ("ao", "fk"):
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -28,12 +28,15 @@ for tag in ("ao", "fk"):
             for r in csv.DictReader(open(f)):
                 agg[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
             for k, v in agg.items():
-                if not any(s in k for s in ("pair_square", "pack_pairs", "gett_kernel", "fock_")):
+                if not any(s in k for s in ("pair_square", "pack_pairs", "gett_kernel", "tgemm_kernel", "fock_")):
                     continue
                 e = out["kernels"].setdefault(tag + ": " + k, {"dispatches": len(v)})
                 e["fetch_GB" if c == "FETCH_SIZE" else "write_GB"] = sum(v) / len(v) * 1024 * (2 if c == "FETCH_SIZE" else 1) / 1e9
+                # (the transform's GEMM launches differ in size: also the sum over one call -- the timing scripts make 2 calls)
+                e["fetch_GB_per_call" if c == "FETCH_SIZE" else "write_GB_per_call"] = sum(v) / 2 * 1024 * (2 if c == "FETCH_SIZE" else 1) / 1e9
                 if k in dur:
                     e["ms_under_pmc"] = sum(dur[k]) / len(dur[k])
+                    e["ms_per_call_under_pmc"] = sum(dur[k]) / 2
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 PY
 echo done

@@ -63,6 +63,10 @@ static int run_big(int argc, char** argv)
     }
     printf("stamps over %d waves: cycles per step %.0f (MFMA floor 8192 at two waves per SIMD), of which barrier %.0f; per tile: epilogue %.0f; longest barrier %.0f\n",
            n, tot / steps, bar / steps, epi / tiles, mx);
+    { double lo = 0, hi = 0; int nl = 0, nh = 0; unsigned long long base = ~0ull;
+      for (int b = 0; b < 512; ++b) { const unsigned long long t8 = st[((size_t)b * 4) * 8 + 6]; if (t8) base = std::min(base, t8); }
+      for (int b = 0; b < 512; ++b) { const unsigned long long t8 = st[((size_t)b * 4) * 8 + 6]; if (!t8) continue; if (b < 256) { lo += t8 - base; ++nl; } else { hi += t8 - base; ++nh; } }
+      printf("  mean time of the 8th tile's end after the earliest: workgroups 0..255 %.0f, 256..511 %.0f (x 10 ns)\n", nl ? lo / nl : 0.0, nh ? hi / nh : 0.0); }
     // when did the workgroups of an XCD (b & 7) finish their 8th tile?  spread in units of 10 ns; a K step is ~370 units
     for (int x = 0; x < 8; ++x) {
         unsigned long long lo = ~0ull, hi = 0;
