@@ -276,16 +276,27 @@ static std::vector<int64_t> assemble_pool(Context& cx, int64_t nblocks, int64_t 
     return off;
 }
 
-// Plan of the spin-orbital (T): i<j<k, three blocks per triple, one launch per integral slab and chunk.
+static bool fused_use_tg(int o, int v);
+
+// Plan of the spin-orbital (T): i<j<k, three blocks per triple; one tgemm_kernel launch per chunk (or, under AFESP_T_GEMM=gett, one
+// gather-GEMM launch per integral slab and chunk).
 static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_begin, int64_t t_end)
 {
     TriplesPlan* p = (TriplesPlan*)slot;
-    if (p && p->o == o && p->v == v && p->t_begin == t_begin && p->t_end == t_end && p->mode == 1 && p->epoch == cx.scratch_epoch) return p;
+    if (p && p->o == o && p->v == v && p->t_begin == t_begin && p->t_end == t_end && p->mode == 1 && p->epoch == cx.scratch_epoch &&
+        p->use_tg == (fused_use_tg(o, v) && (((int64_t)v + o + 15) / 16 * 16) >= 2 * TG_BK))
+        return p;
     delete p;
     p = new TriplesPlan();
     slot = p;
     const int64_t O = o, V = v, Kc = (V + O + 15) / 16 * 16;   // padded, see ccsd_triples
     p->o = o; p->v = v; p->t_begin = t_begin; p->t_end = t_end; p->cr = false; p->mode = 1;
+    // the products of this path on the LDS-DMA kernel too (tgemm.h): K-contiguous operands, one run of the summation index per group
+    p->use_tg = fused_use_tg(o, v) && Kc >= 2 * TG_BK;
+    p->c_pairs = (v % 2) == 0;
+    std::vector<uint32_t> tab32;
+    if (p->use_tg)
+        for (int64_t m = 0; m < V * V; ++m) tab32.push_back((uint32_t)(8 * Kc * m));
     // chunk size: 6 X blocks of (padded) v^3 doubles per triple; W never leaves LDS
     const int64_t nt8 = (V + TT - 1) / TT, vp3 = nt8 * nt8 * nt8 * CUBE;   // a block is stored cube by cube, edges padded to 8
     const int64_t per = 3 * vp3 * (int64_t)sizeof(double);
@@ -332,6 +343,10 @@ static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_b
             if (N > 0) ch.groups.push_back({r, start, N});
         }
         ch.ntab = (int64_t)hBn.size();
+        if (p->use_tg) {
+            ch.tab32_off = (int64_t)tab32.size();
+            for (int64_t x : hBn) tab32.push_back((uint32_t)(8 * x));
+        }
         ch.tab_off = (int64_t)tab.size();
         tab.insert(tab.end(), hBn.begin(), hBn.end());
         tab.insert(tab.end(), hCn.begin(), hCn.end());
@@ -372,10 +387,47 @@ static TriplesPlan* plan_for(Context& cx, void*& slot, int o, int v, int64_t t_b
             for (int C = B; C < nt8; ++C) orb.push_back(A | (B << 10) | (C << 20));
     p->norb = (int)orb.size();
     // (names of their own: a spin-free plan cached in the same context keeps pointing at its tables)
+    tab.resize(tab.size() + 128, 0);   // (the LDS-DMA kernel reads its tables in whole 1-KiB pieces, tgemm.h)
     p->tables = (int64_t*)cx.scratch("so_tables", (int64_t)tab.size());
     p->meta = (TripleMeta*)cx.scratch("so_meta", (int64_t)(metas.size() * sizeof(TripleMeta) / sizeof(double) + 1));
     p->orbits = (int*)cx.scratch("so_orbits", (int64_t)orb.size() / 2 + 1);
     AFESP_HIP(hipMemcpyAsync(p->tables, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
+    std::vector<TgGroup> tg;
+    if (p->use_tg) {
+        tab32.resize(tab32.size() + 256, 0u);
+        p->tables32 = (uint32_t*)cx.scratch("so_tables32", (int64_t)(tab32.size() / 2 + 1));
+        AFESP_HIP(hipMemcpyAsync(p->tables32, tab32.data(), tab32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, cx.stream));
+        const int64_t v2 = V * V;
+        const int mt = (int)((v2 + TG_BM - 1) / TG_BM);
+        for (TriplesPlan::Chunk& ch : p->chunks) {
+            const int64_t* tabs = p->tables + ch.tab_off;
+            ch.tg_off = (int64_t)tg.size();
+            int mx = 0, tile = 0;
+            for (const TriplesPlan::Group& g : ch.groups) mx = std::max(mx, (int)((g.N + TG_BN - 1) / TG_BN));
+            const int gm = tgemm_group_m((int)v2, mx);
+            for (const TriplesPlan::Group& g : ch.groups) {
+                TgGroup d{};
+                d.a1 = d.a2 = Kc * v2 * g.r;            // vt(:, ., ., r)
+                d.colB = p->tables32 + ch.tab32_off + g.start;
+                d.offCn = tabs + ch.ntab + g.start;
+                d.N = (int)g.N;
+                d.ntiles = (int)((g.N + TG_BN - 1) / TG_BN);
+                d.tile_start = tile;
+                d.nk1 = d.nk = (int)(Kc / TG_BK);
+                d.inv_width = tgemm_inverse(gm * d.ntiles);
+                tile += mt * d.ntiles;
+                tg.push_back(d);
+            }
+            TgGroup end{};
+            end.tile_start = tile;
+            tg.push_back(end);
+            ch.tg_ngroups = (int)ch.groups.size();
+            ch.tg_tiles = tile;
+            ch.tg_max_ntiles = mx;
+        }
+        p->tgdesc = (TgGroup*)cx.scratch("so_tgdesc", (int64_t)(tg.size() * sizeof(TgGroup) / sizeof(double) + 1));
+        AFESP_HIP(hipMemcpyAsync(p->tgdesc, tg.data(), tg.size() * sizeof(TgGroup), hipMemcpyHostToDevice, cx.stream));
+    }
     AFESP_HIP(hipMemcpyAsync(p->meta, metas.data(), metas.size() * sizeof(TripleMeta), hipMemcpyHostToDevice, cx.stream));
     AFESP_HIP(hipMemcpyAsync(p->orbits, orb.data(), orb.size() * sizeof(int), hipMemcpyHostToDevice, cx.stream));
     cx.sync();   // the host vectors die here
@@ -1059,6 +1111,10 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
     double* partial = cx.scratch("t_partial", std::max<int64_t>((int64_t)p->norb * p->nb, 512));
     for (const TriplesPlan::Chunk& ch : p->chunks) {
         const int64_t* tabs = p->tables + ch.tab_off;
+        if (p->use_tg) {
+            TgProblem tp{vt.d, tt.d, Xpool, p->tables32, p->tables + p->off_Cm, (int)v2, p->c_pairs, (int)((V + O - (Kc - TG_BK) + 3) / 4)};
+            AFESP_HIP(tgemm_launch(tp, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream));
+        } else
         for (const TriplesPlan::Group& g : ch.groups) {
             GettProblem gp;
             gp.A = vt.d + Kc * v2 * g.r;
