@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
                 for (int r = 0; r < 4; ++r) {
                     const int64_t cm = sc[wm * 64 + 16 * i + 4 * r + ff];
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
+                    for (int jj = 0; jj < 2; ++jj)   // (scalar base + 32-bit offset instead of 64-bit addresses: same time, measured)
                         *reinterpret_cast<v2d*>(Cg + cm + cn[jj]) = (v2d){acc[i][2 * jj][r], acc[i][2 * jj + 1][r]};
                 }
         } else {
