@@ -646,7 +646,27 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
     g.batchC = bC;
     g.a_kcontig = p.a_kc; g.b_kcontig = p.b_kc;
     g.wide = p.wide && ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0);
+    // AFESP_CONTRACT_TRACE=1 (tools/contract_trace.py): every product alone on the device, its labels, extents and time on stderr
+    static const bool trace = getenv("AFESP_CONTRACT_TRACE") != nullptr;
+    if (!trace) {
+        AFESP_HIP(gett_launch(g, cx.ws, cx.stream, force_split, force_tm, force_tn));
+        return;
+    }
+    hipEvent_t e0, e1;
+    AFESP_HIP(hipEventCreate(&e0));
+    AFESP_HIP(hipEventCreate(&e1));
+    AFESP_HIP(hipDeviceSynchronize());
+    AFESP_HIP(hipEventRecord(e0, cx.stream));
     AFESP_HIP(gett_launch(g, cx.ws, cx.stream, force_split, force_tm, force_tn));
+    AFESP_HIP(hipEventRecord(e1, cx.stream));
+    AFESP_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    AFESP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double fl = 2.0 * g.M * (double)g.N * g.K * nbatch, by = 8.0 * (A0.size() + B0.size() + C.size());
+    fprintf(stderr, "contract %-6s,%-6s>%-6s M %7d N %7d K %7d akc %d bkc %d wide %d %9.1f us %6.2f TF %7.1f GB/s%s\n", la0, lb0, lc, g.M, g.N,
+            g.K, (int)g.a_kcontig, (int)g.b_kcontig, (int)g.wide, ms * 1e3, fl / ms * 1e-9, by / ms * 1e-6, cx.in_repack ? "  (repacked)" : "");
 }
 
 // ------------------------------------------------------------------ permute_add
