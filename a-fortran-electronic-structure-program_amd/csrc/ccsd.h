@@ -40,7 +40,7 @@ struct CCState : DiisRing {
     int64_t pp_nm = 0;                                     // rows the row tables cover: max(v(v+1)/2, o v)
     double *ov_ws = nullptr, *ov_wa = nullptr;             // the same split of <ef|ia> (v_vvov) for I_ooov_p, built at init
     Tensor I_vo, I_vv, I_oo_p, I_oo, c, asym, x_voov, I_oooo, I_ovov, I_voov, I_ooov_p;
-    Tensor y_ooov, y_oovo;         // t1-dressed pieces that stand in for I_vovv_p (ccsd_intermediates)
+    Tensor z_ooov;                 // I_ooov_p plus the t1-dressed pieces that stand in for I_vovv_p (ccsd_intermediates)
     double energy = 0.0, energy_old = 0.0, rms = 0.0;
     void* tplan = nullptr;      // cached (T) launch plan (triples.hip)
     Tensor I_vovv_pp, I_ooov_pp;   // completely renormalised moments (ccsd.f90:2338-2551), built on request

@@ -54,7 +54,7 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     s.I_vo = cx.tensor({V, O}); s.I_vv = cx.tensor({V, V}); s.I_oo_p = cx.tensor({O, O}); s.I_oo = cx.tensor({O, O});
     s.c = cx.tensor({O, O, V, V}); s.asym = cx.tensor({O, O, V, V}); s.x_voov = cx.tensor({V, O, O, V});
     s.I_oooo = cx.tensor({O, O, O, O}); s.I_ovov = cx.tensor({O, V, O, V}); s.I_voov = cx.tensor({V, O, O, V});
-    s.I_ooov_p = cx.tensor({O, O, O, V}); s.y_ooov = cx.tensor({O, O, O, V}); s.y_oovo = cx.tensor({O, O, V, O});
+    s.I_ooov_p = cx.tensor({O, O, O, V}); s.z_ooov = cx.tensor({O, O, O, V});
     // pp-ladder (ccsd.f90:1669) over the symmetry-unique column pairs a <= b
     {
         const int64_t np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
@@ -129,7 +129,7 @@ void ccsd_free(Context& cx, CCState& s)
     if (s.eri_own) cx.release(s.eri_own);
     double* bufs[] = {s.e, s.v_oovv.d, s.v_ovov.d, s.v_vvov.d, s.v_oovo.d, s.v_oooo.d, s.v_vvvv.d, s.w_oovv.d, s.w_vvov.d,
                       s.w_oovo.d, s.D1.d, s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.I_vo.d, s.I_vv.d, s.I_oo_p.d, s.I_oo.d, s.c.d,
-                      s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_ooov_p.d, s.y_ooov.d, s.y_oovo.d, s.amp_s, s.hist_t,
+                      s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_ooov_p.d, s.z_ooov.d, s.amp_s, s.hist_t,
                       s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d, s.pp, (double*)s.pp_tab, s.pp_vs, s.pp_va, s.pp_cs,
                       s.pp_ca, s.pp_ps, s.pp_pa, s.bmat, s.ov_ws, s.ov_wa};
     for (double* b : bufs) cx.release(b);
@@ -257,11 +257,17 @@ void ccsd_intermediates(Context& cx, CCState& s)
     lane(4);
     // I_vovv_p(c,i,a,b) = <ab|ci> - t(m,a) <mi|cb> - t(m,b) <ma|ic>          ccsd.f90:1255-1272, :1296-1299
     // is only ever contracted with t(i,e) over its first index (:1700), so the o v^3 tensor is not formed: the first term
-    // is contracted from v_vvov directly (ccsd_amplitudes) and the two t1-dressed terms go through these o^3 v tensors,
-    //   y_ooov(i,m,j,b) = t(i,e) <mj|eb>,   y_oovo(i,m,a,j) = t(i,e) <ma|je>
-    // (three passes over o v^3 elements less per iteration; ccsd_build_I_vovv_p forms the tensor itself on request)
-    C(1.0, s.t1, "ie", s.v_oovv, "mjeb", 0.0, s.y_ooov, "imjb");
-    C(1.0, s.t1, "ie", s.v_ovov, "maje", 0.0, s.y_oovo, "imaj");
+    // is contracted from v_vvov directly (ccsd_amplitudes) and the two t1-dressed terms go through o^3 v tensors,
+    //   y_ooov(i,m,j,b) = t(i,e) <mj|eb>,   y_oovo(i,m,a,j) = t(i,e) <ma|je>,
+    //   r2(ijab) -= t(m,a) y_ooov(i,m,j,b) + t(m,b) y_oovo(i,m,a,j)
+    // (three passes over o v^3 elements less per iteration; ccsd_build_I_vovv_p forms the tensor itself on request).
+    // The residual only ever enters as r2(ijab) + r2(jiba) (P(ia/jb), t2_update_kernel), so a term may be replaced by its image
+    // under (i <-> j, a <-> b): the second one becomes -t(m,a) y_oovo(j,m,b,i), and with the I_ooov_p term of :1705-1715,
+    // -t(m,a) I_ooov_p(i,j,m,b), all three are ONE product with
+    //   z_ooov(i,j,m,b) = y_ooov(i,m,j,b) + y_oovo(j,m,b,i) + I_ooov_p(i,j,m,b)
+    // -- two passes over the o^2 v^2 residual less (0.27 ms of 27 at o = 20, v = 200; two launches less for a small system).
+    C(1.0, s.t1, "ie", s.v_oovv, "mjeb", 0.0, s.z_ooov, "ijmb");
+    C(1.0, s.t1, "je", s.v_ovov, "mbie", 1.0, s.z_ooov, "ijmb");
     lane(5);
     // I_ooov_p(j,k,i,a)                                                  ccsd.f90:1302-1308
     permute_add(cx, 1.0, s.v_oovo, "kjai", 0.0, s.I_ooov_p, "jkia");
@@ -270,6 +276,7 @@ void ccsd_intermediates(Context& cx, CCState& s)
     if (par) cx.wait(x_voov_ready);
     C(1.0, s.t1, "je", s.x_voov, "ekia", 1.0, s.I_ooov_p, "jkia");
     if (par) cx.join();
+    k_axpby(cx, s.z_ooov.d, 1.0, s.I_ooov_p.d, 1.0, s.z_ooov.size());
 }
 
 // Particle-particle ladder (src/ccsd.f90:1669), the O(o^2 v^4) term.  pp(ijab) = sum_ef c(ij,ef) <ef|ab> obeys
@@ -395,7 +402,7 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     const int64_t v0 = sh ? (int64_t)s.v * s.sh_rank / s.sh_world : 0, v1 = sh ? (int64_t)s.v * (s.sh_rank + 1) / s.sh_world : s.v;
     auto sl = [&](const Tensor& t, int axis) { return slice_axis(t, axis, v0, v1); };
     auto lane = [&](int i) { if (par) cx.use_lane(i); };
-    Tensor r2b = s.r2, r2c = s.r2, r2d = s.r2, r1b = s.r1;
+    Tensor r2b = s.r2, r2c = s.r2, r1b = s.r1;
     Tensor r2s = s.r2;              // receives the three ring products: the rank-partial buffer when the iteration is split
     if (sh) {
         r2s.d = s.r2_sh;
@@ -405,7 +412,6 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     if (par) {
         r2b.d = cx.scratch("r2_lane2", s.r2.size());
         r2c.d = cx.scratch("r2_lane3", s.r2.size());
-        r2d.d = cx.scratch("r2_lane4", s.r2.size());
         r1b.d = cx.scratch("r1_lane5", s.r1.size());
         cx.fork(6);
     }
@@ -429,8 +435,6 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     C(-1.0, s.t2, "miba", s.I_oo, "jm", 1.0, s.r2, "ijab");                // :1654-1664
     lane(4);
     ccsd_pp_ladder(cx, s);                                                 // :1669  particle-particle ladder
-    C(-1.0, s.t1, "ma", s.y_ooov, "imjb", par ? 0.0 : 1.0, r2d, "ijab");   // :1700, t1-dressed parts of t(i,e) I_vovv_p(e,j,a,b)
-    C(-1.0, s.t1, "mb", s.y_oovo, "imaj", 1.0, r2d, "ijab");
     lane(1);
     C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");              // :1673  hole-hole ladder
     lane(2);
@@ -445,13 +449,12 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     lane(3);
     if (!sh) C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
     C(1.0, s.t1, "ie", s.v_vvov, "baje", 1.0, r2c, "ijab");                // :1700, bare part: t(i,e) <ab|ej>
-    C(-1.0, s.t1, "ma", s.I_ooov_p, "ijmb", 1.0, r2c, "ijab");             // :1705-1715
+    C(-1.0, s.t1, "ma", s.z_ooov, "ijmb", 1.0, r2c, "ijab");               // :1705-1715 and the t1-dressed parts of :1700 (ccsd_intermediates)
     if (par) {
         cx.join();
         k_axpby(cx, s.r1.d, 1.0, r1b.d, 1.0, s.r1.size());
         k_axpby(cx, s.r2.d, 1.0, r2b.d, 1.0, s.r2.size());
         k_axpby(cx, s.r2.d, 1.0, r2c.d, 1.0, s.r2.size());
-        k_axpby(cx, s.r2.d, 1.0, r2d.d, 1.0, s.r2.size());
     }
     if (sh) {
         // the one exchange of a split iteration: sum over ranks of [PP | r2_sh] (64 + 128 MB at o = 20, v = 200), in place

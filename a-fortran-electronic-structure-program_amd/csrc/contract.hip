@@ -508,9 +508,12 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
             for (auto& l : N) Nd *= l.dim;
             const int64_t limit = (int64_t)1 << 28;
             int which = 0;   // 1 = A, 2 = B (kernel roles)
+            // (... or when the other operand is so much larger that the copy is small change beside streaming it:
+            // asym(m,i,e,f) <ef|ma> -> r1(i,a) at o = 20, v = 200 reads 1.28 GB of integrals against 128 MB of amplitudes that it
+            // would otherwise gather 8 bytes at a time -- 0.76 -> 0.45 ms)
             if (nbatch == 1 && !bA0 && !bB0 && !cx.in_repack) {
-                if (!b_ok && Md >= 512 && B.size() <= limit) which = 2;
-                else if (!a_ok && Nd >= 512 && A.size() <= limit) which = 1;
+                if (!b_ok && (Md >= 512 || A.size() >= 8 * B.size()) && B.size() <= limit) which = 2;
+                else if (!a_ok && (Nd >= 512 || B.size() >= 8 * A.size()) && A.size() <= limit) which = 1;
             }
             if (which) {
                 const Tensor& T = which == 1 ? A : B;

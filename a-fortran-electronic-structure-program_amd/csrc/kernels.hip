@@ -315,7 +315,8 @@ void k_t2_update(Context& cx, double* t2, const double* r2, const double* v_oovv
 {
     LAUNCH(t2_update_kernel, dim3(grid_for((int64_t)o * o * v * v)), t2, r2, v_oovv, D2, pp, o, v);
 }
-// r2_full(ijab) = r2(ijab) + 1/2 pp(ijab): the residual as the reference holds it before P(ia/jb) (tests / get_tensor)
+// r2_full(ijab) = r2(ijab) + 1/2 pp(ijab): the residual before P(ia/jb) (tests / get_tensor) -- the reference's tmp_t2 up to terms that are
+// held as their images under (i <-> j, a <-> b) (ccsd.hip, z_ooov): r2_full(ijab) + r2_full(jiba) is what equals the reference's
 __global__ void r2_full_kernel(double* out, const double* r2, const double* pp, int o, int v)
 {
     const int64_t n = (int64_t)o * o * v * v;

@@ -66,7 +66,9 @@ int afesp_ccsd_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2
 /* Named device tensor -> host (tests / debugging).  Names: v_oovv v_ovov v_vvov v_oovo v_oooo v_vvvv I_vo I_vv I_oo_p
  * I_oo c_oovv asym_t2 x_voov I_oooo I_ovov I_voov I_vovv_p I_ooov_p r1 r2 D1 D2 t1 t2
  * (v_vvvv and I_vovv_p are not kept by a large system's iteration and are formed by this call; v_vvvv needs the packed MO
- * integrals the solver was initialised from: status 1 if afesp_ao2mo_mp2 has replaced them since afesp_ccsd_init) */
+ * integrals the solver was initialised from: status 1 if afesp_ao2mo_mp2 has replaced them since afesp_ccsd_init;
+ * r2 is the T2 residual before P(ia/jb) up to terms held as their images under (i <-> j, a <-> b): r2(ijab) + r2(jiba) is what
+ * equals the same sum of the reference's tmp_t2, src/ccsd.f90:1720-1728) */
 int afesp_ccsd_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t capacity);
 /* intermediates / amplitude equations separately (src/ccsd.f90:350,357), for term-by-term parity tests */
 int afesp_ccsd_update_intermediates(afesp_ctx* ctx);

@@ -7,6 +7,12 @@ import orc
 
 pytestmark = pytest.mark.gpu
 
+def _p(r2):
+    """The residual as it enters the amplitudes, r2(ijab) + r2(jiba) (P(ia/jb), src/ccsd.f90:1720-1728): the engine holds some terms as
+    their images under (i <-> j, a <-> b) (csrc/ccsd.hip, z_ooov), which only this sum is invariant under."""
+    return r2 + r2.transpose(1, 0, 3, 2)
+
+
 INTERMEDIATES = ["asym_t2", "c_oovv", "I_vo", "I_vv", "I_oo_p", "I_oo", "I_oooo", "I_ovov", "I_voov", "I_vovv_p", "x_voov",
                  "I_ooov_p"]
 SLICES = ["v_oovv", "v_ovov", "v_vvov", "v_oovo", "v_oooo", "v_vvvv", "D1", "D2"]
@@ -117,8 +123,8 @@ def test_one_iteration_term_by_term(eng, o, v):
         assert np.max(np.abs(eng.tensor(name) - cc.field(name))) < tol, name
     cc.L.orc_cc_amplitudes(cc.h)
     eng.update_amplitudes()
-    for name in ["r1", "r2"]:
-        assert np.max(np.abs(eng.tensor(name) - cc.field(name))) < tol, name
+    assert np.max(np.abs(eng.tensor("r1") - cc.field("r1"))) < tol
+    assert np.max(np.abs(_p(eng.tensor("r2")) - _p(cc.field("r2")))) < tol
     g1, g2 = eng.amplitudes()
     assert np.max(np.abs(g1 - cc.t1)) < tol and np.max(np.abs(g2 - cc.t2)) < tol
 
@@ -140,7 +146,7 @@ def test_pp_ladder_split_form_on_ragged_extents(eng, o, v, monkeypatch):
     eng.set_amplitudes(t1, t2)
     cc.L.orc_cc_intermediates(cc.h); cc.L.orc_cc_amplitudes(cc.h)
     eng.update_intermediates(); eng.update_amplitudes()
-    assert np.max(np.abs(eng.tensor("r2") - cc.field("r2"))) < 1e-12
+    assert np.max(np.abs(_p(eng.tensor("r2")) - _p(cc.field("r2")))) < 1e-12
     g1, g2 = eng.amplitudes()
     assert np.max(np.abs(g1 - cc.t1)) < 1e-12 and np.max(np.abs(g2 - cc.t2)) < 1e-12
     monkeypatch.setenv("AFESP_PP_SYM", "0")
