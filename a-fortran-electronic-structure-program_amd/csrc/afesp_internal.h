@@ -32,6 +32,7 @@ struct Tensor {
     int rank = 0;
     int64_t dim[6] = {0, 0, 0, 0, 0, 0};
     int64_t stride[6] = {0, 0, 0, 0, 0, 0};
+    int64_t frozen = 0;   // non-zero: an id under which the contents never change (MO integrals): re-laid-out copies are kept (contract)
     int64_t size() const
     {
         int64_t s = 1;
@@ -46,6 +47,9 @@ struct Plan {
     bool swapped, a_kc, b_kc, wide;
     int repack = 0;                 // 1/2: caller's first/second operand is re-laid-out into scratch before the product
     int64_t repack_stride[6] = {0, 0, 0, 0, 0, 0};
+    // the copy in the plan's scratch buffer is the re-laid-out tensor (frozen id, address) as of this scratch epoch: not made again
+    int64_t repack_of = 0, repack_epoch = -1;
+    const double* repack_src = nullptr;
 };
 
 struct Comm;
@@ -164,7 +168,9 @@ void k_div(Context& cx, double* out, const double* num, const double* den, int64
 void k_antisym_pair(Context& cx, double* out, const double* in, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
                     int which);   // which=0: 2x - x(swap idx 0,1)   which=1: 2x - x(swap idx 2,3)
 void k_asym_c(Context& cx, double* asym, double* c, const double* t1, const double* t2, int o, int v);
-void k_t2_update(Context& cx, double* t2, const double* r2, const double* v_oovv, const double* D2, const double* pp, int o, int v);
+// t2 = (P(ia/jb)[r2 + r2b + r2c] + pp + v_oovv) / D2 and t1 = (r1 + r1b) / D1 (ccsd.f90:1720-1728); r2b, r2c, r1b may be null
+void k_t2_update(Context& cx, double* t2, const double* r2, const double* r2b, const double* r2c, const double* v_oovv, const double* D2,
+                 const double* pp, int o, int v, double* t1, const double* r1, const double* r1b, const double* D1);
 void k_r2_full(Context& cx, double* out, const double* r2, const double* pp, int o, int v);
 void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v);
 // symmetric / antisymmetric operands of the pp-ladder (pairs x <= y indexed y(y+1)/2 + x, pairs x < y indexed y(y-1)/2 + x)
@@ -184,7 +190,9 @@ void k_lincomb(Context& cx, double* out, const double* xbase, int64_t xstride, c
                int64_t n);      // out = sum_j coef[j] * x_j
 void k_sub(Context& cx, double* out, const double* a, const double* b, int64_t n);
 // DIIS extrapolation coefficients on the device: bmat (nerr x nerr) gets row/column `slot` from dots[0..n), coef[0..n) out
-void k_diis_solve(Context& cx, double* coef, double* bmat, const double* dots, double* flag, int n, int nerr, int slot);
+void k_diis_solve(Context& cx, double* coef, double* bmat, double* flag, int n, int nerr, int slot);   // sums k_diis_push's partials itself
+void k_diis_push(Context& cx, double* ht, double* he, const double* amp, const double* amp_s, const double* hist_e, int64_t stride, int ny,
+                 int slot, int64_t n);
 constexpr int DIIS_FLAG_SLOT = 48;   // cx.scal[48]: set by diis_solve_kernel when the solve fails, read with the energies
 void diis_check_flag(Context& cx, const double* host_scal);   // throws the reference's error (ccsd.f90:666) if it is set
 // pair-symmetric AO->MO: u(i,j,KL) from the packed array; out(k,l,PQ) = in(q,p,tri(k,l)); packed[tri(PQ,RS)] = full(s,r,PQ)

@@ -601,8 +601,7 @@ int afesp_ccsd_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* energ
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         ccsd_refresh_sharding(ctx->cx, ctx->cc);
         replay(ctx, ctx->graph_cc, ccsd_uses_lanes(ctx->cc), [&] {
-            ccsd_diis_save(ctx->cx, ctx->cc);
-            ccsd_intermediates(ctx->cx, ctx->cc);
+            ccsd_intermediates(ctx->cx, ctx->cc, true);
             ccsd_amplitudes(ctx->cx, ctx->cc);
             ccsd_energy_launch(ctx->cx, ctx->cc);
         });
@@ -641,8 +640,7 @@ int afesp_ccsd_solve(afesp_ctx* ctx, int maxiter, double e_tol, double t_tol, do
         ccsd_refresh_sharding(cx, s);
         for (int it = 1; it <= maxiter; ++it) {
             replay(ctx, ctx->graph_cc, ccsd_uses_lanes(s), [&] {
-                ccsd_diis_save(cx, s);
-                ccsd_intermediates(cx, s);
+                ccsd_intermediates(cx, s, true);
                 ccsd_amplitudes(cx, s);
                 ccsd_energy_launch(cx, s);
             });
@@ -716,9 +714,21 @@ int afesp_ccsd_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t
                 if (e.t->size() > capacity) throw Error(1, std::string("afesp_ccsd_get_tensor: buffer too small for ") + name);
                 AFESP_HIP(hipSetDevice(ctx->cx.device));
                 const double* src = e.t->d;
+                // the residuals of a laned iteration lie in partial buffers that the update kernel adds up (ccsd_amplitudes)
+                auto add_partial = [&](double* dst, const char* buf) {
+                    auto it = ctx->cx.cache.find(buf);
+                    if (ccsd_uses_lanes(s) && it != ctx->cx.cache.end()) k_axpby(ctx->cx, dst, 1.0, (const double*)it->second.first, 1.0, e.t->size());
+                };
                 if (!strcmp(name, "r2")) {   // the reference's tmp_t2 before P(ia/jb) includes 1/2 pp; it is kept packed here
                     double* full = ctx->cx.scratch("r2_full", e.t->size());
                     k_r2_full(ctx->cx, full, s.r2.d, s.pp, s.o, s.v);
+                    add_partial(full, "r2_lane2");
+                    add_partial(full, "r2_lane3");
+                    src = full;
+                } else if (!strcmp(name, "r1")) {
+                    double* full = ctx->cx.scratch("r1_full", e.t->size());
+                    k_copy(ctx->cx, full, s.r1.d, e.t->size());
+                    add_partial(full, "r1_lane5");
                     src = full;
                 }
                 AFESP_HIP(hipMemcpyAsync(out, src, sizeof(double) * e.t->size(), hipMemcpyDeviceToHost, ctx->cx.stream));

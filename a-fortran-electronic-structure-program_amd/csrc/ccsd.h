@@ -62,7 +62,7 @@ void ccsd_need_vvvv(Context& cx, CCState& s);          // forms <ef|ab> (v^4) if
 void ccsd_refresh_sharding(Context& cx, CCState& s);   // call before an iteration: picks up the context's communicator
 bool ccsd_uses_lanes(const CCState& s);   // small systems: the iteration's chains run on parallel lanes (ccsd.hip)
 void ccsd_diis_save(Context& cx, CCState& s);
-void ccsd_intermediates(Context& cx, CCState& s);
+void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis = false);   // save_for_diis: ccsd_diis_save rides along
 void ccsd_amplitudes(Context& cx, CCState& s);
 void ccsd_pp_ladder(Context& cx, CCState& s);
 void ccsd_ooov_pair_form(Context& cx, CCState& s);

@@ -43,6 +43,9 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     k_antisym_pair(cx, s.w_oovv.d, s.v_oovv.d, O, O, V, V, 1);   // 2<ij|ab> - <ij|ba>   (ccsd.f90:1089)
     k_antisym_pair(cx, s.w_vvov.d, s.v_vvov.d, V, V, O, V, 0);   // 2<ab|ic> - <ba|ic>   (ccsd.f90:1101)
     k_antisym_pair(cx, s.w_oovo.d, s.v_oovo.d, O, O, V, O, 0);   // 2<ij|ak> - <ji|ak>   (ccsd.f90:1121)
+    // nothing writes these again while the state lives: contract() keeps the re-laid-out copies it makes of them
+    const int64_t fid = ++cx.amp_clock;
+    for (Tensor* t : {&s.v_oovv, &s.v_ovov, &s.v_vvov, &s.v_oovo, &s.v_oooo, &s.w_oovv, &s.w_vvov, &s.w_oovo}) t->frozen = fid;
     s.D1 = cx.tensor({O, V}); s.D2 = cx.tensor({O, O, V, V});
     k_denominators(cx, s.D1.d, s.D2.d, s.e, o, v);
     s.nvec = ov + o2v2;
@@ -200,7 +203,7 @@ static Tensor slice_axis(Tensor t, int axis, int64_t lo, int64_t hi)
     return t;
 }
 
-void ccsd_intermediates(Context& cx, CCState& s)
+void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
 {
     auto C = [&](double al, const Tensor& A, const char* la, const Tensor& B, const char* lb, double be, const Tensor& Cc,
                  const char* lc) { contract(cx, al, A, la, B, lb, be, Cc, lc); };
@@ -255,6 +258,9 @@ void ccsd_intermediates(Context& cx, CCState& s)
     }
     C(-1.0, s.v_oovo, "imbj", s.t1, "ma", 1.0, s.I_voov, "bjia");
     lane(4);
+    // (the copy of the amplitudes the DIIS error vector is taken against, ccsd.f90:342-343: nothing writes them before the update
+    // at the end of ccsd_amplitudes, so it rides on a lane instead of standing in front of the iteration)
+    if (save_for_diis) diis_save(cx, s);
     // I_vovv_p(c,i,a,b) = <ab|ci> - t(m,a) <mi|cb> - t(m,b) <ma|ic>          ccsd.f90:1255-1272, :1296-1299
     // is only ever contracted with t(i,e) over its first index (:1700), so the o v^3 tensor is not formed: the first term
     // is contracted from v_vvov directly (ccsd_amplitudes) and the two t1-dressed terms go through o^3 v tensors,
@@ -450,12 +456,7 @@ void ccsd_amplitudes(Context& cx, CCState& s)
     if (!sh) C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
     C(1.0, s.t1, "ie", s.v_vvov, "baje", 1.0, r2c, "ijab");                // :1700, bare part: t(i,e) <ab|ej>
     C(-1.0, s.t1, "ma", s.z_ooov, "ijmb", 1.0, r2c, "ijab");               // :1705-1715 and the t1-dressed parts of :1700 (ccsd_intermediates)
-    if (par) {
-        cx.join();
-        k_axpby(cx, s.r1.d, 1.0, r1b.d, 1.0, s.r1.size());
-        k_axpby(cx, s.r2.d, 1.0, r2b.d, 1.0, s.r2.size());
-        k_axpby(cx, s.r2.d, 1.0, r2c.d, 1.0, s.r2.size());
-    }
+    if (par) cx.join();   // (the partial residuals r1b, r2b, r2c are added up by the update kernel below)
     if (sh) {
         // the one exchange of a split iteration: sum over ranks of [PP | r2_sh] (64 + 128 MB at o = 20, v = 200), in place
         const int64_t np = (int64_t)s.v * (s.v + 1) / 2;
@@ -463,8 +464,8 @@ void ccsd_amplitudes(Context& cx, CCState& s)
         k_axpby(cx, s.r2.d, 1.0, s.r2_sh, 1.0, s.r2.size());
     }
     // P(ia/jb), + v_oovv, Jacobi divide                                  ccsd.f90:1720-1728
-    k_div(cx, s.t1.d, s.r1.d, s.D1.d, s.t1.size());
-    k_t2_update(cx, s.t2.d, s.r2.d, s.v_oovv.d, s.D2.d, s.pp, s.o, s.v);
+    k_t2_update(cx, s.t2.d, s.r2.d, par ? r2b.d : nullptr, par ? r2c.d : nullptr, s.v_oovv.d, s.D2.d, s.pp, s.o, s.v, s.t1.d, s.r1.d,
+                par ? r1b.d : nullptr, s.D1.d);
 }
 
 // The intermediate of ccsd.f90:1255-1272 as a tensor (tests / afesp_ccsd_get_tensor); the iteration never forms it.
@@ -573,12 +574,11 @@ void diis_update(Context& cx, DiisRing& s)
     const int slot = s.it - 1, n = s.nact;
     double* ht = s.hist_t + (int64_t)slot * s.nvec;
     double* he = s.hist_e + (int64_t)slot * s.nvec;
-    k_copy(cx, ht, s.amp, s.nvec);
-    k_sub(cx, he, s.amp, s.amp_s, s.nvec);
-    // ccsd.f90:653-673: only row/column `slot` of B changes; the solve and the extrapolation follow on the device with no
-    // host round trip (k_diis_solve), so the whole update is six launches queued behind the amplitude update
-    k_dots(cx, cx.scal, he, s.hist_e, s.nvec, n, s.nvec, false);
-    k_diis_solve(cx, s.coef, s.bmat, cx.scal, cx.scal + DIIS_FLAG_SLOT, n, s.nerr, slot);
+    // ccsd.f90:653-673: only row/column `slot` of B changes; history, error vector and its dot products come out of one pass, the
+    // solve (which sums that pass's partial sums itself) and the extrapolation follow on the device with no host round trip:
+    // three launches queued behind the amplitude update (seven until round 3)
+    k_diis_push(cx, ht, he, s.amp, s.amp_s, s.hist_e, s.nvec, n, slot, s.nvec);
+    k_diis_solve(cx, s.coef, s.bmat, cx.scal + DIIS_FLAG_SLOT, n, s.nerr, slot);
     k_lincomb(cx, s.amp, s.hist_t, s.nvec, s.coef, n, s.nvec);
 }
 

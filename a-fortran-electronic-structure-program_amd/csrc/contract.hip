@@ -617,14 +617,22 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
         it = cx.plans.emplace(key, p).first;
         }
     }
-    const Plan& p = it->second;
+    Plan& p = it->second;
     if (p.repack) {
         const Tensor& src = p.repack == 1 ? A0 : B0;
         Tensor packed = src;
+        packed.frozen = 0;
         for (int i = 0; i < src.rank; ++i) packed.stride[i] = p.repack_stride[i];
         packed.d = cx.scratch("repack:" + std::to_string(cx.cur_lane) + ":" + key, src.size());
         const char* ls = p.repack == 1 ? la0 : lb0;
-        permute_add(cx, 1.0, src, ls, 0.0, packed, ls);
+        // (an immutable operand -- the MO integrals of a solver state -- is re-laid-out once, not once per iteration)
+        const bool have = src.frozen != 0 && p.repack_of == src.frozen && p.repack_src == src.d && p.repack_epoch == cx.scratch_epoch;
+        if (!have) {
+            permute_add(cx, 1.0, src, ls, 0.0, packed, ls);
+            p.repack_of = src.frozen;
+            p.repack_src = src.d;
+            p.repack_epoch = cx.scratch_epoch;
+        }
         cx.in_repack = true;
         try {
             contract(cx, alpha, p.repack == 1 ? packed : A0, la0, p.repack == 2 ? packed : B0, lb0, beta, C, lc, nbatch, bA0, bB0,

@@ -618,6 +618,8 @@ int g_group_m = 0;   // >0 overrides the tile-walk group size (tuning knob, see 
 int g_force_tm = 0, g_force_tn = 0, g_force_split = 0, g_allow_wide = 1;
 // K is sliced when a product has fewer tiles than this (tuning knob AFESP_SPLIT_BELOW)
 static const int g_split_below = getenv("AFESP_SPLIT_BELOW") ? atoi(getenv("AFESP_SPLIT_BELOW")) : 192;
+// ... into slices of at least this many K steps (tuning knob AFESP_SPLIT_MIN_STEPS)
+static const int g_split_min_steps = getenv("AFESP_SPLIT_MIN_STEPS") ? std::max(1, atoi(getenv("AFESP_SPLIT_MIN_STEPS"))) : 4;
 
 // Block tile extent (rows or columns) for a requested code: 1 -> 32, 2 -> 64, 4 -> 128; 8 = 128 with 8 waves.
 static int pick_t(int extent)
@@ -671,10 +673,10 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
         split = force_split;
     } else if (wq_split > 1) {
         split = wq_split;
-    } else if (tiles < g_split_below && ksteps >= 8) {
+    } else if (tiles < g_split_below && ksteps >= 2 * g_split_min_steps) {
         // too few tiles to fill 256 CUs: slice K, at least 4 K steps per slice, aim for ~2 blocks per CU
         split = (int)((512 + tiles - 1) / tiles);
-        if (split > ksteps / 4) split = ksteps / 4;
+        if (split > ksteps / g_split_min_steps) split = ksteps / g_split_min_steps;
     }
     if (split > ksteps) split = ksteps > 0 ? ksteps : 1;
     const int64_t need = (int64_t)split * p.nbatch * p.M * p.N * (int64_t)sizeof(double);

@@ -76,9 +76,11 @@ __global__ void asym_c_kernel(double* asym, double* c, const double* t1, const d
 // t2 = (r2(ijab) + r2(jiba) + v_oovv) / D2   (ccsd.f90:1720-1728).  The particle-particle ladder pp(ijab) =
 // sum_ef c(ij,ef) <ef|ab> satisfies pp(ijab) = pp(jiba), so it is computed for a <= b only and stored packed as
 // PP(i,j,p), p = b(b+1)/2 + a; its contribution to r2(ijab) + r2(jiba) is 2 * 1/2 * pp = PP (ccsd.f90:1669).
-__global__ void t2_update_kernel(double* t2, const double* r2, const double* voovv, const double* D2, const double* pp, int o, int v)
+__global__ void t2_update_kernel(double* t2, const double* r2, const double* r2b, const double* r2c, const double* voovv, const double* D2,
+                                 const double* pp, int o, int v, double* t1, const double* r1, const double* r1b, const double* D1)
 {
-    const int64_t n = (int64_t)o * o * v * v;
+    // (r2b, r2c, r1b: the partial residuals of the laned iteration, null otherwise; t1 = (r1 + r1b) / D1 rides along)
+    const int64_t n = (int64_t)o * o * v * v, n1 = (int64_t)o * v;
     GRID_STRIDE(x, n)
     {
         int i = (int)(x % o);
@@ -89,7 +91,11 @@ __global__ void t2_update_kernel(double* t2, const double* r2, const double* voo
         int64_t y = j + (int64_t)o * (i + (int64_t)o * (b + (int64_t)v * a));
         const int64_t lad = (a <= b) ? i + (int64_t)o * (j + (int64_t)o * ((int64_t)b * (b + 1) / 2 + a))
                                      : j + (int64_t)o * (i + (int64_t)o * ((int64_t)a * (a + 1) / 2 + b));
-        t2[x] = (r2[x] + r2[y] + pp[lad] + voovv[x]) / D2[x];
+        double rx = r2[x], ry = r2[y];
+        if (r2b) { rx += r2b[x]; ry += r2b[y]; }
+        if (r2c) { rx += r2c[x]; ry += r2c[y]; }
+        t2[x] = (rx + ry + pp[lad] + voovv[x]) / D2[x];
+        if (x < n1) t1[x] = (r1[x] + (r1b ? r1b[x] : 0.0)) / D1[x];
     }
 }
 
@@ -178,6 +184,29 @@ __global__ __launch_bounds__(TB) void dots_kernel(double* partial, const double*
     GRID_STRIDE(i, n) acc[0] += x[i] * y[i];
     block_sum<1>(acc, sm);
     if (threadIdx.x == 0) partial[blockIdx.y * RED_BLOCKS + blockIdx.x] = acc[0];
+}
+// The first half of a DIIS update in one pass (ccsd.f90:633-673): the new amplitudes go into the history (ht), their difference
+// to the previous ones into the error history (he = row `slot` of hist_e), and the block's shares of <he, hist_e_j>, j < ny,
+// into partial[j*RED_BLOCKS + blk] (same partition and order as dots_kernel).
+__global__ __launch_bounds__(TB) void diis_push_kernel(double* partial, double* ht, double* he, const double* amp, const double* amp_s,
+                                                       const double* hist_e, int64_t stride, int ny, int slot, int64_t n)
+{
+    __shared__ double sm[16 * 4];
+    double acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+    GRID_STRIDE(i, n)
+    {
+        const double a = amp[i], e = a - amp_s[i];
+        ht[i] = a;
+        he[i] = e;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < ny) acc[j] += e * (j == slot ? e : hist_e[(int64_t)j * stride + i]);
+    }
+    block_sum<16>(acc, sm);
+    if (threadIdx.x == 0)
+        for (int j = 0; j < ny; ++j) partial[j * RED_BLOCKS + blockIdx.x] = acc[j];
 }
 __global__ void lincomb_kernel(double* out, const double* xbase, int64_t xstride, const double* coef, int nx, int64_t n)
 {
@@ -311,9 +340,10 @@ void k_asym_c(Context& cx, double* asym, double* c, const double* t1, const doub
 {
     LAUNCH(asym_c_kernel, dim3(grid_for((int64_t)o * o * v * v)), asym, c, t1, t2, o, v);
 }
-void k_t2_update(Context& cx, double* t2, const double* r2, const double* v_oovv, const double* D2, const double* pp, int o, int v)
+void k_t2_update(Context& cx, double* t2, const double* r2, const double* r2b, const double* r2c, const double* v_oovv, const double* D2,
+                 const double* pp, int o, int v, double* t1, const double* r1, const double* r1b, const double* D1)
 {
-    LAUNCH(t2_update_kernel, dim3(grid_for((int64_t)o * o * v * v)), t2, r2, v_oovv, D2, pp, o, v);
+    LAUNCH(t2_update_kernel, dim3(grid_for((int64_t)o * o * v * v)), t2, r2, r2b, r2c, v_oovv, D2, pp, o, v, t1, r1, r1b, D1);
 }
 // r2_full(ijab) = r2(ijab) + 1/2 pp(ijab): the residual before P(ia/jb) (tests / get_tensor) -- the reference's tmp_t2 up to terms that are
 // held as their images under (i <-> j, a <-> b) (ccsd.hip, z_ooov): r2_full(ijab) + r2_full(jiba) is what equals the reference's
@@ -456,8 +486,19 @@ void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, in
 // column and multipliers travel by lane broadcasts.  The coefficients stay in HBM for lincomb_kernel.  flag[0] is set to 1
 // when a pivot vanishes (reported by the next energy evaluation).
 constexpr int DIIS_MAXN = 17;
-__global__ __launch_bounds__(64) void diis_solve_kernel(double* coef, double* bmat, const double* dots, double* flag, int n, int nerr, int slot)
+__global__ __launch_bounds__(TB) void diis_solve_kernel(double* coef, double* bmat, const double* partial, double* flag, int n, int nerr, int slot)
 {
+    // the new row of B first: dots[q] = sum_b partial[q*RED_BLOCKS + b], the whole block in final_sum_kernel's order
+    __shared__ double sm[4];
+    __shared__ double dots[DIIS_MAXN];
+    for (int q = 0; q < n; ++q) {
+        double acc[1] = {0.0};
+        for (int b = threadIdx.x; b < RED_BLOCKS; b += blockDim.x) acc[0] += partial[q * RED_BLOCKS + b];
+        block_sum<1>(acc, sm);
+        if (threadIdx.x == 0) dots[q] = acc[0];
+        __syncthreads();
+    }
+    if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x, N = n + 1;   // columns 0..n of A, column N = right-hand side
     double col[DIIS_MAXN];
 #pragma unroll
@@ -517,10 +558,16 @@ __global__ __launch_bounds__(64) void diis_solve_kernel(double* coef, double* bm
     }
     if (lane < n) coef[lane] = xj;
 }
-void k_diis_solve(Context& cx, double* coef, double* bmat, const double* dots, double* flag, int n, int nerr, int slot)
+void k_diis_solve(Context& cx, double* coef, double* bmat, double* flag, int n, int nerr, int slot)
 {
-    hipLaunchKernelGGL(diis_solve_kernel, dim3(1), dim3(64), 0, cx.stream, coef, bmat, dots, flag, n, nerr, slot);
+    hipLaunchKernelGGL(diis_solve_kernel, dim3(1), dim3(TB), 0, cx.stream, coef, bmat, cx.scal + 64, flag, n, nerr, slot);
     AFESP_HIP(hipGetLastError());
+}
+void k_diis_push(Context& cx, double* ht, double* he, const double* amp, const double* amp_s, const double* hist_e, int64_t stride, int ny,
+                 int slot, int64_t n)
+{
+    if (ny > 16) throw Error(3, "k_diis_push: too many vectors");
+    LAUNCH(diis_push_kernel, dim3(RED_BLOCKS), cx.scal + 64, ht, he, amp, amp_s, hist_e, stride, ny, slot, n);
 }
 void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v)
 {
