@@ -488,16 +488,15 @@ void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, in
 constexpr int DIIS_MAXN = 17;
 __global__ __launch_bounds__(TB) void diis_solve_kernel(double* coef, double* bmat, const double* partial, double* flag, int n, int nerr, int slot)
 {
-    // the new row of B first: dots[q] = sum_b partial[q*RED_BLOCKS + b], the whole block in final_sum_kernel's order
-    __shared__ double sm[4];
+    // the new row of B first: dots[q] = sum_b partial[q*RED_BLOCKS + b], one wave per q (fixed order), all q side by side
     __shared__ double dots[DIIS_MAXN];
-    for (int q = 0; q < n; ++q) {
-        double acc[1] = {0.0};
-        for (int b = threadIdx.x; b < RED_BLOCKS; b += blockDim.x) acc[0] += partial[q * RED_BLOCKS + b];
-        block_sum<1>(acc, sm);
-        if (threadIdx.x == 0) dots[q] = acc[0];
-        __syncthreads();
+    for (int q = threadIdx.x >> 6; q < n; q += TB / 64) {
+        double acc = 0.0;
+        for (int b = threadIdx.x & 63; b < RED_BLOCKS; b += 64) acc += partial[q * RED_BLOCKS + b];
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) dots[q] = acc;
     }
+    __syncthreads();
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x, N = n + 1;   // columns 0..n of A, column N = right-hand side
     double col[DIIS_MAXN];
