@@ -348,12 +348,15 @@ void ccsd_pp_ladder(Context& cx, CCState& s)
     gp.M = (int)(p1 - p0); gp.N = (int)ns; gp.K = (int)ks;
     const char* fs = getenv("AFESP_PP_SPLIT");   // tuning knob: K slices of the two pair products (0 = the launcher's own choice)
     const int force_split = fs ? atoi(fs) : 0;
-    if (p1 > p0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, force_split, 0, 0));
+    // tuning knob AFESP_PP_TILES="tm,tn,split,tm,tn,split": tile codes and K slices of the symmetric / the antisymmetric product
+    int pt[6] = {0, 0, force_split, 0, 0, force_split};
+    if (const char* e = getenv("AFESP_PP_TILES")) sscanf(e, "%d,%d,%d,%d,%d,%d", &pt[0], &pt[1], &pt[2], &pt[3], &pt[4], &pt[5]);
+    if (p1 > p0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, pt[2], pt[0], pt[1]));
     if (s.pp_pa) {
         gp.A = s.pp_va; gp.B = s.pp_ca; gp.C = s.pp_pa;
         gp.offAm = u + nm + q0; gp.offBk = u + 2 * nm + ks; gp.offCm = u + 3 * nm + 2 * ks + q0;
         gp.M = (int)(q1 - q0); gp.N = (int)na; gp.K = (int)ka;
-        if (q1 > q0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, force_split, 0, 0));
+        if (q1 > q0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, pt[5], pt[3], pt[4]));
     }
     (void)npa;
     k_pp_expand(cx, s.pp, s.pp_ps, s.pp_pa, s.o, s.v, ns, na, p0, p1);

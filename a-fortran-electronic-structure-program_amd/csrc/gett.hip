@@ -650,18 +650,28 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     if (!force_tm && !force_tn && tm == 4 && tn == 4 && wide && p.M >= 2048) {
         // Wave quantisation: 256 CUs take one workgroup each, so a grid of 316 tiles runs as 256 + 60.  Score the two tile
         // shapes with 1..4 K slices by (relative tile speed) x (fill of the last round) and keep the best.
-        auto score = [&](int bm, int bn, int s, double rate) {
+        auto score = [&](int bm, int bn, int s, double rate, int slots) {
             const int64_t work = (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nbatch * s;
-            const int64_t rounds = (work + 255) / 256;
+            const int64_t rounds = (work + slots - 1) / slots;
             const double waste = (double)((p.M + bm - 1) / bm * bm) * ((p.N + bn - 1) / bn * bn) / ((double)p.M * p.N);
-            return rate * (double)work / (double)(rounds * 256) / waste * (s > 1 ? 0.96 : 1.0);
+            return rate * (double)work / (double)(rounds * slots) / waste * (s > 1 ? 0.96 : 1.0);
         };
         double best = 0.0;
         for (int big = 0; big < 2; ++big)
             for (int s = 1; s <= 4; ++s) {
                 if (s > 1 && (force_split > 0 || ksteps / s < 32)) continue;
-                const double sc = score(big ? 256 : 128, 128, s, big ? 1.0 : 0.89);
+                const double sc = score(big ? 256 : 128, 128, s, big ? 1.0 : 0.89, 256);
                 if (sc > best * 1.02) { best = sc; tm = big ? 16 : 4; tn = big ? 8 : 4; wq_split = s; }
+            }
+        // A few columns past a multiple of 128 leave most of the last column tile empty (the antisymmetric pair product of the
+        // pp-ladder at o = 20: 190 columns): the 4-wave 128 x 64 tile (two workgroups per CU) then wins although it runs at 0.82
+        // of the big tile's rate (3.41 -> 3.11 ms there).  A short product is mostly tile prologue and epilogue, where the small tile
+        // loses nothing (I_oooo(ijmn) c(mnab) -> r2, K = 400, 400 columns: 321 -> 274 us); in between it is not offered.
+        if (ksteps >= 256 || ksteps < 64)
+            for (int s = 1; s <= 4; ++s) {
+                if (s > 1 && (force_split > 0 || ksteps / s < 32)) continue;
+                const double sc = score(128, 64, s, ksteps >= 256 ? 0.82 : 0.97, 512);
+                if (sc > best * 1.02) { best = sc; tm = 4; tn = 2; wq_split = s; }
             }
     }
     const int BM = tm == 16 ? 256 : tm == 8 ? 128 : 32 * tm, BN = tn == 16 ? 256 : tn == 8 ? 128 : 32 * tn;
@@ -677,6 +687,11 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
         // too few tiles to fill 256 CUs: slice K, at least 4 K steps per slice, aim for ~2 blocks per CU
         split = (int)((512 + tiles - 1) / tiles);
         if (split > ksteps / g_split_min_steps) split = ksteps / g_split_min_steps;
+    } else if (tiles < 1024 && ksteps >= 64 && (int64_t)p.M * p.N * 16 <= ((int64_t)p.M + p.N) * p.K) {
+        // a long product that mostly streams an operand (its output is small change beside it): a workgroup per CU has too few
+        // loads in flight for the HBM rate -- w(e,b,m,a) t(m,e) -> I_vv(b,a) at o = 20, v = 200: 313 tiles 0.42 ms, in four K slices 0.27
+        split = (int)((1024 + tiles - 1) / tiles);
+        if (split > ksteps / 8) split = ksteps / 8;
     }
     if (split > ksteps) split = ksteps > 0 ? ksteps : 1;
     const int64_t need = (int64_t)split * p.nbatch * p.M * p.N * (int64_t)sizeof(double);
