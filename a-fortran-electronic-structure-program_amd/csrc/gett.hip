@@ -238,23 +238,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
                 int n = nl + 16 * j;
                 cn[j] = offCn[n < Ncur ? n : Ncur - 1];
             }
+            // (beta != 0: the 4 TN old values of a 16-row block are requested together, from clamped -- always valid -- addresses,
+            // before any of them is needed: element by element, each load stood between a wait and a store that might alias it,
+            // 16 TM dependent round trips to memory per tile -- most of the time of a short accumulating product)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                int64_t cm[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cm[r] = p.offCm[min(ml + 16 * i + 4 * r, p.M - 1)];
+                double old[4][TN];
+                if (p.beta != 0.0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) old[r][j] = Cb[cm[r] + cn[j]];
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    int m = ml + 16 * i + 4 * r;
-                    if (m >= p.M) continue;
-                    int64_t cm = p.offCm[m];
+                    if (ml + 16 * i + 4 * r >= p.M) continue;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        int n = nl + 16 * j;
-                        if (n >= Ncur) continue;
-                        double* dst = Cb + cm + cn[j];
+                        if (nl + 16 * j >= Ncur) continue;
                         double val = p.alpha * acc[i][j][r];
-                        if (p.beta != 0.0) val += p.beta * *dst;
-                        *dst = val;
+                        if (p.beta != 0.0) val += p.beta * old[r][j];
+                        Cb[cm[r] + cn[j]] = val;
                     }
                 }
+            }
         } else {
             double* slab = a.ws + ((int64_t)z * a.ksplit + split) * (int64_t)p.M * p.N;
 #pragma unroll
