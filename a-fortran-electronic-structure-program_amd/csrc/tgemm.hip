@@ -275,6 +275,30 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
                     for (int jj = 0; jj < 2; ++jj)   // (scalar base + 32-bit offset instead of 64-bit addresses: same time, measured)
                         *reinterpret_cast<v2d*>(Cg + cm + cn[jj]) = (v2d){acc[i][2 * jj][r], acc[i][2 * jj + 1][r]};
                 }
+        } else if (p.c_pairs) {
+            // a tile on the edge of C: still 16 bytes per lane where both columns of the pair exist -- single doubles leave every
+            // 32-byte sector half written until the other parity's instruction comes, and the L2 fetches such sectors from HBM first
+            // (AO->MO at n = 220, whose second row tile is partial: 55 GB fetched per transform, 44 GB with the stores off)
+            int nl[2];
+            int64_t cn[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                nl[jj] = wn * 64 + 32 * jj + 2 * fm;
+                cn[jj] = sc[128 + nl[jj]];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ml = wm * 64 + 16 * i + 4 * r + ff;
+                    if (ml >= mrem) continue;
+                    const int64_t cm = sc[ml];
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        if (nl[jj] + 1 < nrem) *reinterpret_cast<v2d*>(Cg + cm + cn[jj]) = (v2d){acc[i][2 * jj][r], acc[i][2 * jj + 1][r]};
+                        else if (nl[jj] < nrem) Cg[cm + cn[jj]] = acc[i][2 * jj][r];
+                    }
+                }
         } else {
             int64_t cn[4];
             int nl[4];
