@@ -459,6 +459,7 @@ static int fused_block_size(int o, int v, bool cr, int64_t budget_bytes)
     // launches; from about 900 columns on neither matters any more (config 5: s = 5, 7 -> 506.8, 506.0 ms; s = 4 -> 549), while
     // the pool grows with s^3 -- and every byte allocated for the first time costs on this runtime.  So: the
     // smallest size with >= 900 columns per group, or one of the next two if it fills its column tiles more than 2 % better.
+    if (const char* e = getenv("AFESP_T_BLOCK")) return std::max(1, std::min(smax, atoi(e)));   // tuning knob
     const int smin = std::min(smax, std::max(1, (900 + v - 1) / v));
     auto fill = [&](int sz) { return (double)((int64_t)v * sz) / (double)((((int64_t)v * sz + 127) / 128) * 128); };
     int best = smin;
