@@ -9,5 +9,5 @@ mkdir -p "$OUT"
 make -C "$CS" -j8 > /dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result ${EXTRA:-} -c "$CS/triples.hip" -o "$OUT/triples_$1.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libafesp_$1.so" "$OUT/triples_$1.o" \
-    "$CS"/{gett,gett_grouped,contract,kernels,ccsd,ccsd_so,comm,capi}.o -ldl -lpthread
+    "$CS"/{gett,gett_grouped,tgemm,contract,kernels,ccsd,ccsd_so,comm,capi}.o -ldl -lpthread
 echo "built $OUT/libafesp_$1.so"

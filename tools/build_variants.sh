@@ -13,6 +13,6 @@ for v in "$@"; do
     /opt/rocm/bin/hipcc $F -c "$CS/gett.hip" -o "$OUT/gett_v$v.o" &&
     /opt/rocm/bin/hipcc $F ${GROUPED_EXTRA:-$GROUPED_FLAGS} -c "$CS/gett_grouped.hip" -o "$OUT/gett_grouped_v$v.o" &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libafesp_v$v.so" "$OUT/gett_v$v.o" "$OUT/gett_grouped_v$v.o" \
-      "$CS"/{contract,kernels,ccsd,ccsd_so,triples,comm,capi}.o -ldl -lpthread && echo "built v$v" ) &
+      "$CS"/{tgemm,contract,kernels,ccsd,ccsd_so,triples,comm,capi}.o -ldl -lpthread && echo "built v$v" ) &
 done
 wait
