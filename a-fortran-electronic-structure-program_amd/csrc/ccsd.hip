@@ -241,22 +241,27 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     C(1.0, s.t1, "le", s.v_oovo, "jkei", 1.0, s.I_oooo, "klij");
     lane(2);
     // I_ovov(j,b,i,a)                                                    ccsd.f90:1158-1191
-    k_copy(cx, s.I_ovov.d, s.v_ovov.d, s.I_ovov.size());
-    if (v1 > v0) C(-0.5, s.v_oovv, "mibe", sl(s.c, 2), "mjae", 1.0, sl(s.I_ovov, 3), "jbia");   // (o^3 v^3: sliced over a)
-    C(-1.0, s.v_oovo, "mibj", s.t1, "ma", 1.0, s.I_ovov, "jbia");
-    C(1.0, s.t1, "je", s.v_vvov, "ebia", 1.0, s.I_ovov, "jbia");
+    // (a split iteration only ever reads this rank's slice of I_ovov / I_voov: every term is built for the slice only -- the last
+    // index is the slowest one, a slice is one contiguous range)
+    const int64_t a_len = s.I_ovov.stride[3], a_off = v0 * a_len, a_cnt = (v1 - v0) * a_len;
+    if (v1 > v0) {
+        k_copy(cx, s.I_ovov.d + a_off, s.v_ovov.d + a_off, a_cnt);
+        C(-0.5, s.v_oovv, "mibe", sl(s.c, 2), "mjae", 1.0, sl(s.I_ovov, 3), "jbia");   // (o^3 v^3)
+        C(-1.0, s.v_oovo, "mibj", sl(s.t1, 1), "ma", 1.0, sl(s.I_ovov, 3), "jbia");
+        C(1.0, s.t1, "je", sl(s.v_vvov, 3), "ebia", 1.0, sl(s.I_ovov, 3), "jbia");
+    }
     lane(3);
     // x_voov(b,j,i,a) = <be|ia> t(j,e)                                   ccsd.f90:1275-1290
     C(1.0, s.v_vvov, "beia", s.t1, "je", 0.0, s.x_voov, "bjia");
     const int x_voov_ready = par ? cx.mark() : 0;
     // I_voov(b,j,i,a)                                                    ccsd.f90:1193-1252
-    permute_add(cx, 1.0, s.v_oovv, "jiab", 0.0, s.I_voov, "bjia");
-    k_axpby(cx, s.I_voov.d, 1.0, s.x_voov.d, 1.0, s.I_voov.size());
-    if (v1 > v0) {                                                                             // (o^3 v^3 each: sliced over a)
-        C(0.5, s.w_oovv, "imbe", sl(s.t2, 3), "mjea", 1.0, sl(s.I_voov, 3), "bjia");
+    if (v1 > v0) {
+        permute_add(cx, 1.0, sl(s.v_oovv, 2), "jiab", 0.0, sl(s.I_voov, 3), "bjia");
+        k_axpby(cx, s.I_voov.d + a_off, 1.0, s.x_voov.d + a_off, 1.0, a_cnt);
+        C(0.5, s.w_oovv, "imbe", sl(s.t2, 3), "mjea", 1.0, sl(s.I_voov, 3), "bjia");           // (o^3 v^3 each)
         C(-0.5, s.v_oovv, "imbe", sl(s.c, 2), "mjae", 1.0, sl(s.I_voov, 3), "bjia");
+        C(-1.0, s.v_oovo, "imbj", sl(s.t1, 1), "ma", 1.0, sl(s.I_voov, 3), "bjia");
     }
-    C(-1.0, s.v_oovo, "imbj", s.t1, "ma", 1.0, s.I_voov, "bjia");
     lane(4);
     // (the copy of the amplitudes the DIIS error vector is taken against, ccsd.f90:342-343: nothing writes them before the update
     // at the end of ccsd_amplitudes, so it rides on a lane instead of standing in front of the iteration)
