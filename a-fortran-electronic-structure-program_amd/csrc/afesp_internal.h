@@ -53,6 +53,7 @@ struct Plan {
 };
 
 struct Comm;
+struct Recorder;   // fused.h
 
 // Device arena owned by the context.  On this runtime a hipMalloc of a GB or more is normally 0.3 ms but now and then takes
 // 0.1-5 s, and a calculation frees and re-allocates tens of GB between its stages (AO->MO temporaries,
@@ -75,6 +76,7 @@ struct Context {
     Comm* comm = nullptr;                 // rank-to-rank sums (comm.h); null = single rank
     int cc_split_mode = -1;               // afesp_ccsd_set_split: 1 split the CCSD iteration over the ranks, 0 replicas, -1 environment (default off)
     int test_throw = 0;                   // test hook (afesp_test_inject): the next laned amplitude update throws
+    Recorder* rec = nullptr;              // set while a call sequence is being recorded for the launch-fused path (fused.h): nothing is launched
     hipStream_t stream = nullptr;
     Arena arena;                          // every device allocation of the context goes through it
     std::vector<void*> owned;             // everything freed at destroy
@@ -109,6 +111,11 @@ struct Context {
     int marks_used = 0;
     double* scal = nullptr;               // small device scratch for reductions (64 doubles)
     double* scal_host = nullptr;          // pinned mirror
+    // results a kernel writes straight into host memory (coherent, mapped): [energy, rms, DIIS failure, sequence number] -- the
+    // sequence number is written last; res_seq is the number the next such launch will write (k_cc_tail)
+    double* res_host = nullptr;
+    double* res_dev = nullptr;
+    int64_t res_seq = 0;
     std::map<std::string, Plan> plans;
     size_t plan_bytes = 0;                // device bytes of their offset tables
     // plan tables come out of slabs (a small system builds ~45 plans in its first iteration: one device allocation each was
@@ -193,6 +200,22 @@ void k_sub(Context& cx, double* out, const double* a, const double* b, int64_t n
 void k_diis_solve(Context& cx, double* coef, double* bmat, double* flag, int n, int nerr, int slot);   // sums k_diis_push's partials itself
 void k_diis_push(Context& cx, double* ht, double* he, const double* amp, const double* amp_s, const double* hist_e, int64_t stride, int ny,
                  int slot, int64_t n);
+// The tail of a small system's iteration in two launches (kernels.hip: cc_tail_kernel, cc_finalize_kernel): amplitude update, energy /
+// rms sums and -- when ny > 0 -- the DIIS history push and solve for slot `slot` with ny active vectors; energy and rms land in
+// cx.scal[0..1] and, with the DIIS failure flag and `seq`, in cx.res_host
+struct CCTail {
+    double *t2, *t1;
+    const double *r2, *r1, *voovv, *D2, *D1, *pp;
+    double* t2_old;
+    int o, v;
+    double *ht, *he;
+    const double *amp_s, *hist_e;
+    int64_t stride;
+    int ny, slot, nerr;
+    double *coef, *bmat;
+    int64_t seq;
+};
+void k_cc_tail(Context& cx, const CCTail& a);
 constexpr int DIIS_FLAG_SLOT = 48;   // cx.scal[48]: set by diis_solve_kernel when the solve fails, read with the energies
 void diis_check_flag(Context& cx, const double* host_scal);   // throws the reference's error (ccsd.f90:666) if it is set
 // pair-symmetric AO->MO: u(i,j,KL) from the packed array; out(k,l,PQ) = in(q,p,tri(k,l)); packed[tri(PQ,RS)] = full(s,r,PQ)
@@ -217,6 +240,7 @@ void preload_gett();
 void preload_contract();
 void preload_kernels();
 void preload_ccsd_so();
+void preload_fused();
 void preload_triples();   // copies cx.scal[0..n) to pinned host memory and synchronises
 
 }  // namespace afesp

@@ -11,6 +11,7 @@
 #include "ccsd_so.h"
 #include "tgemm.h"
 #include "comm.h"
+#include "fused.h"
 
 using namespace afesp;
 
@@ -39,6 +40,16 @@ struct afesp_ctx {
         }
     } graph_cc;
     int64_t eri_ao_n = 0;
+    // the launch-fused path of a small system (fused.h): the recorded and levelled call sequences of the spin-free solver --
+    // intermediates alone, amplitudes alone (the term-by-term entry points) and the whole iteration
+    FusedSlot fused_int, fused_amp, fused_iter;
+    void cc_programs_reset()
+    {
+        graph_cc.reset();
+        fused_slot_reset(cx, fused_int);
+        fused_slot_reset(cx, fused_amp);
+        fused_slot_reset(cx, fused_iter);
+    }
     int64_t half_n = 0, half_epoch = -1;   // scratch "ao2mo_a" holds the half-unpacked AO integrals of this basis size / epoch
 };
 
@@ -176,6 +187,26 @@ static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body 
     body();
 }
 
+// One iteration up to the energy kernels (no host synchronisation): the launch-fused program of a small system (fused.h; recorded
+// from the very calls below on first use), the call-by-call sequence otherwise.
+static bool ccsd_iteration_body(afesp_ctx* ctx)   // true: the launch-fused program ran (read with ccsd_tail_read)
+{
+    if (ccsd_uses_lanes(ctx->cc) &&
+        fused_exec(ctx->cx, ctx->fused_iter, [&] {
+            ccsd_intermediates(ctx->cx, ctx->cc, true);
+            ccsd_amplitudes(ctx->cx, ctx->cc, true);
+            ccsd_tail_launch(ctx->cx, ctx->cc);
+        }))
+        return true;
+    ctx->cc.tail_pending = false;
+    replay(ctx, ctx->graph_cc, ccsd_uses_lanes(ctx->cc), [&] {
+        ccsd_intermediates(ctx->cx, ctx->cc, true);
+        ccsd_amplitudes(ctx->cx, ctx->cc);
+        ccsd_energy_launch(ctx->cx, ctx->cc);
+    });
+    return false;
+}
+
 extern "C" {
 
 int afesp_version(void) { return 1; }
@@ -193,8 +224,11 @@ int afesp_ctx_create(int device, afesp_ctx** out)
     c->cx.device = device;
     int rc = guarded(c, [&] {
         AFESP_HIP(hipStreamCreate(&c->cx.stream));
-        c->cx.scal = c->cx.alloc(64 + 16 * 512);
+        c->cx.scal = c->cx.alloc(64 + 18 * 512);
         AFESP_HIP(hipHostMalloc((void**)&c->cx.scal_host, sizeof(double) * 64, hipHostMallocDefault));
+        AFESP_HIP(hipHostMalloc((void**)&c->cx.res_host, sizeof(double) * 8, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(c->cx.res_host, 0, sizeof(double) * 8);
+        AFESP_HIP(hipHostGetDevicePointer((void**)&c->cx.res_dev, c->cx.res_host, 0));
         c->cx.ws.bytes = (size_t)256 << 20;   // split-K slabs
         c->cx.ws.ptr = c->cx.alloc((int64_t)(c->cx.ws.bytes / sizeof(double)));
         c->cx.sync();
@@ -209,6 +243,7 @@ int afesp_ctx_create(int device, afesp_ctx** out)
                 preload_kernels();
                 preload_contract();
                 preload_gett();
+                preload_fused();
                 preload_triples();
                 preload_ccsd_so();
             });
@@ -227,7 +262,7 @@ void afesp_ctx_destroy(afesp_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->cx.device);
     if (ctx->cx.startup.joinable()) ctx->cx.startup.join();
-    ctx->graph_cc.reset();
+    ctx->cc_programs_reset();
     comm_destroy(ctx->cx.comm);
     ctx->cx.comm = nullptr;
     triples_plan_free(ctx->cc);
@@ -550,7 +585,7 @@ int afesp_ccsd_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, const double* e
         } else if (!src || ctx->eri_mo_n != n) {
             throw Error(1, "afesp_ccsd_init: no MO integrals resident for this basis size (call afesp_ao2mo_mp2 first)");
         }
-        ctx->graph_cc.reset();
+        ctx->cc_programs_reset();
         cx.drop_scratch("ao2mo_");   // the AO->MO temporaries
         ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, src, canon_levels, diis_n_errmat);
         if (tmp) {
@@ -578,7 +613,9 @@ int afesp_ccsd_update_intermediates(afesp_ctx* ctx)
     return guarded(ctx, [&] {
         if (!ctx->cc.ready) throw Error(1, "call afesp_ccsd_init first");
         AFESP_HIP(hipSetDevice(ctx->cx.device));
-        ccsd_intermediates(ctx->cx, ctx->cc);
+        ccsd_refresh_sharding(ctx->cx, ctx->cc);
+        if (!(ccsd_uses_lanes(ctx->cc) && fused_exec(ctx->cx, ctx->fused_int, [&] { ccsd_intermediates(ctx->cx, ctx->cc); })))
+            ccsd_intermediates(ctx->cx, ctx->cc);
         ctx->cx.sync();
     });
 }
@@ -588,7 +625,10 @@ int afesp_ccsd_update_amplitudes(afesp_ctx* ctx)
         ctx->cc.amp_epoch = ++ctx->cx.amp_clock;   // (the amplitudes may change: derived copies go stale)
         if (!ctx->cc.ready) throw Error(1, "call afesp_ccsd_init first");
         AFESP_HIP(hipSetDevice(ctx->cx.device));
-        ccsd_amplitudes(ctx->cx, ctx->cc);
+        ccsd_refresh_sharding(ctx->cx, ctx->cc);
+        ctx->cc.tail_pending = false;
+        if (!(ccsd_uses_lanes(ctx->cc) && fused_exec(ctx->cx, ctx->fused_amp, [&] { ccsd_amplitudes(ctx->cx, ctx->cc); })))
+            ccsd_amplitudes(ctx->cx, ctx->cc);
         ctx->cx.sync();
     });
 }
@@ -600,12 +640,8 @@ int afesp_ccsd_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* energ
         if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_iterate: call afesp_ccsd_init first");
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         ccsd_refresh_sharding(ctx->cx, ctx->cc);
-        replay(ctx, ctx->graph_cc, ccsd_uses_lanes(ctx->cc), [&] {
-            ccsd_intermediates(ctx->cx, ctx->cc, true);
-            ccsd_amplitudes(ctx->cx, ctx->cc);
-            ccsd_energy_launch(ctx->cx, ctx->cc);
-        });
-        int conv = ccsd_energy_read(ctx->cx, ctx->cc, e_tol, t_tol);
+        const bool fused = ccsd_iteration_body(ctx);
+        int conv = fused ? ccsd_tail_read(ctx->cx, ctx->cc, e_tol, t_tol) : ccsd_energy_read(ctx->cx, ctx->cc, e_tol, t_tol);
         if (energy) *energy = ctx->cc.energy;
         if (rms_sq) *rms_sq = ctx->cc.rms;
         if (converged) *converged = conv;
@@ -639,12 +675,8 @@ int afesp_ccsd_solve(afesp_ctx* ctx, int maxiter, double e_tol, double t_tol, do
         int result = -1;
         ccsd_refresh_sharding(cx, s);
         for (int it = 1; it <= maxiter; ++it) {
-            replay(ctx, ctx->graph_cc, ccsd_uses_lanes(s), [&] {
-                ccsd_intermediates(cx, s, true);
-                ccsd_amplitudes(cx, s);
-                ccsd_energy_launch(cx, s);
-            });
-            int conv = ccsd_energy_read(cx, s, e_tol, t_tol);
+            const bool fused = ccsd_iteration_body(ctx);
+            int conv = fused ? ccsd_tail_read(cx, s, e_tol, t_tol) : ccsd_energy_read(cx, s, e_tol, t_tol);
             if (iter_energy) iter_energy[it] = s.energy;
             if (iter_rms_sq) iter_rms_sq[it] = s.rms;
             if (conv) {
@@ -1158,7 +1190,7 @@ int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double sca
         double* packed = cx.alloc(ne);
         hipLaunchKernelGGL(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, packed, ne, scale, seed);
         AFESP_HIP(hipGetLastError());
-        ctx->graph_cc.reset();
+        ctx->cc_programs_reset();
         ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, packed, e.data(), diis_n_errmat);
         if (ctx->cc.v_vvvv.d) { cx.release(packed); ctx->cc.eri_src = nullptr; }
         else ctx->cc.eri_own = packed;   // kept for ccsd_need_vvvv
@@ -1343,7 +1375,7 @@ int afesp_comm_init(afesp_ctx* ctx, int rank, int world, int transport, const ch
         AFESP_HIP(hipSetDevice(cx.device));
         if (cx.comm) throw Error(1, "afesp_comm_init: this context already has a communicator");
         cx.comm = comm_create(cx, rank, world, transport, bootstrap_path, unique_id);
-        ctx->graph_cc.reset();   // a captured iteration does not contain the rank split
+        ctx->cc_programs_reset();   // a captured iteration does not contain the rank split
     });
 }
 
@@ -1354,7 +1386,7 @@ int afesp_comm_destroy(afesp_ctx* ctx)
         ctx->cx.sync();
         comm_destroy(ctx->cx.comm);
         ctx->cx.comm = nullptr;
-        ctx->graph_cc.reset();
+        ctx->cc_programs_reset();
     });
 }
 

@@ -14,6 +14,10 @@ struct DiisRing {
     double *hist_t = nullptr, *hist_e = nullptr;   // nerr * nvec each
     double *coef = nullptr;     // device coefficients
     double *bmat = nullptr;     // error overlap matrix on the device (nerr x nerr, full)
+    // launch-fused tail (ccsd_tail_launch): the history push and the solve of the NEXT update have already run, for slot / count
+    // tail_slot / tail_n; diis_update then only advances the counters and extrapolates.  tail_fail: that solve met a vanishing pivot
+    bool tail_pending = false, tail_fail = false;
+    int tail_slot = 0, tail_n = 0;
 };
 void diis_alloc(Context& cx, DiisRing& r, int diis_nerr);   // r.nvec and r.amp set by the caller (init_diis_cc_t, :577-615)
 void diis_save(Context& cx, DiisRing& r);                   // ccsd.f90:342-343
@@ -63,7 +67,11 @@ void ccsd_refresh_sharding(Context& cx, CCState& s);   // call before an iterati
 bool ccsd_uses_lanes(const CCState& s);   // small systems: the iteration's chains run on parallel lanes (ccsd.hip)
 void ccsd_diis_save(Context& cx, CCState& s);
 void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis = false);   // save_for_diis: ccsd_diis_save rides along
-void ccsd_amplitudes(Context& cx, CCState& s);
+void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update = false);   // defer_update: everything but the final division (ccsd_tail_launch does it)
+// amplitude update + energy / rms sums + DIIS push and solve in two launches, results into pinned host memory (small systems);
+// ccsd_tail_read waits for them (polling, no stream synchronisation) and applies the convergence rule
+void ccsd_tail_launch(Context& cx, CCState& s);
+int ccsd_tail_read(Context& cx, CCState& s, double e_tol, double t_tol);
 void ccsd_pp_ladder(Context& cx, CCState& s);
 void ccsd_ooov_pair_form(Context& cx, CCState& s);
 void ccsd_build_I_vovv_p(Context& cx, CCState& s, const Tensor& out);   // out(c,i,a,b), dense v x o x v x v

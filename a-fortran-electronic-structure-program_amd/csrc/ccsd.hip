@@ -13,6 +13,7 @@
 
 #include "ccsd.h"
 #include "comm.h"
+#include "fused.h"
 
 namespace afesp {
 
@@ -216,7 +217,8 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     // Small systems are bound by the latency of ~100 dependent launches: the independent chains below then run on four
     // lanes (streams) side by side.  Each intermediate is built entirely on one lane; I_vo feeds I_oo (same lane), x_voov feeds
     // I_voov (same lane) and the last term of I_ooov_p (explicit event).
-    const bool par = lanes_pay(s);
+    const bool par = lanes_pay(s) && !cx.rec;   // (a recorded sequence is levelled by the compiler of fused.h instead)
+    const bool fused = cx.rec != nullptr;
     auto lane = [&](int i) { if (par) cx.use_lane(i); };
     if (par) cx.fork(6);
     lane(0);
@@ -231,7 +233,14 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     C(1.0, s.w_oovo, "miej", s.t1, "me", 0.0, s.I_oo_p, "ji");
     C(1.0, s.asym, "mjef", s.v_oovv, "mief", 1.0, s.I_oo_p, "ji");
     // I_oo(j,i) = I_oo_p + t(j,e) I_vo(e,i)                              ccsd.f90:1134-1137
-    k_copy(cx, s.I_oo.d, s.I_oo_p.d, s.I_oo.size());
+    // (launch-fused path: a copy of a result costs a dependency level of its own, an o^2 x o v^2 product costs nothing -- I_oo gets
+    // the two products of I_oo_p again, in the stage where I_vo is ready)
+    if (fused) {
+        C(1.0, s.w_oovo, "miej", s.t1, "me", 0.0, s.I_oo, "ji");
+        C(1.0, s.asym, "mjef", s.v_oovv, "mief", 1.0, s.I_oo, "ji");
+    } else {
+        k_copy(cx, s.I_oo.d, s.I_oo_p.d, s.I_oo.size());
+    }
     C(1.0, s.t1, "je", s.I_vo, "ei", 1.0, s.I_oo, "ji");
     lane(1);
     // I_oooo(k,l,i,j)                                                    ccsd.f90:1139-1156
@@ -257,7 +266,9 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     // I_voov(b,j,i,a)                                                    ccsd.f90:1193-1252
     if (v1 > v0) {
         permute_add(cx, 1.0, sl(s.v_oovv, 2), "jiab", 0.0, sl(s.I_voov, 3), "bjia");
-        k_axpby(cx, s.I_voov.d + a_off, 1.0, s.x_voov.d + a_off, 1.0, a_cnt);
+        // (launch-fused path: x_voov's product a second time, straight into I_voov, instead of adding the finished x_voov a level later)
+        if (fused) C(1.0, s.v_vvov, "beia", s.t1, "je", 1.0, s.I_voov, "bjia");
+        else k_axpby(cx, s.I_voov.d + a_off, 1.0, s.x_voov.d + a_off, 1.0, a_cnt);
         C(0.5, s.w_oovv, "imbe", sl(s.t2, 3), "mjea", 1.0, sl(s.I_voov, 3), "bjia");           // (o^3 v^3 each)
         C(-0.5, s.v_oovv, "imbe", sl(s.c, 2), "mjae", 1.0, sl(s.I_voov, 3), "bjia");
         C(-1.0, s.v_oovo, "imbj", sl(s.t1, 1), "ma", 1.0, sl(s.I_voov, 3), "bjia");
@@ -277,7 +288,9 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     // -t(m,a) I_ooov_p(i,j,m,b), all three are ONE product with
     //   z_ooov(i,j,m,b) = y_ooov(i,m,j,b) + y_oovo(j,m,b,i) + I_ooov_p(i,j,m,b)
     // -- two passes over the o^2 v^2 residual less (0.27 ms of 27 at o = 20, v = 200; two launches less for a small system).
-    C(1.0, s.t1, "ie", s.v_oovv, "mjeb", 0.0, s.z_ooov, "ijmb");
+    // (launch-fused path: z_ooov starts from the bare term of I_ooov_p and collects every product of it directly, below)
+    if (fused) permute_add(cx, 1.0, s.v_oovo, "kjai", 0.0, s.z_ooov, "jkia");
+    C(1.0, s.t1, "ie", s.v_oovv, "mjeb", fused ? 1.0 : 0.0, s.z_ooov, "ijmb");
     C(1.0, s.t1, "je", s.v_ovov, "mbie", 1.0, s.z_ooov, "ijmb");
     lane(5);
     // I_ooov_p(j,k,i,a)                                                  ccsd.f90:1302-1308
@@ -287,7 +300,14 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     if (par) cx.wait(x_voov_ready);
     C(1.0, s.t1, "je", s.x_voov, "ekia", 1.0, s.I_ooov_p, "jkia");
     if (par) cx.join();
-    k_axpby(cx, s.z_ooov.d, 1.0, s.I_ooov_p.d, 1.0, s.z_ooov.size());
+    if (fused) {
+        // z_ooov = y_ooov + y_oovo + I_ooov_p with every term of I_ooov_p added to it directly (the consumer of z_ooov then waits for
+        // x_voov only, not for a pass over the finished I_ooov_p)
+        C(1.0, s.t2, "jkef", s.v_vvov, "efia", 1.0, s.z_ooov, "jkia");
+        C(1.0, s.t1, "je", s.x_voov, "ekia", 1.0, s.z_ooov, "jkia");
+    } else {
+        k_axpby(cx, s.z_ooov.d, 1.0, s.I_ooov_p.d, 1.0, s.z_ooov.size());
+    }
 }
 
 // Particle-particle ladder (src/ccsd.f90:1669), the O(o^2 v^4) term.  pp(ijab) = sum_ef c(ij,ef) <ef|ab> obeys
@@ -339,7 +359,8 @@ void ccsd_pp_ladder(Context& cx, CCState& s)
         gp.offAm += p0; gp.offCm += p0;
         gp.M = (int)(p1 - p0); gp.N = (int)N2; gp.K = (int)K2;
         gp.wide = (O % 2 == 0) && (V % 2 == 0) && (np % 2 == 0);
-        if (p1 > p0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+        if (cx.rec) cx.rec->product(gp, V * V * V * V, N2 * K2, N2 * np);
+        else if (p1 > p0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
         return;
     }
     const int64_t npa = V * (V - 1) / 2, ks = s.pp_ks, ka = s.pp_ka, ns = s.pp_ns, na = s.pp_na, nm = s.pp_nm;
@@ -356,12 +377,14 @@ void ccsd_pp_ladder(Context& cx, CCState& s)
     // tuning knob AFESP_PP_TILES="tm,tn,split,tm,tn,split": tile codes and K slices of the symmetric / the antisymmetric product
     int pt[6] = {0, 0, force_split, 0, 0, force_split};
     if (const char* e = getenv("AFESP_PP_TILES")) sscanf(e, "%d,%d,%d,%d,%d,%d", &pt[0], &pt[1], &pt[2], &pt[3], &pt[4], &pt[5]);
-    if (p1 > p0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, pt[2], pt[0], pt[1]));
+    if (cx.rec) cx.rec->product(gp, ks * np, ns * ks, ns * np);
+    else if (p1 > p0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, pt[2], pt[0], pt[1]));
     if (s.pp_pa) {
         gp.A = s.pp_va; gp.B = s.pp_ca; gp.C = s.pp_pa;
         gp.offAm = u + nm + q0; gp.offBk = u + 2 * nm + ks; gp.offCm = u + 3 * nm + 2 * ks + q0;
         gp.M = (int)(q1 - q0); gp.N = (int)na; gp.K = (int)ka;
-        if (q1 > q0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, pt[5], pt[3], pt[4]));
+        if (cx.rec) cx.rec->product(gp, ka * npa, na * ka, na * npa);
+        else if (q1 > q0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, pt[5], pt[3], pt[4]));
     }
     (void)npa;
     k_pp_expand(cx, s.pp, s.pp_ps, s.pp_pa, s.o, s.v, ns, na, p0, p1);
@@ -394,25 +417,27 @@ void ccsd_ooov_pair_form(Context& cx, CCState& s)
     gp.A = s.ov_ws; gp.B = s.pp_cs; gp.C = s.pp_ps;
     gp.offAm = u; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * ks;
     gp.M = (int)M; gp.N = (int)ns; gp.K = (int)ks;
-    AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, slices(ns, ks)));
+    if (cx.rec) cx.rec->product(gp, ks * M, ns * ks, ns * M);
+    else AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, slices(ns, ks)));
     if (s.ov_wa) {
         gp.A = s.ov_wa; gp.B = s.pp_ca; gp.C = s.pp_pa;
         gp.offAm = u + nm; gp.offBk = u + 2 * nm + ks; gp.offCm = u + 3 * nm + 2 * ks;
         gp.M = (int)M; gp.N = (int)na; gp.K = (int)ka;
-        AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, slices(na, ka)));
+        if (cx.rec) cx.rec->product(gp, ka * M, na * ka, na * M);
+        else AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, slices(na, ka)));
     }
     (void)np; (void)npa;
     k_pair_expand_add(cx, s.I_ooov_p.d, s.pp_ps, s.ov_wa ? s.pp_pa : nullptr, s.o, M, ns, na);
 }
 
-void ccsd_amplitudes(Context& cx, CCState& s)
+void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
 {
     auto C = [&](double al, const Tensor& A, const char* la, const Tensor& B, const char* lb, double be, const Tensor& Cc,
                  const char* lc) { contract(cx, al, A, la, B, lb, be, Cc, lc); };
     // lanes (small systems only, see ccsd_intermediates): T1 in two groups, the pp-ladder on its own lane, the other T2 terms
     // in three groups; all but the first group of each go into partial buffers that are added after the join
     ccsd_refresh_sharding(cx, s);
-    const bool par = lanes_pay(s), sh = s.sharded;
+    const bool par = lanes_pay(s) && !cx.rec, sh = s.sharded;
     const int64_t v0 = sh ? (int64_t)s.v * s.sh_rank / s.sh_world : 0, v1 = sh ? (int64_t)s.v * (s.sh_rank + 1) / s.sh_world : s.v;
     auto sl = [&](const Tensor& t, int axis) { return slice_axis(t, axis, v0, v1); };
     auto lane = [&](int i) { if (par) cx.use_lane(i); };
@@ -471,6 +496,7 @@ void ccsd_amplitudes(Context& cx, CCState& s)
         comm_allreduce_dev(cx, cx.comm, s.pp, (int64_t)s.o * s.o * np + s.r2.size());
         k_axpby(cx, s.r2.d, 1.0, s.r2_sh, 1.0, s.r2.size());
     }
+    if (defer_update) return;
     // P(ia/jb), + v_oovv, Jacobi divide                                  ccsd.f90:1720-1728
     k_t2_update(cx, s.t2.d, s.r2.d, par ? r2b.d : nullptr, par ? r2c.d : nullptr, s.v_oovv.d, s.D2.d, s.pp, s.o, s.v, s.t1.d, s.r1.d,
                 par ? r1b.d : nullptr, s.D1.d);
@@ -482,6 +508,75 @@ void ccsd_build_I_vovv_p(Context& cx, CCState& s, const Tensor& out)
     permute_add(cx, 1.0, s.v_vvov, "baic", 0.0, out, "ciab");
     contract(cx, -1.0, s.v_oovv, "micb", s.t1, "ma", 1.0, out, "ciab");
     contract(cx, -1.0, s.v_ovov, "maic", s.t1, "mb", 1.0, out, "ciab");
+}
+
+// The tail of a launch-fused iteration (kernels.hip, cc_tail_kernel / cc_finalize_kernel): P(ia/jb) and the Jacobi division
+// (ccsd.f90:1720-1728), the energy and rms sums (:1764-1782, :1803-1806) and -- speculatively, the caller decides afterwards -- the
+// history push and the solve of update_diis_cc (:633-666) for the slot the next update would use.
+void ccsd_tail_launch(Context& cx, CCState& s)
+{
+    auto launch = [](Context& c, CCState* st) {
+        CCTail a;
+        a.t2 = st->t2.d; a.t1 = st->t1.d; a.r2 = st->r2.d; a.r1 = st->r1.d; a.voovv = st->v_oovv.d; a.D2 = st->D2.d; a.D1 = st->D1.d;
+        a.pp = st->pp; a.t2_old = st->t2_old.d; a.o = st->o; a.v = st->v;
+        a.nerr = st->nerr;
+        a.ny = 0; a.slot = 0;
+        a.ht = a.he = nullptr; a.amp_s = a.hist_e = nullptr; a.stride = st->nvec;
+        a.coef = st->coef; a.bmat = st->bmat;
+        if (st->nerr >= 2) {   // ccsd.f90:633-646, without touching the counters (diis_update advances them if it is called)
+            int it = st->it + 1;
+            if (it > st->nerr) it -= st->nerr;
+            a.slot = it - 1;
+            a.ny = std::min(st->nact + 1, st->nerr);
+            a.ht = st->hist_t + (int64_t)a.slot * st->nvec;
+            a.he = st->hist_e + (int64_t)a.slot * st->nvec;
+            a.amp_s = st->amp_s; a.hist_e = st->hist_e;
+        }
+        st->tail_pending = st->nerr >= 2;
+        st->tail_slot = a.slot; st->tail_n = a.ny;
+        a.seq = ++c.res_seq;
+        k_cc_tail(c, a);
+    };
+    if (cx.rec) {
+        CCState* st = &s;
+        const int64_t n2 = s.t2.size(), n1 = s.t1.size(), np = (int64_t)s.o * s.o * ((int64_t)s.v * (s.v + 1) / 2);
+        std::vector<FusedRange> rd = {frange(s.r2.d, n2), frange(s.r1.d, n1), frange(s.v_oovv.d, n2), frange(s.D2.d, n2), frange(s.D1.d, n1),
+                                      frange(s.pp, np), frange(s.t2_old.d, n2)};
+        std::vector<FusedRange> wr = {frange(s.amp, s.nvec), frange(s.t2_old.d, n2), frange(cx.scal, 64 + 18 * 512)};
+        if (s.nerr >= 2) {
+            rd.push_back(frange(s.amp_s, s.nvec));
+            rd.push_back(frange(s.hist_e, s.nvec * s.nerr));
+            wr.push_back(frange(s.hist_t, s.nvec * s.nerr));
+            wr.push_back(frange(s.hist_e, s.nvec * s.nerr));
+            wr.push_back(frange(s.coef, 32));
+            wr.push_back(frange(s.bmat, (int64_t)s.nerr * s.nerr));
+        }
+        cx.rec->opaque(rd, wr, [launch, st](Context& c) { launch(c, st); });
+        return;
+    }
+    launch(cx, &s);
+}
+
+int ccsd_tail_read(Context& cx, CCState& s, double e_tol, double t_tol)
+{
+    // the finalize kernel writes [energy, rms, failure, sequence number] into coherent host memory, the number last: poll it for a
+    // while (a stream synchronisation costs ~30 us of wake-up latency), then fall back to waiting for the stream
+    volatile double* hr = cx.res_host;
+    const double want = (double)cx.res_seq;
+    bool seen = false;
+    for (int spin = 0; spin < 200000; ++spin) {
+        if (__atomic_load_n((const int64_t*)&cx.res_host[3], __ATOMIC_ACQUIRE) == *(const int64_t*)&want) { seen = true; break; }
+        if ((spin & 1023) == 1023 && hipStreamQuery(cx.stream) != hipErrorNotReady) break;
+    }
+    if (!seen) {
+        AFESP_HIP(hipStreamSynchronize(cx.stream));
+        if (hr[3] != want) throw Error(2, "ccsd_tail_read: the iteration's results did not arrive");
+    }
+    s.tail_fail = hr[2] != 0.0;
+    s.energy_old = s.energy;        // ccsd.f90:1760
+    s.energy = hr[0];
+    s.rms = hr[1];                  // un-rooted, ccsd.f90:1806
+    return (std::sqrt(s.rms) < t_tol && std::fabs(s.energy - s.energy_old) < e_tol) ? 1 : 0;   // ccsd.f90:1805
 }
 
 // The energy evaluation in two halves: the launches (part of the replayed iteration, capi.hip) and the host read.
@@ -575,6 +670,18 @@ void ccsd_diis_update(Context& cx, CCState& s) { diis_update(cx, s); }
 void diis_update(Context& cx, DiisRing& s)
 {
     if (s.nerr < 2) return;
+    if (s.tail_pending) {
+        // the launch-fused tail of this iteration has pushed the history and solved for the coefficients already (ccsd_tail_launch)
+        s.tail_pending = false;
+        s.it = s.tail_slot + 1;
+        s.nact = s.tail_n;
+        if (s.tail_fail) {
+            s.tail_fail = false;
+            throw Error(4, "ccsd::update_diis_cc: Linear solve failed!");   // ccsd.f90:666
+        }
+        k_lincomb(cx, s.amp, s.hist_t, s.nvec, s.coef, s.nact, s.nvec);
+        return;
+    }
     // ccsd.f90:633-646
     s.it += 1;
     if (s.it > s.nerr) s.it -= s.nerr;

@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "afesp_internal.h"
+#include "fused.h"
 
 namespace afesp {
 
@@ -97,6 +98,7 @@ double* Context::alloc_raw(int64_t n)
 int64_t* Context::alloc_i64(int64_t n) { return (int64_t*)alloc(n); }
 double* Context::scratch(const std::string& name, int64_t n)
 {
+    if (rec) rec->uses_scratch = true;
     const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(double);
     auto it = cache.find(name);
     if (it != cache.end() && it->second.second >= bytes) return (double*)it->second.first;
@@ -295,6 +297,7 @@ Context::~Context()
     if (stream) (void)hipStreamSynchronize(stream);
     arena.destroy();   // every block the context ever obtained: owned, cached scratch and idle ones
     if (scal_host) (void)hipHostFree(scal_host);
+    if (res_host) (void)hipHostFree(res_host);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -455,7 +458,8 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
     sig(A0); sig(B0); sig(C);
     // the re-layout decision below depends on these as well: a shape first seen unbatched must not hand its plan to a batched call
     key += (nbatch > 1 || bA0 || bB0) ? "|b" : "|u";
-    key += cx.in_repack ? "r" : "-";
+    const bool norepack = cx.in_repack || cx.rec != nullptr;   // (a recorded product of the launch-fused path is small: never re-laid-out)
+    key += norepack ? "r" : "-";
     auto it = cx.plans.find(key);
     if (it == cx.plans.end()) {
         // orientation: the kernel's column index n runs along lanes in the epilogue -> put C's fastest label in N
@@ -511,7 +515,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
             // (... or when the other operand is so much larger that the copy is small change beside streaming it:
             // asym(m,i,e,f) <ef|ma> -> r1(i,a) at o = 20, v = 200 reads 1.28 GB of integrals against 128 MB of amplitudes that it
             // would otherwise gather 8 bytes at a time -- 0.76 -> 0.45 ms)
-            if (nbatch == 1 && !bA0 && !bB0 && !cx.in_repack) {
+            if (nbatch == 1 && !bA0 && !bB0 && !norepack) {
                 if (!b_ok && (Md >= 512 || A.size() >= 8 * B.size()) && B.size() <= limit) which = 2;
                 else if (!a_ok && (Nd >= 512 || B.size() >= 8 * A.size()) && A.size() <= limit) which = 1;
             }
@@ -657,6 +661,15 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
     g.batchC = bC;
     g.a_kcontig = p.a_kc; g.b_kcontig = p.b_kc;
     g.wide = p.wide && ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0);
+    if (cx.rec) {   // launch-fused path: the product joins the recording instead of being launched
+        auto span = [](const Tensor& t) {
+            int64_t s = 1;
+            for (int i = 0; i < t.rank; ++i) s += (t.dim[i] - 1) * t.stride[i];
+            return s;
+        };
+        cx.rec->product(g, span(p.swapped ? B0 : A0), span(p.swapped ? A0 : B0), span(C));
+        return;
+    }
     // AFESP_CONTRACT_TRACE=1 (tools/contract_trace.py): every product alone on the device, its labels, extents and time on stderr
     static const bool trace = getenv("AFESP_CONTRACT_TRACE") != nullptr;
     if (!trace) {
@@ -781,6 +794,10 @@ void permute_add(Context& cx, double alpha, const Tensor& in, const char* li, do
     a.alpha = alpha;
     a.beta = beta;
     if (a.n == 0) return;
+    if (cx.rec) {
+        cx.rec->elementwise(out.d, in.d, a.rank, a.dim, a.so, a.si, alpha, beta);
+        return;
+    }
     // q_o / q_i: positions (in the enumeration above) of the indices that are unit-stride in out / in
     int q_o = -1, q_i = -1;
     for (int q = 0; q < a.rank; ++q) {

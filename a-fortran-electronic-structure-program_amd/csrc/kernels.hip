@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "afesp_internal.h"
+#include "fused.h"
 
 namespace afesp {
 
@@ -326,9 +327,22 @@ void preload_kernels()
 void k_fill(Context& cx, double* x, int64_t n, double val) { if (n > 0) LAUNCH(fill_kernel, dim3(grid_for(n)), x, n, val); }
 void k_copy(Context& cx, double* dst, const double* src, int64_t n)
 {
+    if (cx.rec) {   // launch-fused path (fused.h): one of the copies of an elementwise stage
+        const int64_t one = 1;
+        if (n > 0) cx.rec->elementwise(dst, src, 1, &n, &one, &one, 1.0, 0.0);
+        return;
+    }
     if (n > 0) AFESP_HIP(hipMemcpyAsync(dst, src, sizeof(double) * n, hipMemcpyDeviceToDevice, cx.stream));
 }
-void k_axpby(Context& cx, double* y, double a, const double* x, double b, int64_t n) { if (n > 0) LAUNCH(axpby_kernel, dim3(grid_for(n)), y, a, x, b, n); }
+void k_axpby(Context& cx, double* y, double a, const double* x, double b, int64_t n)
+{
+    if (cx.rec) {
+        const int64_t one = 1;
+        if (n > 0) cx.rec->elementwise(y, x, 1, &n, &one, &one, a, b);
+        return;
+    }
+    if (n > 0) LAUNCH(axpby_kernel, dim3(grid_for(n)), y, a, x, b, n);
+}
 void k_div(Context& cx, double* out, const double* num, const double* den, int64_t n) { if (n > 0) LAUNCH(div_kernel, dim3(grid_for(n)), out, num, den, n); }
 void k_sub(Context& cx, double* out, const double* a, const double* b, int64_t n) { if (n > 0) LAUNCH(sub_kernel, dim3(grid_for(n)), out, a, b, n); }
 void k_antisym_pair(Context& cx, double* out, const double* in, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int which)
@@ -338,11 +352,27 @@ void k_antisym_pair(Context& cx, double* out, const double* in, int64_t d0, int6
 }
 void k_asym_c(Context& cx, double* asym, double* c, const double* t1, const double* t2, int o, int v)
 {
+    if (cx.rec) {
+        const int64_t n2 = (int64_t)o * o * v * v;
+        cx.rec->opaque({frange(t1, (int64_t)o * v), frange(t2, n2)}, {frange(asym, n2), frange(c, n2)},
+                       [=](Context& c_) { k_asym_c(c_, asym, c, t1, t2, o, v); });
+        return;
+    }
     LAUNCH(asym_c_kernel, dim3(grid_for((int64_t)o * o * v * v)), asym, c, t1, t2, o, v);
 }
 void k_t2_update(Context& cx, double* t2, const double* r2, const double* r2b, const double* r2c, const double* v_oovv, const double* D2,
                  const double* pp, int o, int v, double* t1, const double* r1, const double* r1b, const double* D1)
 {
+    if (cx.rec) {
+        const int64_t n2 = (int64_t)o * o * v * v, n1 = (int64_t)o * v, np = (int64_t)o * o * ((int64_t)v * (v + 1) / 2);
+        std::vector<FusedRange> rd = {frange(r2, n2), frange(v_oovv, n2), frange(D2, n2), frange(pp, np), frange(r1, n1), frange(D1, n1)};
+        if (r2b) rd.push_back(frange(r2b, n2));
+        if (r2c) rd.push_back(frange(r2c, n2));
+        if (r1b) rd.push_back(frange(r1b, n1));
+        cx.rec->opaque(rd, {frange(t2, n2), frange(t1, n1)},
+                       [=](Context& c_) { k_t2_update(c_, t2, r2, r2b, r2c, v_oovv, D2, pp, o, v, t1, r1, r1b, D1); });
+        return;
+    }
     LAUNCH(t2_update_kernel, dim3(grid_for((int64_t)o * o * v * v)), t2, r2, r2b, r2c, v_oovv, D2, pp, o, v, t1, r1, r1b, D1);
 }
 // r2_full(ijab) = r2(ijab) + 1/2 pp(ijab): the residual before P(ia/jb) (tests / get_tensor) -- the reference's tmp_t2 up to terms that are
@@ -463,6 +493,12 @@ void k_vvx_sympack(Context& cx, double* ws, double* wa, const double* x, int v, 
 }
 void k_pair_expand_add(Context& cx, double* out, const double* ps, const double* pa, int o, int64_t ncol, int64_t ns, int64_t na)
 {
+    if (cx.rec) {
+        std::vector<FusedRange> rd = {frange(out, (int64_t)o * o * ncol), frange(ps, ns * ncol)};
+        if (pa) rd.push_back(frange(pa, na * ncol));
+        cx.rec->opaque(rd, {frange(out, (int64_t)o * o * ncol)}, [=](Context& c_) { k_pair_expand_add(c_, out, ps, pa, o, ncol, ns, na); });
+        return;
+    }
     LAUNCH(pair_expand_add_kernel, dim3(grid_for((int64_t)o * o * ncol)), out, ps, pa, o, ncol, ns, na);
 }
 void k_vvvv_sympack_packed(Context& cx, double* vs, double* va, const double* packed, int o, int v, int64_t ks, int64_t ka)
@@ -471,12 +507,26 @@ void k_vvvv_sympack_packed(Context& cx, double* vs, double* va, const double* pa
 }
 void k_c_sympack(Context& cx, double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na)
 {
+    if (cx.rec) {
+        const int64_t np = (int64_t)v * (v + 1) / 2, npa = (int64_t)v * (v - 1) / 2, ks = (np + 1) & ~(int64_t)1, ka = (npa + 1) & ~(int64_t)1;
+        std::vector<FusedRange> wr = {frange(cs, ns * ks)};
+        if (ca) wr.push_back(frange(ca, na * ka));
+        cx.rec->opaque({frange(c, (int64_t)o * o * v * v)}, wr, [=](Context& c_) { k_c_sympack(c_, cs, ca, c, o, v, ns, na); });
+        return;
+    }
     LAUNCH(c_sympack_kernel, dim3(grid_for((int64_t)o * o * v * v)), cs, ca, c, o, v, ns, na);
 }
 void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na, int64_t p0, int64_t p1)
 {
     if (p1 < 0) p1 = (int64_t)v * (v + 1) / 2;
     if (p1 <= p0) return;
+    if (cx.rec) {
+        std::vector<FusedRange> rd = {frange(ps, ns * p1)};
+        if (pa) rd.push_back(frange(pa, na * std::max<int64_t>(1, p1)));
+        cx.rec->opaque(rd, {frange(pp + (int64_t)o * o * p0, (int64_t)o * o * (p1 - p0))},
+                       [=](Context& c_) { k_pp_expand(c_, pp, ps, pa, o, v, ns, na, p0, p1); });
+        return;
+    }
     LAUNCH(pp_expand_kernel, dim3(grid_for((int64_t)o * o * (p1 - p0))), pp, ps, pa, o, v, ns, na, p0, p1);
 }
 // update_diis_cc (ccsd.f90:653-673) without leaving the device: the new row/column `slot` of the error overlap matrix comes
@@ -486,18 +536,9 @@ void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, in
 // column and multipliers travel by lane broadcasts.  The coefficients stay in HBM for lincomb_kernel.  flag[0] is set to 1
 // when a pivot vanishes (reported by the next energy evaluation).
 constexpr int DIIS_MAXN = 17;
-__global__ __launch_bounds__(TB) void diis_solve_kernel(double* coef, double* bmat, const double* partial, double* flag, int n, int nerr, int slot)
+// (wave 0 of the block; dots[0..n) in LDS; returns true when a pivot vanishes)
+__device__ __forceinline__ bool diis_solve_wave(double* coef, double* bmat, const double* dots, int n, int nerr, int slot)
 {
-    // the new row of B first: dots[q] = sum_b partial[q*RED_BLOCKS + b], one wave per q (fixed order), all q side by side
-    __shared__ double dots[DIIS_MAXN];
-    for (int q = threadIdx.x >> 6; q < n; q += TB / 64) {
-        double acc = 0.0;
-        for (int b = threadIdx.x & 63; b < RED_BLOCKS; b += 64) acc += partial[q * RED_BLOCKS + b];
-        acc = wave_sum(acc);
-        if ((threadIdx.x & 63) == 0) dots[q] = acc;
-    }
-    __syncthreads();
-    if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x, N = n + 1;   // columns 0..n of A, column N = right-hand side
     double col[DIIS_MAXN];
 #pragma unroll
@@ -540,10 +581,7 @@ __global__ __launch_bounds__(TB) void diis_solve_kernel(double* coef, double* bm
             }
         }
     }
-    if (singular) {
-        if (lane == 0) flag[0] = 1.0;
-        return;
-    }
+    if (singular) return true;
     double xj = 0.0;
 #pragma unroll
     for (int k = DIIS_MAXN - 1; k >= 0; --k) {
@@ -556,6 +594,122 @@ __global__ __launch_bounds__(TB) void diis_solve_kernel(double* coef, double* bm
         }
     }
     if (lane < n) coef[lane] = xj;
+    return false;
+}
+__global__ __launch_bounds__(TB) void diis_solve_kernel(double* coef, double* bmat, const double* partial, double* flag, int n, int nerr, int slot)
+{
+    // the new row of B first: dots[q] = sum_b partial[q*RED_BLOCKS + b], one wave per q (fixed order), all q side by side
+    __shared__ double dots[DIIS_MAXN];
+    for (int q = threadIdx.x >> 6; q < n; q += TB / 64) {
+        double acc = 0.0;
+        for (int b = threadIdx.x & 63; b < RED_BLOCKS; b += 64) acc += partial[q * RED_BLOCKS + b];
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) dots[q] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    if (diis_solve_wave(coef, bmat, dots, n, nerr, slot) && threadIdx.x == 0) flag[0] = 1.0;
+}
+
+// ---- the tail of a small system's iteration in two launches (launch-fused path, fused.h) instead of six and a blocking copy:
+// cc_tail_kernel      P(ia/jb) + Jacobi division (t2_update_kernel), the energy and rms sums (cc_energy_kernel) and the first half of the
+//                     DIIS update (diis_push_kernel) in ONE pass over the amplitudes: the new t1 enters the energy as r1 / D1, the very
+//                     quotient that is stored, so nothing waits for another thread's store;
+// cc_finalize_kernel  the ordered sums of the partials, the DIIS solve (speculative: the caller decides afterwards whether it
+//                     extrapolates), and the results written straight into pinned host memory, sequence number last -- the host
+//                     polls that word instead of paying a copy and a stream synchronisation (~40 us) per iteration.
+struct TailArgs {
+    double *t2, *t1;
+    const double *r2, *r1, *voovv, *D2, *D1, *pp;
+    double* t2_old;
+    int o, v;
+    double *ht, *he;               // DIIS history rows of this iteration ([t1 ; t2] vectors); unused when ny == 0
+    const double *amp_s, *hist_e;
+    int64_t stride;
+    int ny, slot;
+};
+__global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p)
+{
+    __shared__ double sm[18 * 4];
+    const int o = p.o, v = p.v, ny = p.ny, slot = p.slot;
+    const int64_t n = (int64_t)o * o * v * v, n1 = (int64_t)o * v;
+    double acc[18];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) acc[j] = 0.0;
+    GRID_STRIDE(x, n)
+    {
+        const int i = (int)(x % o);
+        int64_t r = x / o;
+        const int j = (int)(r % o);
+        r /= o;
+        const int a = (int)(r % v), b = (int)(r / v);
+        const int64_t y = j + (int64_t)o * (i + (int64_t)o * (b + (int64_t)v * a));
+        const int64_t lad = (a <= b) ? i + (int64_t)o * (j + (int64_t)o * ((int64_t)b * (b + 1) / 2 + a))
+                                     : j + (int64_t)o * (i + (int64_t)o * ((int64_t)a * (a + 1) / 2 + b));
+        const double t = (p.r2[x] + p.r2[y] + p.pp[lad] + p.voovv[x]) / p.D2[x];
+        const double tia = p.r1[i + o * a] / p.D1[i + o * a], tjb = p.r1[j + o * b] / p.D1[j + o * b];
+        const double vx = p.voovv[i + (int64_t)o * (j + (int64_t)o * (b + (int64_t)v * a))];
+        acc[16] += (2.0 * p.voovv[x] - vx) * (t + tia * tjb);
+        const double d = t - p.t2_old[x];
+        acc[17] += d * d;
+        p.t2_old[x] = t;
+        p.t2[x] = t;
+        if (ny) {
+            const double e = t - p.amp_s[n1 + x];
+            p.ht[n1 + x] = t;
+            p.he[n1 + x] = e;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (q < ny) acc[q] += e * (q == slot ? e : p.hist_e[(int64_t)q * p.stride + n1 + x]);
+        }
+        if (x < n1) {
+            const double t1v = p.r1[x] / p.D1[x];
+            p.t1[x] = t1v;
+            if (ny) {
+                const double e = t1v - p.amp_s[x];
+                p.ht[x] = t1v;
+                p.he[x] = e;
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (q < ny) acc[q] += e * (q == slot ? e : p.hist_e[(int64_t)q * p.stride + x]);
+            }
+        }
+    }
+    block_sum<18>(acc, sm);
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < ny; ++q) partial[q * RED_BLOCKS + blockIdx.x] = acc[q];
+        partial[16 * RED_BLOCKS + blockIdx.x] = acc[16];
+        partial[17 * RED_BLOCKS + blockIdx.x] = acc[17];
+    }
+}
+__global__ __launch_bounds__(TB) void cc_finalize_kernel(double* out2, double* host_res, double seq, double* coef, double* bmat,
+                                                         const double* partial, int nblk, int n, int nerr, int slot)
+{
+    __shared__ double dots[DIIS_MAXN + 2];
+    __shared__ int fail;
+    if (threadIdx.x == 0) fail = 0;
+    for (int q = threadIdx.x >> 6; q < n + 2; q += TB / 64) {
+        const int row = q < n ? q : 16 + (q - n);
+        double acc = 0.0;
+        for (int b = threadIdx.x & 63; b < nblk; b += 64) acc += partial[row * RED_BLOCKS + b];
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) dots[q] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && n > 0) {
+        const bool singular = diis_solve_wave(coef, bmat, dots, n, nerr, slot);
+        if (singular && threadIdx.x == 0) fail = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[0] = dots[n];
+        out2[1] = dots[n + 1];
+        host_res[0] = dots[n];
+        host_res[1] = dots[n + 1];
+        host_res[2] = fail ? 1.0 : 0.0;
+        __threadfence_system();
+        __hip_atomic_store(&host_res[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 void k_diis_solve(Context& cx, double* coef, double* bmat, double* flag, int n, int nerr, int slot)
 {
@@ -577,8 +731,25 @@ static double* partials(Context& cx) { return cx.scal + 64; }
 
 void k_cc_energy(Context& cx, double* out2, const double* v_oovv, const double* t1, const double* t2, double* t2_old, int o, int v)
 {
+    if (cx.rec) {
+        const int64_t n2 = (int64_t)o * o * v * v;
+        cx.rec->opaque({frange(v_oovv, n2), frange(t1, (int64_t)o * v), frange(t2, n2), frange(t2_old, n2)},
+                       {frange(t2_old, n2), frange(out2, 2), frange(partials(cx), 2 * RED_BLOCKS)},
+                       [=](Context& c_) { k_cc_energy(c_, out2, v_oovv, t1, t2, t2_old, o, v); });
+        return;
+    }
     LAUNCH(cc_energy_kernel, dim3(RED_BLOCKS), partials(cx), v_oovv, t1, t2, t2_old, o, v);
     LAUNCH(final_sum_kernel, dim3(1), out2, partials(cx), RED_BLOCKS, 2, 0);
+}
+void k_cc_tail(Context& cx, const CCTail& a)
+{
+    if (a.ny > 16) throw Error(3, "k_cc_tail: too many DIIS vectors");
+    TailArgs p;
+    p.t2 = a.t2; p.t1 = a.t1; p.r2 = a.r2; p.r1 = a.r1; p.voovv = a.voovv; p.D2 = a.D2; p.D1 = a.D1; p.pp = a.pp; p.t2_old = a.t2_old;
+    p.o = a.o; p.v = a.v; p.ht = a.ht; p.he = a.he; p.amp_s = a.amp_s; p.hist_e = a.hist_e; p.stride = a.stride; p.ny = a.ny; p.slot = a.slot;
+    const int nblk = (int)grid_for((int64_t)a.o * a.o * a.v * a.v, RED_BLOCKS);   // (only blocks that have elements write partials)
+    LAUNCH(cc_tail_kernel, dim3(nblk), partials(cx), p);
+    LAUNCH(cc_finalize_kernel, dim3(1), cx.scal, cx.res_dev, (double)a.seq, a.coef, a.bmat, partials(cx), nblk, a.ny, a.nerr, a.slot);
 }
 void k_mp2_energy(Context& cx, double* out1, const double* v_oovv, const double* D2, int o, int v)
 {

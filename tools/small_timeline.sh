@@ -12,7 +12,7 @@ for f in glob.glob("/tmp/kt_small/*/*kernel_trace.csv"):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 end = int(rows[-1]["End_Timestamp"])
-sel = [r for r in rows if int(r["Start_Timestamp"]) >= end - 0.55e6]
+sel = [r for r in rows if int(r["Start_Timestamp"]) >= end - float(__import__("os").environ.get("WINDOW_NS", "0.55e6"))]
 t0 = int(sel[0]["Start_Timestamp"])
 with open(sys.argv[1], "w") as o:
     for r in sel:
