@@ -30,7 +30,7 @@ EXPORTS = [
     "afesp_read_eri_text", "afesp_write_fcidump", "afesp_set_eri", "afesp_build_fock", "afesp_ccsd_t_plain",
     "afesp_synthetic_ao", "afesp_ccsd_pp_ladder_flop", "afesp_ccsd_iteration_flop",
     "afesp_device_count", "afesp_comm_unique_id", "afesp_comm_init", "afesp_comm_destroy", "afesp_allreduce_sum",
-    "afesp_ccsd_t_block_size", "afesp_test_inject", "afesp_ccsd_is_split", "afesp_ccsd_set_split", "afesp_debug_stamps", "afesp_arena_stats",
+    "afesp_ccsd_t_block_size", "afesp_test_inject", "afesp_ccsd_is_split", "afesp_ccsd_set_split", "afesp_ccsd_set_fused", "afesp_ccsd_iteration_launches", "afesp_debug_stamps", "afesp_arena_stats",
 ]
 COMM_RCCL, COMM_HOST = 0, 1
 
@@ -114,6 +114,8 @@ def load_library():
     L.afesp_arena_stats.argtypes = [C.c_void_p, _dp]
     L.afesp_ccsd_is_split.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.afesp_ccsd_set_split.argtypes = [C.c_void_p, C.c_int]
+    L.afesp_ccsd_set_fused.argtypes = [C.c_void_p, C.c_int]
+    L.afesp_ccsd_iteration_launches.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.afesp_debug_stamps.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L
@@ -285,6 +287,16 @@ class Engine:
     def ccsd_set_split(self, mode):
         """1: split the CCSD iteration over the ranks, 0: replicas, -1: as AFESP_CC_SHARD says (default replicas)."""
         self._chk(self.L.afesp_ccsd_set_split(self.h, int(mode)))
+
+    def ccsd_set_fused(self, mode):
+        """1: the launch-fused iteration of small systems (csrc/fused.h), 0: call by call, -1: as AFESP_FUSED says (default on)."""
+        self._chk(self.L.afesp_ccsd_set_fused(self.h, int(mode)))
+
+    def ccsd_iteration_launches(self):
+        """Kernel launches of one compiled (launch-fused) iteration; 0 when the iteration runs call by call."""
+        n = C.c_int()
+        self._chk(self.L.afesp_ccsd_iteration_launches(self.h, C.byref(n)))
+        return n.value
 
     def ccsd_is_split(self):
         f = C.c_int()

@@ -76,6 +76,7 @@ struct Context {
     Comm* comm = nullptr;                 // rank-to-rank sums (comm.h); null = single rank
     int cc_split_mode = -1;               // afesp_ccsd_set_split: 1 split the CCSD iteration over the ranks, 0 replicas, -1 environment (default off)
     int test_throw = 0;                   // test hook (afesp_test_inject): the next laned amplitude update throws
+    int fused_mode = -1;                  // afesp_ccsd_set_fused: 1 launch-fused small-system path on, 0 off, -1 environment (default on)
     Recorder* rec = nullptr;              // set while a call sequence is being recorded for the launch-fused path (fused.h): nothing is launched
     hipStream_t stream = nullptr;
     Arena arena;                          // every device allocation of the context goes through it
@@ -111,8 +112,8 @@ struct Context {
     int marks_used = 0;
     double* scal = nullptr;               // small device scratch for reductions (64 doubles)
     double* scal_host = nullptr;          // pinned mirror
-    // results a kernel writes straight into host memory (coherent, mapped): [energy, rms, DIIS failure, sequence number] -- the
-    // sequence number is written last; res_seq is the number the next such launch will write (k_cc_tail)
+    // results a kernel writes straight into host memory (coherent, mapped): [energy, rms, -, sequence number, ..., B(i,j) at 8 + i + 16 j]
+    // -- the sequence number is written last; res_seq is the number the next such launch will write (k_cc_tail)
     double* res_host = nullptr;
     double* res_dev = nullptr;
     int64_t res_seq = 0;
@@ -216,6 +217,8 @@ struct CCTail {
     int64_t seq;
 };
 void k_cc_tail(Context& cx, const CCTail& a);
+// out = sum_j coef[j] x_j with the coefficients handed over by value (the host solved for them)
+void k_lincomb_vals(Context& cx, double* out, const double* xbase, int64_t xstride, const double* coef_host, int nx, int64_t n);
 constexpr int DIIS_FLAG_SLOT = 48;   // cx.scal[48]: set by diis_solve_kernel when the solve fails, read with the energies
 void diis_check_flag(Context& cx, const double* host_scal);   // throws the reference's error (ccsd.f90:666) if it is set
 // pair-symmetric AO->MO: u(i,j,KL) from the packed array; out(k,l,PQ) = in(q,p,tri(k,l)); packed[tri(PQ,RS)] = full(s,r,PQ)

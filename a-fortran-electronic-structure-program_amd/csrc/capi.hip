@@ -226,8 +226,8 @@ int afesp_ctx_create(int device, afesp_ctx** out)
         AFESP_HIP(hipStreamCreate(&c->cx.stream));
         c->cx.scal = c->cx.alloc(64 + 18 * 512);
         AFESP_HIP(hipHostMalloc((void**)&c->cx.scal_host, sizeof(double) * 64, hipHostMallocDefault));
-        AFESP_HIP(hipHostMalloc((void**)&c->cx.res_host, sizeof(double) * 8, hipHostMallocCoherent | hipHostMallocMapped));
-        memset(c->cx.res_host, 0, sizeof(double) * 8);
+        AFESP_HIP(hipHostMalloc((void**)&c->cx.res_host, sizeof(double) * (8 + 256), hipHostMallocCoherent | hipHostMallocMapped));
+        memset(c->cx.res_host, 0, sizeof(double) * (8 + 256));
         AFESP_HIP(hipHostGetDevicePointer((void**)&c->cx.res_dev, c->cx.res_host, 0));
         c->cx.ws.bytes = (size_t)256 << 20;   // split-K slabs
         c->cx.ws.ptr = c->cx.alloc((int64_t)(c->cx.ws.bytes / sizeof(double)));
@@ -1406,6 +1406,22 @@ int afesp_ccsd_is_split(afesp_ctx* ctx, int* split)
         if (!ctx->cc.ready || !split) throw Error(1, "afesp_ccsd_is_split: no CCSD state");
         ccsd_refresh_sharding(ctx->cx, ctx->cc);
         *split = ctx->cc.sharded ? 1 : 0;
+    });
+}
+
+int afesp_ccsd_set_fused(afesp_ctx* ctx, int mode)
+{
+    return guarded(ctx, [&] {
+        if (mode < -1 || mode > 1) throw Error(1, "afesp_ccsd_set_fused: mode is -1 (environment), 0 (call by call) or 1 (launch-fused)");
+        ctx->cx.fused_mode = mode;
+    });
+}
+
+int afesp_ccsd_iteration_launches(afesp_ctx* ctx, int* launches)
+{
+    return guarded(ctx, [&] {
+        if (!launches) throw Error(1, "afesp_ccsd_iteration_launches: null argument");
+        *launches = fused_launches(ctx->fused_iter.prog);
     });
 }
 

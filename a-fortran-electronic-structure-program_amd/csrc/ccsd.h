@@ -15,9 +15,10 @@ struct DiisRing {
     double *coef = nullptr;     // device coefficients
     double *bmat = nullptr;     // error overlap matrix on the device (nerr x nerr, full)
     // launch-fused tail (ccsd_tail_launch): the history push and the solve of the NEXT update have already run, for slot / count
-    // tail_slot / tail_n; diis_update then only advances the counters and extrapolates.  tail_fail: that solve met a vanishing pivot
-    bool tail_pending = false, tail_fail = false;
+    // tail_slot / tail_n; diis_update then only advances the counters and extrapolates.
+    bool tail_pending = false;
     int tail_slot = 0, tail_n = 0;
+    double tail_b[256];          // the error overlap matrix of that update as the finalize kernel left it in host memory (tail_n x tail_n, ld 16)
 };
 void diis_alloc(Context& cx, DiisRing& r, int diis_nerr);   // r.nvec and r.amp set by the caller (init_diis_cc_t, :577-615)
 void diis_save(Context& cx, DiisRing& r);                   // ccsd.f90:342-343

@@ -572,7 +572,8 @@ int ccsd_tail_read(Context& cx, CCState& s, double e_tol, double t_tol)
         AFESP_HIP(hipStreamSynchronize(cx.stream));
         if (hr[3] != want) throw Error(2, "ccsd_tail_read: the iteration's results did not arrive");
     }
-    s.tail_fail = hr[2] != 0.0;
+    for (int j = 0; j < s.tail_n; ++j)
+        for (int i = 0; i < s.tail_n; ++i) s.tail_b[i + 16 * j] = hr[8 + i + 16 * j];
     s.energy_old = s.energy;        // ccsd.f90:1760
     s.energy = hr[0];
     s.rms = hr[1];                  // un-rooted, ccsd.f90:1806
@@ -675,11 +676,32 @@ void diis_update(Context& cx, DiisRing& s)
         s.tail_pending = false;
         s.it = s.tail_slot + 1;
         s.nact = s.tail_n;
-        if (s.tail_fail) {
-            s.tail_fail = false;
-            throw Error(4, "ccsd::update_diis_cc: Linear solve failed!");   // ccsd.f90:666
+        // [B -1; -1 0] c = (0,...,0,-1) (ccsd.f90:653-666; the reference calls dsysv, linalg.fpp:38-56), Gaussian elimination with
+        // partial pivoting on the host: at most 17 x 17
+        const int n = s.nact, N = n + 1;
+        double A[17][18];
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j <= N; ++j)
+                A[i][j] = (i < n && j < n) ? s.tail_b[i + 16 * j] : (j == N) ? (i == n ? -1.0 : 0.0) : (i == n && j == n) ? 0.0 : -1.0;
+        for (int k = 0; k < N; ++k) {
+            int p = k;
+            for (int i = k + 1; i < N; ++i)
+                if (std::fabs(A[i][k]) > std::fabs(A[p][k])) p = i;
+            if (A[p][k] == 0.0) throw Error(4, "ccsd::update_diis_cc: Linear solve failed!");   // ccsd.f90:666
+            if (p != k)
+                for (int j = 0; j <= N; ++j) std::swap(A[k][j], A[p][j]);
+            for (int i = k + 1; i < N; ++i) {
+                const double f = A[i][k] / A[k][k];
+                for (int j = k; j <= N; ++j) A[i][j] -= f * A[k][j];
+            }
         }
-        k_lincomb(cx, s.amp, s.hist_t, s.nvec, s.coef, s.nact, s.nvec);
+        double c[17];
+        for (int k = N - 1; k >= 0; --k) {
+            double r = A[k][N];
+            for (int j = k + 1; j < N; ++j) r -= A[k][j] * c[j];
+            c[k] = r / A[k][k];
+        }
+        k_lincomb_vals(cx, s.amp, s.hist_t, s.nvec, c, n, s.nvec);
         return;
     }
     // ccsd.f90:633-646

@@ -88,12 +88,12 @@ struct FusedSlot {
 template <typename Body>
 inline bool fused_exec(Context& cx, FusedSlot& slot, Body body);   // false: not fused, caller runs the body itself
 void fused_slot_reset(Context& cx, FusedSlot& slot);
-bool fused_enabled();                                              // AFESP_FUSED=0 switches the whole mechanism off
+bool fused_enabled(const Context& cx);                             // afesp_ccsd_set_fused, else AFESP_FUSED=0 switches the whole mechanism off
 
 template <typename Body>
 inline bool fused_exec(Context& cx, FusedSlot& slot, Body body)
 {
-    if (slot.disabled || !fused_enabled()) return false;
+    if (slot.disabled || !fused_enabled(cx)) return false;
     if (slot.prog && fused_epoch(slot.prog) != -2 && fused_epoch(slot.prog) != cx.scratch_epoch) fused_slot_reset(cx, slot);
     if (!slot.prog) {
         Recorder rec;

@@ -339,10 +339,10 @@ TileKind pick_tile(int M, int N)
 
 }  // namespace
 
-bool fused_enabled()
+bool fused_enabled(const Context& cx)
 {
     static const bool on = [] { const char* e = getenv("AFESP_FUSED"); return !(e && e[0] == '0'); }();
-    return on;
+    return cx.fused_mode >= 0 ? cx.fused_mode == 1 : on;
 }
 
 FusedProgram* fused_compile(Context& cx, Recorder& r)

@@ -12,11 +12,28 @@ constexpr int TB = 256;
 inline unsigned grid_for(int64_t n, int cap = 4096) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + TB - 1) / TB, cap)); }
 #define GRID_STRIDE(IDX_, n) for (int64_t IDX_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; IDX_ < (n); IDX_ += (int64_t)gridDim.x * blockDim.x)
 
+// Sum over the 64 lanes of a wave, the same value in every lane, in a fixed order (bit-reproducible).  Four butterfly steps inside
+// each row of 16 lanes as DPP moves (one VALU instruction per 32-bit half; a __shfl is a ds_bpermute plus ~8 instructions of lane
+// arithmetic -- eighteen sums of a block reduction were ~2000 instructions per wave), then the four row sums through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_permuted(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int from)   // `from` uniform: the value lands in scalar registers
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), from), hi = __builtin_amdgcn_readlane(__double2hiint(v), from);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    v += dpp_permuted<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_permuted<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_permuted<0x141>(v);   // row_half_mirror
+    v += dpp_permuted<0x140>(v);   // row_mirror: every lane of a row holds the row's sum
+    return ((lane_value(v, 0) + lane_value(v, 16)) + lane_value(v, 32)) + lane_value(v, 48);
 }
 // block-wide sum of up to NV values; result valid in thread 0
 template <int NV>
@@ -551,45 +568,54 @@ __device__ __forceinline__ bool diis_solve_wave(double* coef, double* bmat, cons
         col[i] = v;
     }
     if (lane < n) bmat[slot + nerr * lane] = bmat[lane + nerr * slot] = dots[lane];
+    // Column k of the matrix lives in lane k, and k is a compile-time constant in the unrolled loops below: its elements are read
+    // with v_readlane (a few cycles, the value uniform in scalar registers) -- a __shfl is a ds_bpermute, ~100 cycles of latency,
+    // and the elimination is a chain of ~N^2 of them (the single-wave solve took 18-20 us with shuffles).
     bool singular = false;
 #pragma unroll
     for (int k = 0; k < DIIS_MAXN; ++k) {
         if (k < N && !singular) {
+            double colk[DIIS_MAXN];   // column k from row k down, before the row exchange
             double big = -1.0;
             int p = k;
 #pragma unroll
             for (int i = k; i < DIIS_MAXN; ++i) {
                 if (i < N) {   // (uniform: rows beyond the system cost nothing)
-                    const double v = fabs(__shfl(col[i], k, 64));
+                    colk[i] = lane_value(col[i], k);
+                    const double v = fabs(colk[i]);
                     if (v > big) { big = v; p = i; }
                 }
             }
             singular = big == 0.0;
+            double pivot = colk[k];
             if (p != k) {
                 const double t = col[k];
 #pragma unroll
                 for (int i = k + 1; i < DIIS_MAXN; ++i)
-                    if (i == p) { col[k] = col[i]; col[i] = t; }
+                    if (i == p) { col[k] = col[i]; col[i] = t; pivot = colk[i]; colk[i] = colk[k]; }
             }
-            const double rkk = singular ? 0.0 : 1.0 / __shfl(col[k], k, 64);
+            const double rkk = singular ? 0.0 : 1.0 / pivot;
 #pragma unroll
             for (int i = k + 1; i < DIIS_MAXN; ++i) {
                 if (i < N) {
-                    const double f = __shfl(col[i], k, 64) * rkk;
+                    const double f = colk[i] * rkk;
                     col[i] -= f * col[k];
                 }
             }
         }
     }
     if (singular) return true;
+    // back substitution, column by column, on the right-hand side held uniformly: x_k = r_k / U(k,k), r_i -= U(i,k) x_k for i < k
+    double r[DIIS_MAXN];
+#pragma unroll
+    for (int i = 0; i < DIIS_MAXN; ++i) r[i] = i < N ? lane_value(col[i], N) : 0.0;
     double xj = 0.0;
 #pragma unroll
     for (int k = DIIS_MAXN - 1; k >= 0; --k) {
         if (k < N) {
-            double term = (lane > k && lane < N) ? col[k] * xj : 0.0;
+            const double xk = r[k] / lane_value(col[k], k);
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) term += __shfl_xor(term, off, 64);
-            const double xk = (__shfl(col[k], N, 64) - term) / __shfl(col[k], k, 64);
+            for (int i = 0; i < k; ++i) r[i] -= lane_value(col[i], k) * xk;
             if (lane == k) xj = xk;
         }
     }
@@ -655,23 +681,29 @@ __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p
         p.t2_old[x] = t;
         p.t2[x] = t;
         if (ny) {
+            // (the history rows are read unconditionally, rows past ny clamped: a load under a branch per row makes hipcc wait
+            // for each one in turn -- sixteen memory round trips instead of one)
+            double h[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) h[q] = p.hist_e[(int64_t)min(q, ny - 1) * p.stride + n1 + x];
             const double e = t - p.amp_s[n1 + x];
             p.ht[n1 + x] = t;
             p.he[n1 + x] = e;
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (q < ny) acc[q] += e * (q == slot ? e : p.hist_e[(int64_t)q * p.stride + n1 + x]);
+            for (int q = 0; q < 16; ++q) acc[q] += q < ny ? e * (q == slot ? e : h[q]) : 0.0;
         }
         if (x < n1) {
             const double t1v = p.r1[x] / p.D1[x];
             p.t1[x] = t1v;
             if (ny) {
+                double h[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) h[q] = p.hist_e[(int64_t)min(q, ny - 1) * p.stride + x];
                 const double e = t1v - p.amp_s[x];
                 p.ht[x] = t1v;
                 p.he[x] = e;
 #pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    if (q < ny) acc[q] += e * (q == slot ? e : p.hist_e[(int64_t)q * p.stride + x]);
+                for (int q = 0; q < 16; ++q) acc[q] += q < ny ? e * (q == slot ? e : h[q]) : 0.0;
             }
         }
     }
@@ -682,12 +714,10 @@ __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p
         partial[17 * RED_BLOCKS + blockIdx.x] = acc[17];
     }
 }
-__global__ __launch_bounds__(TB) void cc_finalize_kernel(double* out2, double* host_res, double seq, double* coef, double* bmat,
-                                                         const double* partial, int nblk, int n, int nerr, int slot)
+__global__ __launch_bounds__(TB) void cc_finalize_kernel(double* out2, double* host_res, double seq, double* bmat, const double* partial, int nblk,
+                                                         int n, int nerr, int slot)
 {
     __shared__ double dots[DIIS_MAXN + 2];
-    __shared__ int fail;
-    if (threadIdx.x == 0) fail = 0;
     for (int q = threadIdx.x >> 6; q < n + 2; q += TB / 64) {
         const int row = q < n ? q : 16 + (q - n);
         double acc = 0.0;
@@ -696,20 +726,43 @@ __global__ __launch_bounds__(TB) void cc_finalize_kernel(double* out2, double* h
         if ((threadIdx.x & 63) == 0) dots[q] = acc;
     }
     __syncthreads();
-    if (threadIdx.x < 64 && n > 0) {
-        const bool singular = diis_solve_wave(coef, bmat, dots, n, nerr, slot);
-        if (singular && threadIdx.x == 0) fail = 1;
+    // row / column `slot` of the error overlap matrix (ccsd.f90:653-663) on the device, and the whole matrix for the host, which
+    // solves the <= 17 x 17 system itself (as the reference does, linalg.fpp:38-56) while this stream goes on
+    if ((int)threadIdx.x < n) bmat[slot + nerr * threadIdx.x] = bmat[threadIdx.x + nerr * slot] = dots[threadIdx.x];
+    __syncthreads();
+    for (int x = threadIdx.x; x < n * n; x += TB) {
+        const int i = x % n, j = x / n;
+        host_res[8 + i + 16 * j] = (i == slot) ? dots[j] : (j == slot) ? dots[i] : bmat[i + nerr * j];
     }
+    __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
         out2[0] = dots[n];
         out2[1] = dots[n + 1];
         host_res[0] = dots[n];
         host_res[1] = dots[n + 1];
-        host_res[2] = fail ? 1.0 : 0.0;
         __threadfence_system();
         __hip_atomic_store(&host_res[3], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+struct Coefs {
+    double c[16];
+};
+__global__ void lincomb_vals_kernel(double* out, const double* xbase, int64_t xstride, Coefs coef, int nx, int64_t n)
+{
+    GRID_STRIDE(i, n)
+    {
+        double s = 0.0;
+        for (int j = 0; j < nx; ++j) s += coef.c[j] * xbase[j * xstride + i];
+        out[i] = s;
+    }
+}
+void k_lincomb_vals(Context& cx, double* out, const double* xbase, int64_t xstride, const double* coef_host, int nx, int64_t n)
+{
+    if (nx > 16) throw Error(3, "k_lincomb_vals: too many vectors");
+    Coefs c;
+    for (int j = 0; j < 16; ++j) c.c[j] = j < nx ? coef_host[j] : 0.0;
+    LAUNCH(lincomb_vals_kernel, dim3(grid_for(n)), out, xbase, xstride, c, nx, n);
 }
 void k_diis_solve(Context& cx, double* coef, double* bmat, double* flag, int n, int nerr, int slot)
 {
@@ -749,7 +802,7 @@ void k_cc_tail(Context& cx, const CCTail& a)
     p.o = a.o; p.v = a.v; p.ht = a.ht; p.he = a.he; p.amp_s = a.amp_s; p.hist_e = a.hist_e; p.stride = a.stride; p.ny = a.ny; p.slot = a.slot;
     const int nblk = (int)grid_for((int64_t)a.o * a.o * a.v * a.v, RED_BLOCKS);   // (only blocks that have elements write partials)
     LAUNCH(cc_tail_kernel, dim3(nblk), partials(cx), p);
-    LAUNCH(cc_finalize_kernel, dim3(1), cx.scal, cx.res_dev, (double)a.seq, a.coef, a.bmat, partials(cx), nblk, a.ny, a.nerr, a.slot);
+    LAUNCH(cc_finalize_kernel, dim3(1), cx.scal, cx.res_dev, (double)a.seq, a.bmat, partials(cx), nblk, a.ny, a.nerr, a.slot);
 }
 void k_mp2_energy(Context& cx, double* out1, const double* v_oovv, const double* D2, int o, int v)
 {

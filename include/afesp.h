@@ -173,6 +173,15 @@ int afesp_allreduce_sum(afesp_ctx* ctx, double* inout, int64_t n);
  * AFESP_CC_SHARD=0 keeps replicas whatever mode says).  *split of afesp_ccsd_is_split = what the next iteration will do. */
 int afesp_ccsd_set_split(afesp_ctx* ctx, int mode);
 int afesp_ccsd_is_split(afesp_ctx* ctx, int* split);
+/* Small systems (o^2 v^2 <= 2^20 amplitudes, one rank): the iteration of afesp_ccsd_iterate / afesp_ccsd_solve -- every contraction
+ * site of update_restricted_intermediates and update_amplitudes_restricted (src/ccsd.f90:1040-1312, :1538-1732), update_cc_energy
+ * (:1764-1806) and the first half of update_diis_cc (:633-663) -- runs as a compiled sequence of ~11 launches, one grouped launch
+ * per dependency level (csrc/fused.h), instead of ~75 launches call by call.  mode 1 = on, 0 = off (the call-by-call path on
+ * parallel streams, graph-replayed after AFESP_GRAPH_AFTER iterations), -1 = as the environment says (AFESP_FUSED=0 switches it
+ * off; default on).  *launches of afesp_ccsd_iteration_launches = kernel launches of one compiled iteration (0: not compiled,
+ * or not eligible). */
+int afesp_ccsd_set_fused(afesp_ctx* ctx, int mode);
+int afesp_ccsd_iteration_launches(afesp_ctx* ctx, int* launches);
 /* Occupied block size of the (T) triple enumeration on this rank's device (it depends on the device memory size and on the
  * AFESP_T_POOL_GIB / AFESP_T_SPLIT_TILES environment): ranks whose values differ would enumerate different flat orders, so
  * callers compare it across ranks before sharding (bench.py and els_amd put it into their first all-reduce). */

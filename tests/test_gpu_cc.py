@@ -94,8 +94,9 @@ def test_completely_renormalised_triples_match_bundled_outputs(eng, name):
     assert np.max(np.abs(parts - out)) < 1e-12
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("o,v", [(4, 9), (12, 72)])
-def test_one_iteration_term_by_term(eng, o, v):
+def test_one_iteration_term_by_term(eng, o, v, fused):
     """Every intermediate and both residuals after one update from non-trivial amplitudes (t1 != 0).  The second size is
     the largest the oracle does in seconds and is past the thresholds where the launcher switches to the kernels config 5
     runs on: 256x128 / 128x128 tiles with 16-byte staging, K slicing by the wave-quantisation score, re-laid-out operands,
@@ -108,6 +109,7 @@ def test_one_iteration_term_by_term(eng, o, v):
     else:
         n, e, eri = molecules.synthetic_system(o, v, scale=0.05)
     cc = orc.OracleCC(o, v, eri, e, 8)
+    eng.ccsd_set_fused(fused)       # both evaluation orders: one grouped launch per dependency level (csrc/fused.hip) / call by call
     eng.ccsd_init(o, v, e, eri, 8)
     rng = np.random.default_rng(5)
     t1 = 0.05 * rng.standard_normal((o, v))
@@ -126,7 +128,39 @@ def test_one_iteration_term_by_term(eng, o, v):
     assert np.max(np.abs(eng.tensor("r1") - cc.field("r1"))) < tol
     assert np.max(np.abs(_p(eng.tensor("r2")) - _p(cc.field("r2")))) < tol
     g1, g2 = eng.amplitudes()
+    eng.ccsd_set_fused(-1)
     assert np.max(np.abs(g1 - cc.t1)) < tol and np.max(np.abs(g2 - cc.t2)) < tol
+
+
+@pytest.mark.parametrize("pp_sym", ["0", "1"])
+@pytest.mark.parametrize("o,v", [(5, 53), (7, 21), (9, 19), (4, 10), (1, 3), (2, 2), (9, 1), (1, 9), (6, 4)])
+def test_launch_fused_iteration_equals_the_call_by_call_iteration(o, v, pp_sym, monkeypatch):
+    """Small systems run their iteration as a compiled sequence of grouped launches (csrc/fused.hip: the recorded calls of
+    update_restricted_intermediates / update_amplitudes_restricted levelled by data dependence, the update / energy / DIIS tail in
+    two kernels, the DIIS system solved on the host).  Same DIIS path as the call-by-call evaluation, iteration by iteration; at
+    most 25 launches per iteration; and the two may alternate inside one solve (the error overlap matrix lives on the device)."""
+    from afesp_amd.capi import Engine
+    monkeypatch.setenv("AFESP_PP_SYM", pp_sym)
+    runs = {}
+    with Engine(0) as e2:
+        for mode in ("fused", "plain", "mixed"):
+            e2.ccsd_set_fused(0 if mode == "plain" else 1)
+            e2.synthetic_init(o, v, 0.03, 4711, 5)
+            e2.ccsd_energy()
+            en = []
+            for it in range(9):
+                if mode == "mixed":
+                    e2.ccsd_set_fused(1 if (it // 2) % 2 == 0 else 0)
+                en.append(e2.ccsd_iterate(1e-14, 1e-14)[:2])
+                e2.ccsd_diis()
+            if mode == "fused":
+                nl = e2.ccsd_iteration_launches()
+                assert 0 < nl <= 25, nl
+            runs[mode] = (np.array(en), e2.amplitudes())
+        e2.ccsd_set_fused(-1)
+    for mode in ("plain", "mixed"):
+        assert np.max(np.abs(runs["fused"][0] - runs[mode][0])) < 1e-12, mode
+        assert np.max(np.abs(runs["fused"][1][0] - runs[mode][1][0])) < 1e-12 and np.max(np.abs(runs["fused"][1][1] - runs[mode][1][1])) < 1e-12
 
 
 @pytest.mark.parametrize("o,v", [(1, 3), (2, 2), (3, 8), (6, 4), (5, 9), (2, 17), (7, 21), (9, 2)])
