@@ -1083,6 +1083,10 @@ int afesp_ccsd_so_get_tensor(afesp_ctx* ctx, const char* name, double* out, int6
     return guarded(ctx, [&] {
         if (!ctx->so.ready) throw Error(1, "afesp_ccsd_so_get_tensor: no spin-orbital CCSD state");
         SOState& s = ctx->so;
+        if (!strcmp(name, "W_vvvv")) {   // not formed by the iteration (so_ladder): built from the current t1 on request
+            AFESP_HIP(hipSetDevice(ctx->cx.device));
+            so_build_W_vvvv(ctx->cx, s);
+        }
         struct { const char* n; const Tensor* t; } tab[] = {
             {"F_vv", &s.F_vv}, {"F_oo", &s.F_oo}, {"F_ov", &s.F_ov}, {"W_oooo", &s.W_oooo}, {"W_vvvv", &s.W_vvvv},
             {"W_ovvo", &s.W_ovvo}, {"tau", &s.tau}, {"tau_tilde", &s.tau_t}, {"oovv", &s.oovv}, {"vvvv", &s.vvvv},

@@ -16,8 +16,14 @@ struct SOState : DiisRing {
     Tensor oooo, ooov, ovoo, oovo, oovv, ovvo, ovvv, vovv, vvvv;
     Tensor D1, D2, t1, t2, t2_old, r1, r2;
     Tensor F_vv, F_oo, F_ov, W_oooo, W_vvvv, W_ovvo, tau, tau_t;
+    Tensor t1_w;                     // t1 as the last so_intermediates saw it
     double energy = 0.0, energy_old = 0.0, rms = 0.0;
     void* tplan = nullptr;           // cached (T) launch plan (triples_so.hip)
+    // 1/2 tau_ijef W_abef (ccsd.f90:1021-1024) without W_abef (so_ladder): the bare part over antisymmetric pairs -- va(ef, ab) =
+    // <ab||ef> for e < f, a < b built once, ta(ij, ef) = tau for i < j, e < f and the product pa(ij, ab) per iteration
+    double *va = nullptr, *ta = nullptr, *pa = nullptr;
+    int64_t* lad_tab = nullptr;
+    int64_t lad_ka = 0, lad_na = 0;  // even leading dimensions: v(v-1)/2 and o(o-1)/2 rounded up
 };
 
 // eri_mo_dev: packed chemist MO integrals on the device (length neri(nbasis)); e_host: spatial orbital energies (host)
@@ -26,6 +32,7 @@ void so_init(Context& cx, SOState& s, int nbasis, int nel, const double* eri_mo_
 void so_free(Context& cx, SOState& s);
 void so_intermediates(Context& cx, SOState& s);   // build_tau, build_F, build_W
 void so_amplitudes(Context& cx, SOState& s);      // update_amplitudes
+void so_build_W_vvvv(Context& cx, SOState& s);    // W_abef itself (ccsd.f90:852-861), on request: the iteration never forms it
 int so_energy(Context& cx, SOState& s, double e_tol, double t_tol);
 // (T): contribution of the triples i<j<k with flat index in [t_begin, t_end) to E_T (ccsd.f90:1910)
 int64_t so_triples_count(int o);

@@ -56,11 +56,12 @@ __global__ void so_denominators_kernel(double* D1, double* D2, const double* e, 
 }
 
 // ccsd.f90:678-714
-__global__ void so_tau_kernel(double* tau, double* tau_t, const double* t1, const double* t2, int o, int v)
+__global__ void so_tau_kernel(double* tau, double* tau_t, const double* t1, const double* t2, int o, int v, double* t1_w)
 {
     const int64_t n2 = (int64_t)o * o * v * v;
     SO_STRIDE(x, n2)
     {
+        if (x < (int64_t)o * v) t1_w[x] = t1[x];   // the t1 these intermediates belong to (so_build_W_vvvv forms W_abef from it on request)
         const int i = (int)(x % o), j = (int)((x / o) % o), a = (int)((x / ((int64_t)o * o)) % v), b = (int)(x / ((int64_t)o * o * v));
         const double y = t1[i + o * a] * t1[j + o * b] - t1[i + o * b] * t1[j + o * a];
         const double tt = t2[x] + 0.5 * y;
@@ -158,6 +159,56 @@ __global__ void so_g_kernel(double* G, const double* F_oo, const double* Y, int 
     }
 }
 
+// pairs x < y are numbered y(y-1)/2 + x
+__device__ __forceinline__ void unpair_lt(int64_t p, int& lo, int& hi)
+{
+    int64_t h = (int64_t)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);
+    while (h * (h - 1) / 2 > p) --h;
+    while ((h + 1) * h / 2 <= p) ++h;
+    hi = (int)h;
+    lo = (int)(p - h * (h - 1) / 2);
+}
+// va(ef, ab) = <ab||ef>, e < f, a < b, leading dimension ka
+__global__ void so_vvvv_asympack_kernel(double* va, const double* vvvv, int v, int64_t ka)
+{
+    const int64_t V = v, np = V * (V - 1) / 2;
+    SO_STRIDE(x, np * np)
+    {
+        int e, f, a, b;
+        unpair_lt(x % np, e, f);
+        unpair_lt(x / np, a, b);
+        va[x % np + ka * (x / np)] = vvvv[a + V * (b + V * (e + V * f))];
+    }
+}
+// ta(ij, ef) = tau(i,j,e,f), i < j, e < f, leading dimension na
+__global__ void so_tau_asympack_kernel(double* ta, const double* tau, int o, int v, int64_t na)
+{
+    const int64_t O = o, V = v, npo = O * (O - 1) / 2, npv = V * (V - 1) / 2;
+    SO_STRIDE(x, npo * npv)
+    {
+        int i, j, e, f;
+        unpair_lt(x % npo, i, j);
+        unpair_lt(x / npo, e, f);
+        ta[x % npo + na * (x / npo)] = tau[i + O * (j + O * (e + V * f))];
+    }
+}
+// r2(i,j,a,b) = +- pa(ij, ab): + for (i < j, a < b) and (j < i, b < a), - when exactly one pair is exchanged, 0 on the diagonals
+__global__ void so_ladder_expand_kernel(double* r2, const double* pa, int o, int v, int64_t na)
+{
+    const int64_t n2 = (int64_t)o * o * v * v;
+    SO_STRIDE(x, n2)
+    {
+        const int i = (int)(x % o), j = (int)((x / o) % o), a = (int)((x / ((int64_t)o * o)) % v), b = (int)(x / ((int64_t)o * o * v));
+        double val = 0.0;
+        if (i != j && a != b) {
+            const int il = min(i, j), ih = max(i, j), al = min(a, b), ah = max(a, b);
+            const double p = pa[(int64_t)ih * (ih - 1) / 2 + il + na * ((int64_t)ah * (ah - 1) / 2 + al)];
+            val = ((i < j) == (a < b)) ? p : -p;
+        }
+        r2[x] = val;
+    }
+}
+
 #define SO_LAUNCH(kernel, n, ...)                                                         \
     do {                                                                                  \
         if ((n) > 0) {                                                                    \
@@ -199,8 +250,28 @@ void so_init(Context& cx, SOState& s, int nbasis, int nel, const double* eri_mo_
     s.r1 = view(res, {O, V}); s.r2 = view(res + ov, {O, O, V, V});
     s.t2_old = cx.tensor({O, O, V, V});
     s.F_vv = cx.tensor({V, V}); s.F_oo = cx.tensor({O, O}); s.F_ov = cx.tensor({O, V});
-    s.W_oooo = cx.tensor({O, O, O, O}); s.W_vvvv = cx.tensor({V, V, V, V}); s.W_ovvo = cx.tensor({O, V, V, O});
-    s.tau = cx.tensor({O, O, V, V}); s.tau_t = cx.tensor({O, O, V, V});
+    s.W_oooo = cx.tensor({O, O, O, O}); s.W_ovvo = cx.tensor({O, V, V, O});   // (W_vvvv: so_build_W_vvvv, on request only)
+    {
+        // the bare part of 1/2 tau W_abef over antisymmetric pairs (so_ladder)
+        auto even = [](int64_t x) { return (x + 1) & ~(int64_t)1; };
+        const int64_t npv = V * (V - 1) / 2, npo = O * (O - 1) / 2, ka = even(std::max<int64_t>(npv, 1)), na = even(std::max<int64_t>(npo, 1));
+        s.lad_ka = ka; s.lad_na = na;
+        if (npv > 0 && npo > 0) {
+            s.va = cx.alloc(ka * npv); s.ta = cx.alloc(na * ka); s.pa = cx.alloc(na * npv);
+            SO_LAUNCH(so_vvvv_asympack_kernel, npv * npv, s.va, s.vvvv.d, v, ka);
+            // [ k (also n) | ka*m | na*k | na*m ]
+            std::vector<int64_t> tab;
+            const int64_t kn = std::max(ka, na);
+            for (int64_t k = 0; k < kn; ++k) tab.push_back(k);
+            for (int64_t m = 0; m < npv; ++m) tab.push_back(ka * m);
+            for (int64_t k = 0; k < ka; ++k) tab.push_back(na * k);
+            for (int64_t m = 0; m < npv; ++m) tab.push_back(na * m);
+            s.lad_tab = cx.alloc_i64((int64_t)tab.size());
+            AFESP_HIP(hipMemcpyAsync(s.lad_tab, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
+            cx.sync();
+        }
+    }
+    s.tau = cx.tensor({O, O, V, V}); s.tau_t = cx.tensor({O, O, V, V}); s.t1_w = cx.tensor({O, V});
     k_div(cx, s.t2.d, s.oovv.d, s.D2.d, o2v2);   // ccsd.f90:516 (t1 = 0 from the zero-filled allocation, :472)
     diis_alloc(cx, s, diis_nerr);
     s.energy = s.energy_old = s.rms = 0.0;
@@ -213,7 +284,7 @@ void so_free(Context& cx, SOState& s)
     if (!s.o) return;
     double* bufs[] = {s.e, s.oooo.d, s.ooov.d, s.ovoo.d, s.oovo.d, s.oovv.d, s.ovvo.d, s.ovvv.d, s.vovv.d, s.vvvv.d, s.D1.d,
                       s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.F_vv.d, s.F_oo.d, s.F_ov.d, s.W_oooo.d, s.W_vvvv.d, s.W_ovvo.d,
-                      s.tau.d, s.tau_t.d, s.amp_s, s.hist_t, s.hist_e, s.coef, s.bmat};
+                      s.tau.d, s.tau_t.d, s.amp_s, s.hist_t, s.hist_e, s.coef, s.bmat, s.va, s.ta, s.pa, (double*)s.lad_tab, s.t1_w.d};
     for (double* b : bufs) cx.release(b);
     cx.drop_scratch();
     so_triples_plan_free(s);
@@ -229,7 +300,7 @@ void so_intermediates(Context& cx, SOState& s)
     };
     const int o = s.o, v = s.v;
     const int64_t O = o, V = v;
-    SO_LAUNCH(so_tau_kernel, s.t2.size(), s.tau.d, s.tau_t.d, s.t1.d, s.t2.d, o, v);
+    SO_LAUNCH(so_tau_kernel, s.t2.size(), s.tau.d, s.tau_t.d, s.t1.d, s.t2.d, o, v, s.t1_w.d);
     // ---- build_F, ccsd.f90:716-797
     C(1.0, s.ovvv, "mafe", s.t1, "mf", 0.0, s.F_vv, "ae");             // :749-759
     C(0.5, s.tau_t, "mnaf", s.oovv, "mnfe", 1.0, s.F_vv, "ae");        // :783-786 (tmp_4_1(a,m,n,f) = tau~(m,n,a,f))
@@ -247,12 +318,7 @@ void so_intermediates(Context& cx, SOState& s)
     P(1.0, sc, "mnij", 1.0, s.W_oooo, "ijmn");
     P(-1.0, sc, "mnji", 1.0, s.W_oooo, "ijmn");                        // :827-828
     C(0.5, s.oovv, "mnef", s.tau, "ijef", 1.0, s.W_oooo, "ijmn");      // :832-836
-    // Eq. 7, stored W(e,f,a,b) (:852-861)
-    Tensor sv = view(cx.scratch("so_sc_vvvv", V * V * V * V), {V, V, V, V});
-    C(1.0, s.t1, "mb", s.ovvv, "maef", 0.0, sv, "baef");               // :853
-    P(1.0, s.vvvv, "abef", 0.0, s.W_vvvv, "efab");
-    P(1.0, sv, "baef", 1.0, s.W_vvvv, "efab");                         // + reshape_scratch(a,b,e,f) = scratch(b,a,e,f)
-    P(-1.0, sv, "abef", 1.0, s.W_vvvv, "efab");                        // - scratch(a,b,e,f)
+    // Eq. 7, W_abef (:852-861), is not stored: so_amplitudes contracts tau with its three terms one by one (so_ladder)
     // Eq. 8 (:866-902)
     k_copy(cx, s.W_ovvo.d, s.ovvo.d, s.ovvo.size());
     C(1.0, s.ovvv, "mbef", s.t1, "jf", 1.0, s.W_ovvo, "mbej");         // :867
@@ -260,6 +326,52 @@ void so_intermediates(Context& cx, SOState& s)
     Tensor ro = view(cx.scratch("so_ring_operand", O * V * O * V), {O, V, O, V});
     SO_LAUNCH(so_ring_operand_kernel, ro.size(), ro.d, s.t1.d, s.t2.d, o, v);
     C(-1.0, s.oovv, "mnef", ro, "nfjb", 1.0, s.W_ovvo, "mbej");        // :883-901
+}
+
+// W_abef = <ab||ef> - P(ab) t(m,b) <ma||ef> as a tensor W(e,f,a,b) (ccsd.f90:852-861): tests / afesp_ccsd_so_get_tensor only
+void so_build_W_vvvv(Context& cx, SOState& s)
+{
+    const int64_t V = s.v;
+    if (!s.W_vvvv.d) s.W_vvvv = cx.tensor({V, V, V, V});
+    Tensor sv = view(cx.scratch("so_sc_vvvv", V * V * V * V), {V, V, V, V});
+    contract(cx, 1.0, s.t1_w, "mb", s.ovvv, "maef", 0.0, sv, "baef");             // :853 (t1 as of the last so_intermediates)
+    permute_add(cx, 1.0, s.vvvv, "abef", 0.0, s.W_vvvv, "efab");
+    permute_add(cx, 1.0, sv, "baef", 1.0, s.W_vvvv, "efab");                      // + reshape_scratch(a,b,e,f) = scratch(b,a,e,f)
+    permute_add(cx, -1.0, sv, "abef", 1.0, s.W_vvvv, "efab");                     // - scratch(a,b,e,f)
+}
+
+// r2(ijab) = 1/2 sum_ef tau(ijef) W(efab) (ccsd.f90:1021-1024) without forming W_abef -- at the H2O/cc-pVTZ shape (v = 106 spin
+// orbitals) building it was three permuting passes over v^4 = 1 GB plus a v^4 scratch, 2.6 of the 4.3 ms of an iteration, and the
+// product read it once more.  With W(efab) = <ab||ef> + t(m,b) <ma||ef> - t(m,a) <mb||ef>:
+//   bare part   sum_{e<f} tau(ijef) <ab||ef> for i < j, a < b only -- tau and the integrals are antisymmetric in each pair -- one
+//               product over pair indices, an eighth of the o^2 v^4 multiply-adds, against va(ef, ab) built once (so_init);
+//   t1 parts    1/2 sum_m [ t(m,b) Z(ijma) - t(m,a) Z(ijmb) ],  Z(ijma) = sum_ef tau(ijef) <ma||ef>  (o^3 v^3 and two K = o products).
+static void so_ladder(Context& cx, SOState& s)
+{
+    const int o = s.o, v = s.v;
+    const int64_t O = o, V = v, npv = V * (V - 1) / 2, npo = O * (O - 1) / 2, ka = s.lad_ka, na = s.lad_na;
+    if (npv == 0 || npo == 0) {
+        k_fill(cx, s.r2.d, s.r2.size(), 0.0);
+    } else {
+        SO_LAUNCH(so_tau_asympack_kernel, npo * npv, s.ta, s.tau.d, o, v, na);
+        const int64_t* t = s.lad_tab;
+        const int64_t kn = std::max(ka, na);
+        GettProblem gp;
+        gp.alpha = 1.0; gp.beta = 0.0;
+        gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
+        gp.a_kcontig = true; gp.b_kcontig = false;
+        gp.wide = true;
+        gp.A = s.va; gp.B = s.ta; gp.C = s.pa;
+        gp.offAk = t; gp.offBn = gp.offCn = t;
+        gp.offAm = t + kn; gp.offBk = t + kn + npv; gp.offCm = t + kn + npv + ka;
+        gp.M = (int)npv; gp.N = (int)na; gp.K = (int)ka;
+        AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+        SO_LAUNCH(so_ladder_expand_kernel, s.r2.size(), s.r2.d, s.pa, o, v, na);
+    }
+    Tensor Z = view(cx.scratch("so_Z", O * O * O * V), {O, O, O, V});
+    contract(cx, 1.0, s.tau, "ijef", s.ovvv, "maef", 0.0, Z, "ijma");
+    contract(cx, 0.5, Z, "ijma", s.t1, "mb", 1.0, s.r2, "ijab");
+    contract(cx, -0.5, Z, "ijmb", s.t1, "ma", 1.0, s.r2, "ijab");
 }
 
 void so_amplitudes(Context& cx, SOState& s)
@@ -296,8 +408,8 @@ void so_amplitudes(Context& cx, SOState& s)
     C(-1.0, G, "mi", s.t2, "mjab", 0.0, A, "ijab");
     C(1.0, s.t1, "ie", s.vovv, "ejab", 1.0, A, "ijab");
     // 1/2 tau_mnab W_mnij + 1/2 tau_ijef W_abef  (:1021-1024)
-    C(0.5, s.W_oooo, "ijmn", s.tau, "mnab", 0.0, s.r2, "ijab");
-    C(0.5, s.tau, "ijef", s.W_vvvv, "efab", 1.0, s.r2, "ijab");
+    so_ladder(cx, s);
+    C(0.5, s.W_oooo, "ijmn", s.tau, "mnab", 1.0, s.r2, "ijab");
     // :1027-1028 (t1 first: r1 / D_ia)
     k_div(cx, s.t1.d, s.r1.d, s.D1.d, O * V);
     SO_LAUNCH(so_t2_assemble_kernel, o2v2, s.t2.d, s.r2.d, s.oovv.d, AB.d, A.d, Bm.d, s.D2.d, o, v);

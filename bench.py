@@ -567,6 +567,30 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             "e_t": [float(x) for x in acc["last"]], "rccl_ranks": rccl_ranks, "t_allreduce": red.kind,
             "ccsd_split": bool(split), "ccsd_split_check": split_check,
         }
+        nl = eng.ccsd_iteration_launches()
+        if nl and world == 1:
+            # Small systems: the iteration above ran as the compiled sequence of grouped launches (csrc/fused.hip).  Beside it, from the
+            # same state, the call-by-call evaluation on parallel streams ("laned", what a 15-30-iteration solve saw until round 4) and
+            # its graph replay (captured after AFESP_GRAPH_AFTER = 40 iterations)
+            def iter_time(n):
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    eng.ccsd_iterate()
+                    eng.ccsd_diis()
+                return (time.perf_counter() - t0) / n
+            eng.ccsd_set_fused(0)
+            iter_time(5)
+            laned = iter_time(30)
+            iter_time(10)            # (past the 40 calls after which the graph is captured)
+            replayed = iter_time(30)
+            eng.ccsd_set_fused(1)
+            iter_time(3)
+            fused = iter_time(30)
+            eng.ccsd_set_fused(-1)
+            res["ccsd_iter_paths"] = {"launch_fused_s": fused, "launches_per_iteration": nl, "call_by_call_laned_s": laned,
+                                      "call_by_call_graph_replayed_s": replayed,
+                                      "note": "launch_fused = default path of afesp_ccsd_iterate for o^2 v^2 <= 2^20 (one grouped launch per "
+                                              "dependency level, csrc/fused.hip); the other two: afesp_ccsd_set_fused(0)"}
         if per_rank:
             res["per_rank"] = {"ccsd_iter_ms": [round(r[0], 4) for r in per_rank], "t_shard_ms": [round(r[1], 4) for r in per_rank],
                                "allreduce_us_incl_wait_for_slowest_rank": [round(r[2], 1) for r in per_rank],
