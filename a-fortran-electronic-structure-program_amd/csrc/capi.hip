@@ -43,6 +43,7 @@ struct afesp_ctx {
     // the launch-fused path of a small system (fused.h): the recorded and levelled call sequences of the spin-free solver --
     // intermediates alone, amplitudes alone (the term-by-term entry points) and the whole iteration
     FusedSlot fused_int, fused_amp, fused_iter;
+    FusedSlot fused_so;   // ... and the spin-orbital iteration (build_tau / F / W + update_amplitudes)
     void cc_programs_reset()
     {
         graph_cc.reset();
@@ -50,6 +51,7 @@ struct afesp_ctx {
         fused_slot_reset(cx, fused_amp);
         fused_slot_reset(cx, fused_iter);
     }
+    void so_programs_reset() { fused_slot_reset(cx, fused_so); }
     int64_t half_n = 0, half_epoch = -1;   // scratch "ao2mo_a" holds the half-unpacked AO integrals of this basis size / epoch
 };
 
@@ -263,6 +265,7 @@ void afesp_ctx_destroy(afesp_ctx* ctx)
     (void)hipSetDevice(ctx->cx.device);
     if (ctx->cx.startup.joinable()) ctx->cx.startup.join();
     ctx->cc_programs_reset();
+    ctx->so_programs_reset();
     comm_destroy(ctx->cx.comm);
     ctx->cx.comm = nullptr;
     triples_plan_free(ctx->cc);
@@ -1013,6 +1016,7 @@ int afesp_ccsd_so_init(afesp_ctx* ctx, int64_t nbasis, int64_t nel, const double
             throw Error(1, "afesp_ccsd_so_init: no MO integrals resident for this basis size (call afesp_ao2mo_mp2 first)");
         }
         cx.drop_scratch("ao2mo_");   // the AO->MO temporaries
+        ctx->so_programs_reset();
         so_init(cx, ctx->so, (int)nbasis, (int)nel, src, canon_levels, diis_n_errmat, (flags & AFESP_SO_FOO_AS_PUBLISHED) != 0);
         if (tmp) cx.release(tmp);
     });
@@ -1035,9 +1039,14 @@ int afesp_ccsd_so_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* en
     return guarded(ctx, [&] {
         if (!ctx->so.ready) throw Error(1, "afesp_ccsd_so_iterate: call afesp_ccsd_so_init first");
         AFESP_HIP(hipSetDevice(ctx->cx.device));
-        diis_save(ctx->cx, ctx->so);
-        so_intermediates(ctx->cx, ctx->so);
-        so_amplitudes(ctx->cx, ctx->so);
+        // (the levelled sequence of fused.h where the system is small enough for its products to be launch-bound: the big ones
+        // keep their own kernels inside it)
+        auto body = [&] {
+            diis_save(ctx->cx, ctx->so);
+            so_intermediates(ctx->cx, ctx->so);
+            so_amplitudes(ctx->cx, ctx->so);
+        };
+        if (!(ctx->so.t2.size() <= ((int64_t)1 << 22) && fused_exec(ctx->cx, ctx->fused_so, body))) body();
         int conv = so_energy(ctx->cx, ctx->so, e_tol, t_tol);
         if (energy) *energy = ctx->so.energy;
         if (rms_sq) *rms_sq = ctx->so.rms;

@@ -2,6 +2,7 @@
 // Every contraction the reference writes as reshape + dgemm or as a loop nest is one label-driven contract() here;
 // the index letters are the reference's.
 #include "ccsd_so.h"
+#include "fused.h"
 
 #include <cmath>
 
@@ -217,6 +218,22 @@ __global__ void so_ladder_expand_kernel(double* r2, const double* pa, int o, int
         }                                                                                 \
     } while (0)
 
+// ... or, while a call sequence is being recorded for the levelled path (fused.h), noted with the memory it reads and writes
+#define SO_KERNEL(READS, WRITES, kernel, n, ...)                                                                         \
+    do {                                                                                                                 \
+        if (cx.rec) {                                                                                                    \
+            if ((n) > 0)                                                                                                 \
+                cx.rec->opaque(READS, WRITES, [=](Context& c_) {                                                         \
+                    hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(TB), 0, c_.stream, __VA_ARGS__);                \
+                    AFESP_HIP(hipGetLastError());                                                                        \
+                });                                                                                                      \
+        } else {                                                                                                         \
+            SO_LAUNCH(kernel, n, __VA_ARGS__);                                                                           \
+        }                                                                                                                \
+    } while (0)
+#define FR(p, n) frange(p, n)
+typedef std::vector<FusedRange> Ranges;
+
 }  // namespace
 
 void so_init(Context& cx, SOState& s, int nbasis, int nel, const double* eri_mo_dev, const double* e_host, int diis_nerr,
@@ -300,7 +317,8 @@ void so_intermediates(Context& cx, SOState& s)
     };
     const int o = s.o, v = s.v;
     const int64_t O = o, V = v;
-    SO_LAUNCH(so_tau_kernel, s.t2.size(), s.tau.d, s.tau_t.d, s.t1.d, s.t2.d, o, v, s.t1_w.d);
+    SO_KERNEL((Ranges{FR(s.t1.d, O * V), FR(s.t2.d, s.t2.size())}), (Ranges{FR(s.tau.d, s.t2.size()), FR(s.tau_t.d, s.t2.size()), FR(s.t1_w.d, O * V)}),
+              so_tau_kernel, s.t2.size(), s.tau.d, s.tau_t.d, s.t1.d, s.t2.d, o, v, s.t1_w.d);
     // ---- build_F, ccsd.f90:716-797
     C(1.0, s.ovvv, "mafe", s.t1, "mf", 0.0, s.F_vv, "ae");             // :749-759
     C(0.5, s.tau_t, "mnaf", s.oovv, "mnfe", 1.0, s.F_vv, "ae");        // :783-786 (tmp_4_1(a,m,n,f) = tau~(m,n,a,f))
@@ -324,7 +342,8 @@ void so_intermediates(Context& cx, SOState& s)
     C(1.0, s.ovvv, "mbef", s.t1, "jf", 1.0, s.W_ovvo, "mbej");         // :867
     C(1.0, s.t1, "nb", s.oovo, "nmej", 1.0, s.W_ovvo, "mbej");         // :871-877
     Tensor ro = view(cx.scratch("so_ring_operand", O * V * O * V), {O, V, O, V});
-    SO_LAUNCH(so_ring_operand_kernel, ro.size(), ro.d, s.t1.d, s.t2.d, o, v);
+    SO_KERNEL((Ranges{FR(s.t1.d, O * V), FR(s.t2.d, s.t2.size())}), (Ranges{FR(ro.d, ro.size())}), so_ring_operand_kernel, ro.size(), ro.d, s.t1.d,
+              s.t2.d, o, v);
     C(-1.0, s.oovv, "mnef", ro, "nfjb", 1.0, s.W_ovvo, "mbej");        // :883-901
 }
 
@@ -353,7 +372,7 @@ static void so_ladder(Context& cx, SOState& s)
     if (npv == 0 || npo == 0) {
         k_fill(cx, s.r2.d, s.r2.size(), 0.0);
     } else {
-        SO_LAUNCH(so_tau_asympack_kernel, npo * npv, s.ta, s.tau.d, o, v, na);
+        SO_KERNEL((Ranges{FR(s.tau.d, s.tau.size())}), (Ranges{FR(s.ta, na * ka)}), so_tau_asympack_kernel, npo * npv, s.ta, s.tau.d, o, v, na);
         const int64_t* t = s.lad_tab;
         const int64_t kn = std::max(ka, na);
         GettProblem gp;
@@ -365,8 +384,9 @@ static void so_ladder(Context& cx, SOState& s)
         gp.offAk = t; gp.offBn = gp.offCn = t;
         gp.offAm = t + kn; gp.offBk = t + kn + npv; gp.offCm = t + kn + npv + ka;
         gp.M = (int)npv; gp.N = (int)na; gp.K = (int)ka;
-        AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
-        SO_LAUNCH(so_ladder_expand_kernel, s.r2.size(), s.r2.d, s.pa, o, v, na);
+        if (cx.rec) cx.rec->product(gp, ka * npv, na * ka, na * npv);
+        else AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+        SO_KERNEL((Ranges{FR(s.pa, na * npv)}), (Ranges{FR(s.r2.d, s.r2.size())}), so_ladder_expand_kernel, s.r2.size(), s.r2.d, s.pa, o, v, na);
     }
     Tensor Z = view(cx.scratch("so_Z", O * O * O * V), {O, O, O, V});
     contract(cx, 1.0, s.tau, "ijef", s.ovvv, "maef", 0.0, Z, "ijma");
@@ -404,7 +424,7 @@ void so_amplitudes(Context& cx, SOState& s)
     C(-1.0, s.oovo, "ijam", s.t1, "mb", 1.0, Bm, "ijab");
     // -P(ij) [ t_imab (F_mj + 1/2 t_je F_me) ]  (:1004-1007,:1017-1020)  and  P(ij) t_ie <ej||ab>  (:1008-1011)
     C(1.0, s.t1, "je", s.F_ov, "me", 0.0, Y, "jm");
-    SO_LAUNCH(so_g_kernel, O * O, G.d, s.F_oo.d, Y.d, o);
+    SO_KERNEL((Ranges{FR(s.F_oo.d, O * O), FR(Y.d, O * O)}), (Ranges{FR(G.d, O * O)}), so_g_kernel, O * O, G.d, s.F_oo.d, Y.d, o);
     C(-1.0, G, "mi", s.t2, "mjab", 0.0, A, "ijab");
     C(1.0, s.t1, "ie", s.vovv, "ejab", 1.0, A, "ijab");
     // 1/2 tau_mnab W_mnij + 1/2 tau_ijef W_abef  (:1021-1024)
@@ -412,7 +432,8 @@ void so_amplitudes(Context& cx, SOState& s)
     C(0.5, s.W_oooo, "ijmn", s.tau, "mnab", 1.0, s.r2, "ijab");
     // :1027-1028 (t1 first: r1 / D_ia)
     k_div(cx, s.t1.d, s.r1.d, s.D1.d, O * V);
-    SO_LAUNCH(so_t2_assemble_kernel, o2v2, s.t2.d, s.r2.d, s.oovv.d, AB.d, A.d, Bm.d, s.D2.d, o, v);
+    SO_KERNEL((Ranges{FR(s.r2.d, o2v2), FR(s.oovv.d, o2v2), FR(AB.d, o2v2), FR(A.d, o2v2), FR(Bm.d, o2v2), FR(s.D2.d, o2v2)}), (Ranges{FR(s.t2.d, o2v2)}),
+              so_t2_assemble_kernel, o2v2, s.t2.d, s.r2.d, s.oovv.d, AB.d, A.d, Bm.d, s.D2.d, o, v);
 }
 
 int so_energy(Context& cx, SOState& s, double e_tol, double t_tol)

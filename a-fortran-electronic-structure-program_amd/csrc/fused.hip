@@ -242,9 +242,18 @@ void preload_fused()
 void Recorder::product(const GettProblem& g, int64_t a_span, int64_t b_span, int64_t c_span)
 {
     if (g.nbatch != 1 || g.batchA || g.batchB || g.batchC) return fail("batched product");
-    if ((int64_t)g.M * g.N != c_span) return fail("product into a strided view");
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail("empty product");
-    if (a_span >= ((int64_t)1 << 28) || b_span >= ((int64_t)1 << 28) || c_span >= ((int64_t)1 << 28)) return fail("operand beyond 32-bit byte offsets");
+    // A product with real work in it keeps the tiled kernel of its own (gett.h: LDS-staged 16-byte gathers, a launch of tens of
+    // microseconds anyway); it takes its place in the levelled sequence as a kernel launched as it is.
+    static const double big = [] { const char* e = getenv("AFESP_FUSED_BIG_FLOP"); return e ? atof(e) : 4e8; }();
+    if (2.0 * g.M * (double)g.N * g.K >= big || a_span >= ((int64_t)1 << 28) || b_span >= ((int64_t)1 << 28) || c_span >= ((int64_t)1 << 28)) {
+        std::vector<FusedRange> rd = {frange(g.A, a_span), frange(g.B, b_span)};
+        if (g.beta != 0.0) rd.push_back(frange(g.C, c_span));
+        const GettProblem gp = g;
+        opaque(rd, {frange(g.C, c_span)}, [gp](Context& c) { AFESP_HIP(gett_launch(gp, c.ws, c.stream)); });
+        return;
+    }
+    if ((int64_t)g.M * g.N != c_span) return fail("product into a strided view");
     Op o;
     o.kind = PRODUCT;
     o.g = g;
@@ -406,8 +415,8 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
     // (128 of a single-MFMA one), fewer when the stage has little work for the ~2000 waves the device holds.
     int ncu = 256;
     {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, cx.device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cx.device) == hipSuccess && v > 0) ncu = v;
     }
     auto envll = [](const char* name, int64_t dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
     const int64_t target_items = envll("AFESP_FUSED_ITEMS", (int64_t)ncu * 8);

@@ -341,7 +341,14 @@ void preload_kernels()
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(fill_kernel));
     (void)hipGetLastError();
 }
-void k_fill(Context& cx, double* x, int64_t n, double val) { if (n > 0) LAUNCH(fill_kernel, dim3(grid_for(n)), x, n, val); }
+void k_fill(Context& cx, double* x, int64_t n, double val)
+{
+    if (cx.rec) {
+        if (n > 0) cx.rec->opaque({}, {frange(x, n)}, [=](Context& c_) { k_fill(c_, x, n, val); });
+        return;
+    }
+    if (n > 0) LAUNCH(fill_kernel, dim3(grid_for(n)), x, n, val);
+}
 void k_copy(Context& cx, double* dst, const double* src, int64_t n)
 {
     if (cx.rec) {   // launch-fused path (fused.h): one of the copies of an elementwise stage
@@ -360,7 +367,14 @@ void k_axpby(Context& cx, double* y, double a, const double* x, double b, int64_
     }
     if (n > 0) LAUNCH(axpby_kernel, dim3(grid_for(n)), y, a, x, b, n);
 }
-void k_div(Context& cx, double* out, const double* num, const double* den, int64_t n) { if (n > 0) LAUNCH(div_kernel, dim3(grid_for(n)), out, num, den, n); }
+void k_div(Context& cx, double* out, const double* num, const double* den, int64_t n)
+{
+    if (cx.rec) {
+        if (n > 0) cx.rec->opaque({frange(num, n), frange(den, n)}, {frange(out, n)}, [=](Context& c_) { k_div(c_, out, num, den, n); });
+        return;
+    }
+    if (n > 0) LAUNCH(div_kernel, dim3(grid_for(n)), out, num, den, n);
+}
 void k_sub(Context& cx, double* out, const double* a, const double* b, int64_t n) { if (n > 0) LAUNCH(sub_kernel, dim3(grid_for(n)), out, a, b, n); }
 void k_antisym_pair(Context& cx, double* out, const double* in, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int which)
 {

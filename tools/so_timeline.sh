@@ -13,7 +13,7 @@ for f in glob.glob("/tmp/kt_so/*/*kernel_trace.csv"):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last iteration: from the last so_tau_kernel to the kernel before the first (T) launch after it
-idx = max(i for i, r in enumerate(rows) if "so_tau_kernel" in r["Kernel_Name"])
+idx = max(i for i, r in enumerate(rows) if "so_tau_kernel" in r["Kernel_Name"]) - 1
 sel = []
 for r in rows[idx:]:
     if "triples" in r["Kernel_Name"] or "tgemm" in r["Kernel_Name"]: break
