@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "gett.h"
+#include "tgemm.h"
 
 namespace afesp {
 
@@ -82,6 +83,7 @@ struct Context {
     Arena arena;                          // every device allocation of the context goes through it
     std::vector<void*> owned;             // everything freed at destroy
     GettWorkspace ws{nullptr, 0};
+    TgLaunchState tg;                     // ticket counters / grid size of this context's tgemm_kernel launches (tgemm.h)
     bool in_repack = false;               // set while contract() runs on a re-laid-out operand
     // Lanes: extra streams (each with its own split-K workspace) on which independent chains of small launches run side
     // by side.  `stream` / `ws` above always denote the lane in use; lane 0 is the context's main stream.

@@ -436,7 +436,7 @@ void ao2mo_tg_xform(Context& cx, Ao2moTg& t, const double* in, double* out, int6
     t.groups_used += (int64_t)hv.size();
     AFESP_HIP(hipMemcpyAsync(dev, hv.data(), hv.size() * sizeof(TgGroup), hipMemcpyHostToDevice, cx.stream));
     TgProblem p{t.ct, in, out, t.rowA + row0, t.offCm + row0, (int)M, true, (int)((n - (t.Kc - TG_BK) + 3) / 4)};
-    AFESP_HIP(tgemm_launch(p, dev, ng, tile, mx, cx.stream));
+    AFESP_HIP(tgemm_launch(p, dev, ng, tile, mx, cx.stream, cx.tg));
 }
 }  // namespace
 

@@ -298,6 +298,7 @@ Context::~Context()
     arena.destroy();   // every block the context ever obtained: owned, cached scratch and idle ones
     if (scal_host) (void)hipHostFree(scal_host);
     if (res_host) (void)hipHostFree(res_host);
+    tgemm_state_free(tg);
     if (stream) (void)hipStreamDestroy(stream);
 }
 

@@ -46,7 +46,16 @@ constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 16;
 // Every group needs nk >= 2 and 1 <= nk1 <= nk; tables as above.  max_ntiles = the largest ntiles of a group.
 // The kernel fetches a tile's tables in 1-KiB pieces: rowA and every colB must be readable up to 255 entries, offCm and every
 // offCn up to 127 entries beyond their last element (pad the buffers; what is read there is never used).
-hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngroups, int total_tiles, int max_ntiles, hipStream_t stream);
+// What a launcher keeps between launches: the per-XCD ticket counters (64 bytes of device memory) and the number of workgroups
+// the device holds at once.  One per context (Context::tg) -- two contexts that launch at the same time on one device each
+// draw from their own counters; launches of ONE state must be ordered on one stream (the counters are reset in stream order).
+struct TgLaunchState {
+    unsigned* tickets = nullptr;
+    int cap = 0;
+};
+void tgemm_state_free(TgLaunchState& st);
+hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngroups, int total_tiles, int max_ntiles, hipStream_t stream,
+                        TgLaunchState& st);
 void preload_tgemm();
 unsigned tgemm_inverse(int d);
 int tgemm_group_m(int M, int max_ntiles);

@@ -496,10 +496,17 @@ void preload_tgemm()
     (void)hipGetLastError();
 }
 
-hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngroups, int total_tiles, int max_ntiles, hipStream_t stream)
+void tgemm_state_free(TgLaunchState& st)
+{
+    if (st.tickets) (void)hipFree(st.tickets);
+    st.tickets = nullptr;
+}
+
+hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngroups, int total_tiles, int max_ntiles, hipStream_t stream,
+                        TgLaunchState& st)
 {
     if (p.M <= 0 || ngroups <= 0 || total_tiles <= 0) return hipSuccess;
-    static int cap = 0;
+    int& cap = st.cap;
     if (cap == 0) {
         int dev = 0, cus = 256, occ = 2;
         if (hipGetDevice(&dev) == hipSuccess) {
@@ -525,18 +532,14 @@ hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngrou
     a.prio_shift = (int64_t)total_tiles >= (int64_t)2 * grid ? prio_env : 0;
     static const bool dyn_env = !(getenv("AFESP_TG_DYNAMIC") && getenv("AFESP_TG_DYNAMIC")[0] == '0');
     static const bool dyn_force = getenv("AFESP_TG_DYNAMIC") && getenv("AFESP_TG_DYNAMIC")[0] == '2';   // tests: also for small launches
-    static unsigned* tickets[16] = {};
     a.tickets = nullptr;
     a.chunk = (int)(grid / 8);
     a.inv_chunk = tgemm_inverse(a.chunk);
     if (dyn_env && grid % 8 == 0 && ((int64_t)total_tiles >= (int64_t)4 * grid || dyn_force)) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        dev &= 15;
-        if (!tickets[dev] && hipMalloc((void**)&tickets[dev], 64) != hipSuccess) return hipErrorOutOfMemory;
-        const hipError_t me = hipMemsetAsync(tickets[dev], 0, 64, stream);
+        if (!st.tickets && hipMalloc((void**)&st.tickets, 64) != hipSuccess) return hipErrorOutOfMemory;
+        const hipError_t me = hipMemsetAsync(st.tickets, 0, 64, stream);
         if (me != hipSuccess) return me;
-        a.tickets = tickets[dev];
+        a.tickets = st.tickets;
     }
     hipLaunchKernelGGL(tgemm_kernel, dim3(grid), dim3(256), 0, stream, a);
     return hipGetLastError();

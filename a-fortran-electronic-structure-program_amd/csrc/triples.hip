@@ -968,10 +968,10 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             gm.C = Mpool;
             if (p->use_tg) {
                 TgProblem tp{vt.d, tt.d, Xpool, p->tables32, p->tables + p->off_Cm, (int)v2, p->c_pairs, (int)((V + O - (Kc - TG_BK) + 3) / 4)};
-                AFESP_HIP(tgemm_launch(tp, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream));
+                AFESP_HIP(tgemm_launch(tp, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream, cx.tg));
                 if (cr) {
                     TgProblem tm{vt2.d, tt2.d, Mpool, p->tables32, p->tables + p->off_Cm, (int)v2, p->c_pairs, (int)((V + O - (Kc - TG_BK) + 3) / 4)};
-                    AFESP_HIP(tgemm_launch(tm, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream));
+                    AFESP_HIP(tgemm_launch(tm, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream, cx.tg));
                 }
             } else {
             if (ch.ngroups_off > 0) {
@@ -1114,7 +1114,7 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
         const int64_t* tabs = p->tables + ch.tab_off;
         if (p->use_tg) {
             TgProblem tp{vt.d, tt.d, Xpool, p->tables32, p->tables + p->off_Cm, (int)v2, p->c_pairs, (int)((V + O - (Kc - TG_BK) + 3) / 4)};
-            AFESP_HIP(tgemm_launch(tp, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream));
+            AFESP_HIP(tgemm_launch(tp, p->tgdesc + ch.tg_off, ch.tg_ngroups, ch.tg_tiles, ch.tg_max_ntiles, cx.stream, cx.tg));
         } else
         for (const TriplesPlan::Group& g : ch.groups) {
             GettProblem gp;

@@ -156,9 +156,8 @@ int afesp_ccsd_so_t(afesp_ctx* ctx, int64_t t_begin, int64_t t_end, double* e_t)
  *             the RCCL unique id there / it backs the shared segment; removed once every rank has joined.  With
  *             unique_id != NULL (128 bytes from afesp_comm_unique_id on rank 0, distributed by the caller -- bench.py
  *             broadcasts it through torch.distributed) no file is used.
- * After afesp_comm_init with world > 1 the CCSD iteration of this context also splits its large products over the ranks
- * (column panels of the o^3 v^3 ring terms and of the pair-form ladder) and sums the T2 residual with one all-reduce per
- * iteration; every rank must then make the same sequence of afesp_ccsd_* calls. */
+ * A communicator alone does not change how the CCSD iteration is evaluated: splitting it over the ranks is a separate, opt-in
+ * switch (afesp_ccsd_set_split below).  Once that is on, every rank must make the same sequence of afesp_ccsd_* calls. */
 #define AFESP_COMM_RCCL 0
 #define AFESP_COMM_HOST 1
 int afesp_device_count(void);

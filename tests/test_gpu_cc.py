@@ -495,10 +495,14 @@ def test_build_fock_on_device_matches_restatement(eng):
     assert abs(e + ints.e_nuc - molecules.SURVEY_GOLD["h2o-cc-pvdz"]["rhf_total"]) < 1e-6
 
 
+@pytest.mark.parametrize("t_gemm", [None, "gett"])
 @pytest.mark.parametrize("o,v", [(3, 8), (5, 19), (6, 24)])
-def test_plain_triples_equal_the_full_evaluation(eng, o, v):
+def test_plain_triples_equal_the_full_evaluation(eng, o, v, t_gemm, monkeypatch):
     """afesp_ccsd_t_plain (one Z evaluation per element, the symmetriser moved onto W) against afesp_ccsd_t, whole range and
-    shards, and against the oracle."""
+    shards, and against the oracle -- with the products on the LDS-DMA kernel (default) and on the grouped gather kernel
+    (AFESP_T_GEMM=gett: what the planner falls back to when 32-bit byte offsets do not reach every operand row)."""
+    if t_gemm:
+        monkeypatch.setenv("AFESP_T_GEMM", t_gemm)
     n, e, eri = molecules.synthetic_system(o, v, scale=0.04, seed=3 + v)
     eng.ccsd_init(o, v, e, eri, 6)
     cc = orc.OracleCC(o, v, eri, e, 6)
@@ -656,14 +660,17 @@ def test_vvvv_slice_is_formed_on_request_when_the_ladder_runs_in_pair_form(monke
         assert np.max(np.abs(eng.tensor("v_vvvv") - 2.0 * cc.field("v_vvvv"))) < 1e-15
 
 
+@pytest.mark.parametrize("t_gemm", [None, "gett"])
 @pytest.mark.parametrize("o,v,tiny_pool", [(5, 12, False), (7, 10, True), (4, 17, False)])
-def test_coinciding_pair_blocks_in_their_own_launch(o, v, tiny_pool, monkeypatch):
+def test_coinciding_pair_blocks_in_their_own_launch(o, v, tiny_pool, t_gemm, monkeypatch):
     """Blocks Y^{p;qq} are computed as X over half the summation index in a launch of their own and symmetrised by the orbit
     kernel; at small sizes that launch is normally folded into the main one, so force it (AFESP_T_SPLIT_TILES=1) and check
     the plain, the full and the completely renormalised evaluation against the oracle, whole range and shards.  A tiny
     pool gives one chunk per triple (chunks with and without coinciding pairs)."""
     from afesp_amd.capi import Engine
     monkeypatch.setenv("AFESP_T_SPLIT_TILES", "1")
+    if t_gemm:
+        monkeypatch.setenv("AFESP_T_GEMM", t_gemm)   # (the knob above only moves launches of the gather kernel: both kernels here)
     if tiny_pool:
         monkeypatch.setenv("AFESP_T_POOL_GIB", "0")   # occupied blocks of one index: a chunk per triple
     n, e, eri = molecules.synthetic_system(o, v, scale=0.04, seed=31 + v)
@@ -688,6 +695,39 @@ def test_coinciding_pair_blocks_in_their_own_launch(o, v, tiny_pool, monkeypatch
         assert np.max(np.abs(out - ref_cr)) < 1e-10 * max(1.0, np.max(np.abs(ref_cr)))
     finally:
         eng.close()
+
+
+def test_two_live_contexts_launch_the_lds_dma_gemm_side_by_side():
+    """The ticket counters and the grid size of tgemm_kernel's launcher belong to the context (Context::tg; they were process-wide
+    statics keyed by device until round 4): two contexts on one device run their (T) at the same time from two host threads, tickets
+    forced for these small launches (AFESP_TG_DYNAMIC=2, read once per process -> a process of its own), and each reproduces its
+    serial result."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, threading
+        import numpy as np
+        sys.path.insert(0, %r)
+        from afesp_amd.capi import Engine
+        engs = [Engine(0), Engine(0)]
+        refs = []
+        for k, e in enumerate(engs):
+            e.synthetic_init(6 + k, 24 - 3 * k, 0.03, 99 + k, 6)
+            e.do_ccsd_spatial(12, 1e-9, 1e-9)
+            refs.append(e.do_ccsd_t_spatial())
+        bad = []
+        def work(k):
+            for _ in range(12):
+                out = engs[k].do_ccsd_t_spatial()
+                if not np.max(np.abs(out - refs[k])) < 1e-13 * max(1.0, np.max(np.abs(refs[k]))):
+                    bad.append((k, out, refs[k]))
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        [t.start() for t in th]; [t.join() for t in th]
+        for e in engs: e.close()
+        assert not bad, bad
+        print("ok")
+    """) % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "a-fortran-electronic-structure-program_amd")
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AFESP_TG_DYNAMIC="2"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.parametrize("o,v,tiny_pool", [(6, 16, True), (7, 12, False)])

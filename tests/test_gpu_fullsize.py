@@ -63,8 +63,8 @@ def test_triples_shards_add_up_and_match_oracle_on_device_tensors(big):
     assert np.max(np.abs(got - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref)))
 
 
-@pytest.mark.parametrize("pool_gib", ["6", None])
-def test_first_block_of_triples_against_the_blas_backed_restatement(big, monkeypatch, pool_gib):
+@pytest.mark.parametrize("pool_gib,t_gemm", [("6", None), ("6", "gett"), (None, None)])
+def test_first_block_of_triples_against_the_blas_backed_restatement(big, monkeypatch, pool_gib, t_gemm):
     """All sorted triples i <= j <= k over the first s occupied orbitals (the first block triple of the engine's enumeration: coinciding
     pairs, a triple with i = j = k, every multiplicity) = all s^3 ordered triples of the reference's loop over those orbitals,
     evaluated by the dgemm-per-term restatement (oracle/afesp_oracle_blas.c, pinned to the loop form by tests/test_oracle_golden.py)
@@ -75,6 +75,8 @@ def test_first_block_of_triples_against_the_blas_backed_restatement(big, monkeyp
         pytest.skip("numpy's bundled OpenBLAS not found")
     if pool_gib:
         monkeypatch.setenv("AFESP_T_POOL_GIB", pool_gib)
+    if t_gemm:
+        monkeypatch.setenv("AFESP_T_GEMM", t_gemm)   # the fallback kernel of the products (csrc/gett_grouped.hip) at full size
     s = big.t_block_size()
     assert 2 <= s <= (4 if pool_gib else 8)
     nsorted = s * (s + 1) * (s + 2) // 6

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <vector>
 using namespace afesp;
+static TgLaunchState g_tg;   // (one launcher state for this stand-alone program)
 
 static int run_big(int argc, char** argv)
 {
@@ -46,7 +47,7 @@ static int run_big(int argc, char** argv)
     for (int q = 0; q < ng; ++q) flop += 2.0 * M * N * 16.0 * g[q].nk;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0, 0);
-        hipError_t e = tgemm_launch(p, dg, ng, tile, nt, 0);
+        hipError_t e = tgemm_launch(p, dg, ng, tile, nt, 0, g_tg);
         hipEventRecord(e1, 0);
         hipError_t e2 = hipDeviceSynchronize();
         float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
@@ -127,7 +128,7 @@ int main(int argc, char** argv)
     hipMemcpy(dg, g, sizeof(g), hipMemcpyHostToDevice);
     // (offCn[n] = M n: columns are adjacent only when M == 1; pairs are exercised with TG_PAIRS=1, which lays C out column-pair-major)
     TgProblem p{dA, dB, dC, d32, d64, M, pairs, (Kv - (Kc - 16) + 3) / 4};
-    hipError_t e = tgemm_launch(p, dg, 2, tile, mx, 0);
+    hipError_t e = tgemm_launch(p, dg, 2, tile, mx, 0, g_tg);
     hipError_t e2 = hipDeviceSynchronize();
     printf("launch %s sync %s tiles %d gm %d\n", hipGetErrorString(e), hipGetErrorString(e2), tile, gm);
     hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost);
