@@ -260,7 +260,20 @@ def spinorb_h2o_tz(rank, world, local, dist, cdev, torch, backend, jobdir):
     t_t = time.perf_counter() - t0
     red.close()
     eng.close()
-    return {"nocc_spin": nel, "nvirt_spin": 2 * n - nel, "ccsd_iter_s": float(np.median(per_iter)), "t_s": t_t, "e_t": float(et[0]),
+    os_, vs_ = nel, 2 * n - nel
+    npo, npv = os_ * (os_ - 1) // 2, vs_ * (vs_ - 1) // 2
+    t_it = float(np.median(per_iter))
+    # what the iteration executes (csrc/ccsd_so.hip): the W_abef term over antisymmetric pairs, Z(ijma) = tau <ma||ef>, the two (ov)^3
+    # products of W_mbej / T2, the two o^4 v^2 products of W_mnij; beside it the count of the reference's formulation (stored W_abef:
+    # 2 o v^4 to build it, 2 o^2 v^4 to contract it, src/ccsd.f90:849-858, :1021-1024)
+    flop_exec = 2.0 * npo * npv * npv + 2.0 * os_**3 * vs_**3 + 4.0 * (os_ * vs_) ** 3 + 4.0 * os_**4 * vs_**2 + 4.0 * os_**2 * vs_**3
+    flop_ref = 2.0 * os_**2 * vs_**4 + 2.0 * os_ * vs_**4 + 4.0 * (os_ * vs_) ** 3 + 4.0 * os_**4 * vs_**2 + 4.0 * os_**2 * vs_**3
+    return {"nocc_spin": nel, "nvirt_spin": 2 * n - nel, "ccsd_iter_s": t_it, "t_s": t_t, "e_t": float(et[0]),
+            "flop_per_iter_executed": flop_exec, "flop_per_iter_reference_formulation": flop_ref,
+            "fraction_of_mfma_peak": flop_exec / t_it / 1e12 / MFMA_F64_PEAK_TFLOPS,
+            "tflops_reference_equivalent": flop_ref / t_it / 1e12,
+            "dominant_kernels": "gett_kernel: tau(ij,ef) <ab||ef> over antisymmetric pairs (M = K = v(v-1)/2, N = o(o-1)/2; streams 8 [v(v-1)/2]^2 bytes), "
+                                "Z = tau <ma||ef>, the two (ov)^3 ring products -- kernel sequence in profiles/r04_so_timeline.txt",
             "t_allreduce": red.kind, "integrals": "synthetic (the reference tree has no eri.dat for H2O/cc-pVTZ: .MISSING_LARGE_BLOBS)",
             "published_reference_s": PUBLISHED["h2o-cc-pvtz_spinorb"]}
 
@@ -568,7 +581,7 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             "ccsd_split": bool(split), "ccsd_split_check": split_check,
         }
         nl = eng.ccsd_iteration_launches()
-        if nl and world == 1:
+        if nl and world == 1 and with_roofline:
             # Small systems: the iteration above ran as the compiled sequence of grouped launches (csrc/fused.hip).  Beside it, from the
             # same state, the call-by-call evaluation on parallel streams ("laned", what a 15-30-iteration solve saw until round 4) and
             # its graph replay (captured after AFESP_GRAPH_AFTER = 40 iterations)
@@ -651,6 +664,18 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             res["pp_ladder"] = {"ms_per_launch": ms_lad, "tflops_executed": eng.pp_ladder_flop() / (ms_lad * 1e-3) / 1e12,
                                 "tflops_reference_equivalent": 2 * o**2 * v**4 / (ms_lad * 1e-3) / 1e12,
                                 "algorithmic_gbs": 8 * (v**3 * (v + 1) / 2 + 2 * o**2 * v**2) / (ms_lad * 1e-3) / 1e9}
+            if world == 1:
+                # the completely renormalised (T) (src/ccsd.f90:2186-2194, :2338-2551) -- the variant of every bundled reference
+                # output: its intermediates, then the triples with the M3 moments (a second pool of product blocks, the CR orbit kernel)
+                t0 = time.perf_counter()
+                eng.build_cr_intermediates()
+                t_cri = time.perf_counter() - t0
+                eng.do_ccsd_t_spatial_cr(lo, hi)           # (plan, pools)
+                t0 = time.perf_counter()
+                cr = eng.do_ccsd_t_spatial_cr(lo, hi)
+                t_cr = time.perf_counter() - t0
+                res["cr_t"] = {"cr_intermediates_s": t_cri, "cr_t_s": t_cr, "out": [float(x) for x in cr],
+                               "max_abs_diff_of_E[T]_E(T)_to_the_plain_evaluation": float(np.max(np.abs(np.asarray(cr[:2]) - np.asarray(acc["last"][:2]))))}
             res["ao2mo"] = time_ao2mo(eng, o, v, 21 if o * v < 2000 else 5)
         if args.cpu_baseline and with_cpu and world == 1:   # rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(o, v, scale, seed, eng)

@@ -18,6 +18,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_h2o -- python3 $
 python3 $R/tools/summarize_profile.py /tmp/kt_cfg5 > $O/${TAG}_bench_cfg5_kernels.json
 python3 $R/tools/summarize_profile.py /tmp/kt_h2o > $O/${TAG}_bench_h2o_tz_kernels.json
 python3 $R/tools/small_system_gaps.py /tmp/kt_h2o 600 > $O/${TAG}_bench_h2o_tz_gaps.txt
+echo "== timelines: small-system iteration (launch-fused / laned / graph-replayed), spin-orbital iteration, config-5 iteration"; date
+bash $R/tools/small_timeline.sh $O/${TAG}_small_timeline_fused.txt > /dev/null
+AFESP_FUSED=0 AFESP_NO_GRAPH=1 bash $R/tools/small_timeline.sh $O/${TAG}_small_timeline_laned.txt > /dev/null
+AFESP_FUSED=0 bash $R/tools/small_timeline.sh $O/${TAG}_small_timeline_replayed.txt > /dev/null
+bash $R/tools/so_timeline.sh $O/${TAG}_so_timeline.txt
+bash $R/tools/iter_timeline.sh $O/${TAG}_iter_timeline.txt
 echo "== PMC passes (one counter per pass)"; date
 bash $R/tools/refresh_traffic.sh $TAG || exit 1
 bash $R/tools/pmc_ao2mo_fock.sh $TAG || exit 1
