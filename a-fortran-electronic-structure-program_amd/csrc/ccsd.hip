@@ -551,7 +551,7 @@ void ccsd_tail_launch(Context& cx, CCState& s)
             wr.push_back(frange(s.coef, 32));
             wr.push_back(frange(s.bmat, (int64_t)s.nerr * s.nerr));
         }
-        cx.rec->opaque(rd, wr, [launch, st](Context& c) { launch(c, st); });
+        cx.rec->opaque(rd, wr, [launch, st](Context& c) { launch(c, st); }, 2);
         return;
     }
     launch(cx, &s);

@@ -52,6 +52,7 @@ struct Recorder {
         double alpha = 1.0, beta = 0.0;
         // OPAQUE: a kernel of the solver launched as it is (on the context's stream at replay time)
         std::function<void(Context&)> fn;
+        int nlaunch = 1;           // kernels that function launches (afesp_ccsd_iteration_launches)
     };
     std::vector<Op> ops;
     bool failed = false;
@@ -62,7 +63,7 @@ struct Recorder {
     void product(const GettProblem& g, int64_t a_span, int64_t b_span, int64_t c_span);
     void elementwise(double* out, const double* in, int rank, const int64_t* dim, const int64_t* so, const int64_t* si, double alpha,
                      double beta);
-    void opaque(std::vector<FusedRange> reads, std::vector<FusedRange> writes, std::function<void(Context&)> fn);
+    void opaque(std::vector<FusedRange> reads, std::vector<FusedRange> writes, std::function<void(Context&)> fn, int nlaunch = 1);
     void fail(const std::string& w)
     {
         if (!failed) why = w;

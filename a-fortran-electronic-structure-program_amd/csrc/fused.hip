@@ -295,13 +295,14 @@ void Recorder::elementwise(double* out, const double* in, int rank, const int64_
     ops.push_back(std::move(o));
 }
 
-void Recorder::opaque(std::vector<FusedRange> reads, std::vector<FusedRange> writes, std::function<void(Context&)> fn)
+void Recorder::opaque(std::vector<FusedRange> reads, std::vector<FusedRange> writes, std::function<void(Context&)> fn, int nlaunch)
 {
     Op o;
     o.kind = OPAQUE;
     o.reads = std::move(reads);
     o.writes = std::move(writes);
     o.fn = std::move(fn);
+    o.nlaunch = nlaunch;
     ops.push_back(std::move(o));
 }
 
@@ -559,7 +560,7 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
                 if (o.stage != s) continue;
                 if (o.kind == Recorder::OPAQUE) {
                     st.opaque.push_back(o.fn);
-                    ++P->launches;
+                    P->launches += o.nlaunch;
                 } else if (o.kind == Recorder::ELEMENTWISE) {
                     EwOp e{};
                     e.out = o.out; e.in = o.in;

@@ -802,7 +802,7 @@ void k_cc_energy(Context& cx, double* out2, const double* v_oovv, const double* 
         const int64_t n2 = (int64_t)o * o * v * v;
         cx.rec->opaque({frange(v_oovv, n2), frange(t1, (int64_t)o * v), frange(t2, n2), frange(t2_old, n2)},
                        {frange(t2_old, n2), frange(out2, 2), frange(partials(cx), 2 * RED_BLOCKS)},
-                       [=](Context& c_) { k_cc_energy(c_, out2, v_oovv, t1, t2, t2_old, o, v); });
+                       [=](Context& c_) { k_cc_energy(c_, out2, v_oovv, t1, t2, t2_old, o, v); }, 2);
         return;
     }
     LAUNCH(cc_energy_kernel, dim3(RED_BLOCKS), partials(cx), v_oovv, t1, t2, t2_old, o, v);
