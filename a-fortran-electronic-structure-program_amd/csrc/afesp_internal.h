@@ -119,6 +119,7 @@ struct Context {
     double* res_host = nullptr;
     double* res_dev = nullptr;
     int64_t res_seq = 0;
+    int64_t pub_seq = 0;                  // sequence number of host_scalars' publishing area (res_host + 264)
     std::map<std::string, Plan> plans;
     size_t plan_bytes = 0;                // device bytes of their offset tables
     // plan tables come out of slabs (a small system builds ~45 plans in its first iteration: one device allocation each was

@@ -228,8 +228,8 @@ int afesp_ctx_create(int device, afesp_ctx** out)
         AFESP_HIP(hipStreamCreate(&c->cx.stream));
         c->cx.scal = c->cx.alloc(64 + 18 * 512);
         AFESP_HIP(hipHostMalloc((void**)&c->cx.scal_host, sizeof(double) * 64, hipHostMallocDefault));
-        AFESP_HIP(hipHostMalloc((void**)&c->cx.res_host, sizeof(double) * (8 + 256), hipHostMallocCoherent | hipHostMallocMapped));
-        memset(c->cx.res_host, 0, sizeof(double) * (8 + 256));
+        AFESP_HIP(hipHostMalloc((void**)&c->cx.res_host, sizeof(double) * (8 + 256 + 72), hipHostMallocCoherent | hipHostMallocMapped));
+        memset(c->cx.res_host, 0, sizeof(double) * (8 + 256 + 72));
         AFESP_HIP(hipHostGetDevicePointer((void**)&c->cx.res_dev, c->cx.res_host, 0));
         c->cx.ws.bytes = (size_t)256 << 20;   // split-K slabs
         c->cx.ws.ptr = c->cx.alloc((int64_t)(c->cx.ws.bytes / sizeof(double)));

@@ -676,6 +676,13 @@ __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p
     double acc[18];
 #pragma unroll
     for (int j = 0; j < 18; ++j) acc[j] = 0.0;
+    // every load of an element is issued before anything is computed from one: the history rows (clamped past ny; a harmless
+    // address when there is no DIIS) and the t1 part (clamped past o v) do not wait for the division of the t2 part -- a load
+    // behind a branch or behind a use costs a memory round trip of its own
+    const double* hist = ny ? p.hist_e : p.voovv;
+    const double* amps = ny ? p.amp_s : p.voovv;
+    const int nyc = ny ? ny - 1 : 0;
+    const int64_t hstride = ny ? p.stride : 0, hbase = ny ? n1 : 0;
     GRID_STRIDE(x, n)
     {
         const int i = (int)(x % o);
@@ -686,38 +693,40 @@ __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p
         const int64_t y = j + (int64_t)o * (i + (int64_t)o * (b + (int64_t)v * a));
         const int64_t lad = (a <= b) ? i + (int64_t)o * (j + (int64_t)o * ((int64_t)b * (b + 1) / 2 + a))
                                      : j + (int64_t)o * (i + (int64_t)o * ((int64_t)a * (a + 1) / 2 + b));
-        const double t = (p.r2[x] + p.r2[y] + p.pp[lad] + p.voovv[x]) / p.D2[x];
-        const double tia = p.r1[i + o * a] / p.D1[i + o * a], tjb = p.r1[j + o * b] / p.D1[j + o * b];
+        const int64_t x1 = x < n1 ? x : n1 - 1;
+        const double r2x = p.r2[x], r2y = p.r2[y], ppv = p.pp[lad], vx0 = p.voovv[x], d2 = p.D2[x];
+        const double ria = p.r1[i + o * a], dia = p.D1[i + o * a], rjb = p.r1[j + o * b], djb = p.D1[j + o * b];
         const double vx = p.voovv[i + (int64_t)o * (j + (int64_t)o * (b + (int64_t)v * a))];
-        acc[16] += (2.0 * p.voovv[x] - vx) * (t + tia * tjb);
-        const double d = t - p.t2_old[x];
+        const double told = p.t2_old[x], as2 = amps[hbase + x], r1x = p.r1[x1], d1x = p.D1[x1], as1 = amps[x1];
+        double h[16], h1[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            h[q] = hist[(int64_t)min(q, nyc) * hstride + hbase + x];
+            h1[q] = hist[(int64_t)min(q, nyc) * hstride + x1];
+        }
+        const double t = (r2x + r2y + ppv + vx0) / d2;
+        const double tia = ria / dia, tjb = rjb / djb;
+        acc[16] += (2.0 * vx0 - vx) * (t + tia * tjb);
+        const double d = t - told;
         acc[17] += d * d;
         p.t2_old[x] = t;
         p.t2[x] = t;
         if (ny) {
-            // (the history rows are read unconditionally, rows past ny clamped: a load under a branch per row makes hipcc wait
-            // for each one in turn -- sixteen memory round trips instead of one)
-            double h[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) h[q] = p.hist_e[(int64_t)min(q, ny - 1) * p.stride + n1 + x];
-            const double e = t - p.amp_s[n1 + x];
+            const double e = t - as2;
             p.ht[n1 + x] = t;
             p.he[n1 + x] = e;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] += q < ny ? e * (q == slot ? e : h[q]) : 0.0;
         }
         if (x < n1) {
-            const double t1v = p.r1[x] / p.D1[x];
+            const double t1v = r1x / d1x;
             p.t1[x] = t1v;
             if (ny) {
-                double h[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) h[q] = p.hist_e[(int64_t)min(q, ny - 1) * p.stride + x];
-                const double e = t1v - p.amp_s[x];
+                const double e = t1v - as1;
                 p.ht[x] = t1v;
                 p.he[x] = e;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] += q < ny ? e * (q == slot ? e : h[q]) : 0.0;
+                for (int q = 0; q < 16; ++q) acc[q] += q < ny ? e * (q == slot ? e : h1[q]) : 0.0;
             }
         }
     }
