@@ -78,6 +78,7 @@ struct Context {
     int cc_split_mode = -1;               // afesp_ccsd_set_split: 1 split the CCSD iteration over the ranks, 0 replicas, -1 environment (default off)
     int test_throw = 0;                   // test hook (afesp_test_inject): the next laned amplitude update throws
     int fused_mode = -1;                  // afesp_ccsd_set_fused: 1 launch-fused small-system path on, 0 off, -1 environment (default on)
+    std::vector<std::vector<int64_t>> pending_host;   // host images of plan tables whose uploads are still in flight (recording only)
     Recorder* rec = nullptr;              // set while a call sequence is being recorded for the launch-fused path (fused.h): nothing is launched
     hipStream_t stream = nullptr;
     Arena arena;                          // every device allocation of the context goes through it
@@ -227,6 +228,8 @@ void diis_check_flag(Context& cx, const double* host_scal);   // throws the refe
 // pair-symmetric AO->MO: u(i,j,KL) from the packed array; out(k,l,PQ) = in(q,p,tri(k,l)); packed[tri(PQ,RS)] = full(s,r,PQ)
 void k_unpack_half(Context& cx, double* u, const double* packed, int n, int64_t c_begin = 0, int64_t c_end = -1);   // slab of (kl) pairs
 void k_pair_transpose(Context& cx, double* out, const double* in, int n);
+// out(:,:,S) = C in(:,:,S) C^T for npairs symmetric n x n blocks, n <= 64: both quarter transforms of a pair index in one launch
+void k_pair_xform(Context& cx, double* out, const double* in, const double* C, int n, int64_t npairs);
 void k_pair_square_packed(Context& cx, double* out, const double* g, int n, int64_t c_begin, int64_t c_end);   // out(k,l,P) = g(P, tri(k,l))
 void k_tri_pack(Context& cx, double* g, const double* half, int n, int64_t k_begin, int64_t k_end);           // g(PQ,K) = half(q,p,K)
 void k_pack_pairs(Context& cx, double* packed, const double* full, int n, int64_t p_begin = 0, int64_t p_end = -1);

@@ -241,7 +241,27 @@ int afesp_ctx_create(int device, afesp_ctx** out)
         if (!(np && np[0] == '1'))
             c->cx.startup = std::thread([device, c] {
                 if (hipSetDevice(device) != hipSuccess) return;
-                Context::prepare_lanes(c->cx.prepared, 6);   // (the context itself is not touched: fork() adopts them)
+                // (the parallel streams of the call-by-call iteration: small systems run the launch-fused iteration on ONE stream since
+                // round 4, so the 10-25 ms of queue creation are only spent ahead of time on request; fork() makes them when needed)
+                const char* pl = getenv("AFESP_PRELOAD_LANES");
+                if (pl && pl[0] == '1') Context::prepare_lanes(c->cx.prepared, 6);   // (the context itself is not touched: fork() adopts them)
+                {
+                    // the runtime's own first-use set-up (staging buffers of pageable copies, its fill / copy kernels): ~8 ms that
+                    // the first plan upload of a process would otherwise pay inside the first CCSD iteration
+                    void* d = nullptr;
+                    hipStream_t st = nullptr;
+                    std::vector<double> h(4096, 1.0);
+                    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(&d, h.size() * sizeof(double)) == hipSuccess) {
+                        (void)hipMemsetAsync(d, 0, h.size() * sizeof(double), st);
+                        (void)hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, st);
+                        (void)hipMemcpyAsync((char*)d + 8192, d, 8192, hipMemcpyDeviceToDevice, st);
+                        (void)hipMemcpyAsync(h.data(), d, h.size() * sizeof(double), hipMemcpyDeviceToHost, st);
+                        (void)hipStreamSynchronize(st);
+                    }
+                    if (d) (void)hipFree(d);
+                    if (st) (void)hipStreamDestroy(st);
+                    (void)hipGetLastError();
+                }
                 preload_kernels();
                 preload_contract();
                 preload_gett();
@@ -513,6 +533,14 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
                 ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, ps, np, n, 1);
                 k_pack_pairs(cx, packed, Tb.d, (int)n);                  // mp2.f90:388-410
                 cx.sync();                                               // (the descriptors' host copies die with tg)
+            } else if (n <= 64 && !(getenv("AFESP_AO2MO_PAIR") && getenv("AFESP_AO2MO_PAIR")[0] == '0')) {
+                // up to 64 basis functions (every bundled input, the H2O/cc-pVTZ shape): both quarter transforms of a pair index in one
+                // kernel with the n x n block resident in LDS -- five launches for the whole transform (AFESP_AO2MO_PAIR=0: the
+                // gather-GEMM form below)
+                k_pair_xform(cx, Tb.d, Ta.d, Cm.d, (int)n, np);              // (ij|K) -> (pq|K)         mp2.f90:321-348
+                k_pair_transpose(cx, Ta.d, Tb.d, (int)n);                    // (kl|PQ), kl squared up, p >= q
+                k_pair_xform(cx, Tb.d, Ta.d, Cm.d, (int)n, np);              // (kl|P) -> (rs|P)         mp2.f90:357-385
+                k_pack_pairs(cx, packed, Tb.d, (int)n);                      // mp2.f90:388-410
             } else {
                 contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
                 contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348

@@ -626,7 +626,8 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
                     AFESP_HIP(hipMemcpyAsync(base + runs[r].second, small.data() + runs[r].first, len * sizeof(int64_t), hipMemcpyHostToDevice,
                                              cx.stream));
             }
-            AFESP_HIP(hipStreamSynchronize(cx.stream));   // `small` is a temporary
+            if (cx.rec && !verify) cx.pending_host.push_back(std::move(small));   // recording: ONE wait for all the uploads (fused_compile)
+            else AFESP_HIP(hipStreamSynchronize(cx.stream));                      // `small` is a temporary
             if (verify) {
                 auto pairs = [](const std::vector<int64_t>& t) {
                     if (t.size() % 2) return false;

@@ -16,6 +16,7 @@
 // Products that accumulate into one result in the same stage share its slabs: one pass sums them all.  The compiled program
 // (descriptor tables in device memory) is replayed every iteration; nothing is decided on the host between launches.
 #pragma once
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -97,16 +98,24 @@ inline bool fused_exec(Context& cx, FusedSlot& slot, Body body)
     if (slot.disabled || !fused_enabled(cx)) return false;
     if (slot.prog && fused_epoch(slot.prog) != -2 && fused_epoch(slot.prog) != cx.scratch_epoch) fused_slot_reset(cx, slot);
     if (!slot.prog) {
+        const bool dbg = getenv("AFESP_FUSED_DEBUG") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         Recorder rec;
         cx.rec = &rec;
         try {
             body();
         } catch (...) {
             cx.rec = nullptr;
+            (void)hipStreamSynchronize(cx.stream);
+            cx.pending_host.clear();
             throw;
         }
         cx.rec = nullptr;
+        const auto t1 = std::chrono::steady_clock::now();
         slot.prog = fused_compile(cx, rec);
+        if (dbg)
+            fprintf(stderr, "afesp fused: recorded in %.2f ms, compiled in %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
         if (!slot.prog) {
             slot.disabled = true;
             slot.why = rec.why;

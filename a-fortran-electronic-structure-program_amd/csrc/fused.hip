@@ -357,6 +357,10 @@ bool fused_enabled(const Context& cx)
 
 FusedProgram* fused_compile(Context& cx, Recorder& r)
 {
+    if (!cx.pending_host.empty()) {   // the plan tables built while recording: their uploads share this one wait
+        AFESP_HIP(hipStreamSynchronize(cx.stream));
+        cx.pending_host.clear();
+    }
     if (r.failed) return nullptr;
     auto& ops = r.ops;
     const bool debug = getenv("AFESP_FUSED_DEBUG") != nullptr;

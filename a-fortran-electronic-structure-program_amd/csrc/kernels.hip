@@ -943,6 +943,111 @@ void k_unpack_half(Context& cx, double* u, const double* packed, int n, int64_t 
     if (c_end < 0) c_end = np;
     if (c_end > c_begin) LAUNCH(pair_square_kernel<0>, dim3(pair_square_grid(n, c_begin, c_end)), u, packed, n, c_begin, c_end);
 }
+// ---- both quarter transforms of a pair index in ONE kernel, for bases of up to 64 functions (mp2.f90:321-348 resp. :357-385):
+//   out(:, :, S) = C in(:, :, S) C^T   for every pair S, in(:, :, S) symmetric
+// A workgroup owns one S: the n x n block goes to LDS once (zero-padded to 64 x 64), T1 = C U is formed by the four waves
+// (32 x 32 quadrants, 2 x 2 accumulators of v_mfma_f64_16x16x4_f64), written back over U in the layout the second product reads
+// its A fragments in, and T2 = T1 C^T leaves through its transpose -- T2 is symmetric -- so that the lanes of a store run along the
+// fastest index.  The coefficient fragments come straight from memory (C is 27 KB at n = 58: L1 / L2 resident), all of them
+// requested before the first product starts.  No intermediate touches HBM: the two gather-GEMM launches per pair, their K-slice
+// reductions and 2 x 8 n^2 npair bytes of traffic become one launch.
+constexpr int PX = 64, PXS = 66;   // padded extent, LDS row stride
+__global__ __launch_bounds__(256, 2) void pair_xform_kernel(double* __restrict__ out, const double* __restrict__ in, const double* __restrict__ C,
+                                                            int n)
+{
+    typedef double v4d_t __attribute__((ext_vector_type(4)));
+    __shared__ double S[PX * PXS];
+    const int64_t nn = (int64_t)n * n;
+    const double* __restrict__ u = in + nn * blockIdx.x;
+    double* __restrict__ o = out + nn * blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1, lm = lane & 15, lk = lane >> 4;
+    // coefficient fragments: as A operand of the first product (row p, k = i) and as B operand of the second (column q, k = j)
+    double ca[16][2], cb[16][2];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int k = min(4 * s + lk, n - 1);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            ca[s][f] = C[min(32 * wm + 16 * f + lm, n - 1) + (int64_t)n * k];
+            cb[s][f] = C[min(32 * wn + 16 * f + lm, n - 1) + (int64_t)n * k];
+        }
+    }
+    // U into LDS, zero-padded; (a, b) and (b, a) are the same number, so the lanes run along the fastest index on both sides
+    // (clamped addresses, the padding zeroed afterwards: a load under a condition would be waited for on its own, sixteen round
+    // trips instead of one)
+    double ur[PX * PX / 256];
+#pragma unroll
+    for (int r = 0; r < PX * PX / 256; ++r) {
+        const int e = t + 256 * r, a = e & 63, b = e >> 6;
+        ur[r] = u[min(a, n - 1) + (int64_t)n * min(b, n - 1)];
+    }
+#pragma unroll
+    for (int r = 0; r < PX * PX / 256; ++r) {
+        const int e = t + 256 * r, a = e & 63, b = e >> 6;
+        S[b * PXS + a] = (a < n && b < n) ? ur[r] : 0.0;
+    }
+    __syncthreads();
+    v4d_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d_t){0.0, 0.0, 0.0, 0.0};
+    // T1(p, j) = sum_i C(p, i) U(i, j)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        double bf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = S[(4 * s + lk) * PXS + 32 * wn + 16 * j + lm];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[s][i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();   // every wave has read U
+    // T1 over U, k-major for the second product's A fragments: S[j][p]  (C/D layout: column = lane & 15, row = (lane >> 4) + 4 r)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(32 * wn + 16 * j + lm) * PXS + 32 * wm + 16 * i + lk + 4 * r] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4d_t){0.0, 0.0, 0.0, 0.0};
+    // T2(p, q) = sum_j T1(p, j) C(q, j); the k >= n rows of T1 are zero (U's padding), so the clamped coefficient rows do no harm
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        double af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = S[(4 * s + lk) * PXS + 32 * wm + 16 * i + lm];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], cb[s][j], acc[i][j], 0, 0, 0);
+    }
+    // out(q, p) = T2(p, q) = T2(q, p): the lanes of a store run along q
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = 32 * wm + 16 * i + lk + 4 * r;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = 32 * wn + 16 * j + lm;
+                if (p < n && q < n) o[q + (int64_t)n * p] = acc[i][j][r];
+            }
+        }
+}
+void k_pair_xform(Context& cx, double* out, const double* in, const double* C, int n, int64_t npairs)
+{
+    if (n > PX) throw Error(3, "k_pair_xform: more than 64 basis functions");
+    if (npairs > 0) {
+        hipLaunchKernelGGL(pair_xform_kernel, dim3((unsigned)npairs), dim3(256), 0, cx.stream, out, in, C, n);
+        AFESP_HIP(hipGetLastError());
+    }
+}
 void k_pair_transpose(Context& cx, double* out, const double* in, int n)
 {
     const int64_t np = (int64_t)n * (n + 1) / 2;

@@ -1,0 +1,26 @@
+#!/bin/bash
+# ao2mo_small_timeline.sh [n o] -- kernel sequence (start, duration) of one AO->MO + MP2 call on a small basis (default n = 58, o = 5)
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+export TMPDIR=/tmp; cd /tmp && rm -rf /tmp/kt_ao
+cat > /tmp/ao_run.py <<PY
+import sys
+sys.path.insert(0, "$HERE/a-fortran-electronic-structure-program_amd"); sys.path.insert(0, "$HERE")
+import bench
+from afesp_amd.capi import Engine
+n, o = int("${1:-58}"), int("${2:-5}")
+with Engine(0) as eng:
+    print(bench.time_ao2mo(eng, o, n - o, 5))
+PY
+rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_ao -- python3 /tmp/ao_run.py > /tmp/kt_ao.log 2>&1; tail -1 /tmp/kt_ao.log
+python3 - <<'PY'
+import csv, glob
+rows = []
+for f in glob.glob("/tmp/kt_ao/*/*kernel_trace.csv"):
+    rows += list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+sel = rows[-14:]
+t0 = int(sel[0]["Start_Timestamp"])
+for r in sel:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    print("%8.1f us +%6.1f us  %s" % ((s - t0) / 1e3, (e - s) / 1e3, r["Kernel_Name"][:90]))
+PY
