@@ -91,9 +91,9 @@ __device__ __forceinline__ void fused_tile(const FItem& it, const int lane)
             const uint32_t ka = ko[buf][u >> 1][2 * (u & 1)], kb = ko[buf][u >> 1][2 * (u & 1) + 1];
 #if defined(AFESP_FUSED_DIAG) && (AFESP_FUSED_DIAG & 2)   // diagnostic build: no operand loads
 #pragma unroll
-            for (int i = 0; i < TMF; ++i) a[buf][u][i] = (double)(ka + aoff[i]);
+            for (int i = 0; i < TMF; ++i) a[buf][u][i] = 1e-300 * (double)(ka + aoff[i]);   // (tiny: the iteration stays finite)
 #pragma unroll
-            for (int jj = 0; jj < TNF; ++jj) b[buf][u][jj] = (double)(kb + boff[jj]);
+            for (int jj = 0; jj < TNF; ++jj) b[buf][u][jj] = 1e-300 * (double)(kb + boff[jj]);
 #else
 #pragma unroll
             for (int i = 0; i < TMF; ++i) a[buf][u][i] = *(const double __attribute__((address_space(1)))*)(A + (aoff[i] + ka));

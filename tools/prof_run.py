@@ -7,13 +7,13 @@ from afesp_amd.capi import Engine
 ap = argparse.ArgumentParser()
 ap.add_argument("--o", type=int, default=20); ap.add_argument("--v", type=int, default=200)
 ap.add_argument("--iters", type=int, default=2); ap.add_argument("--triples", type=int, default=32)
-ap.add_argument("--ladder", type=int, default=0); ap.add_argument("--scale", type=float, default=0.005)
+ap.add_argument("--no-diis", action="store_true"); ap.add_argument("--ladder", type=int, default=0); ap.add_argument("--scale", type=float, default=0.005)
 a = ap.parse_args()
 eng = Engine(0)
 eng.synthetic_init(a.o, a.v, a.scale, 12345, 8)
 print("MP1", eng.ccsd_energy())
 for it in range(a.iters):
-    t0 = time.perf_counter(); r = eng.ccsd_iterate(); eng.ccsd_diis(); print("iter", it, r, time.perf_counter() - t0)
+    t0 = time.perf_counter(); r = eng.ccsd_iterate(); (None if a.no_diis else eng.ccsd_diis()); print("iter", it, r, time.perf_counter() - t0)
 if a.ladder:
     print("pp-ladder ms", eng.time_pp_ladder(a.ladder))
 if a.triples:
