@@ -94,6 +94,7 @@ struct Context {
         hipEvent_t done = nullptr;
     };
     std::vector<Lane> lanes;
+    size_t lane_ws_bytes = (size_t)8 << 20;   // split-K workspace of a lane (lanes made so far are re-equipped when this grows)
     // Lanes made ahead of time on the context's start-up thread (afesp_ctx_create): five streams are five hardware queues,
     // 10-25 ms that a small molecule would otherwise pay inside its first iteration.  fork() adopts them.
     struct Prepared {

@@ -210,11 +210,18 @@ void Context::fork(int nlanes)
         prepared.lanes.clear();
         prepared.ws_block = nullptr;
     }
+    for (size_t i = 1; i < lanes.size(); ++i)
+        if (lanes[i].ws.bytes < lane_ws_bytes) {   // (the old workspace stays with the context: a lane may still be reading it)
+            void* p = arena.get(lane_ws_bytes);
+            owned.push_back(p);
+            lanes[i].ws.ptr = (double*)p;
+            lanes[i].ws.bytes = lane_ws_bytes;
+        }
     while ((int)lanes.size() < nlanes) {
         Lane l;
         AFESP_HIP(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         AFESP_HIP(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
-        l.ws.bytes = (size_t)8 << 20;   // lanes only carry small problems
+        l.ws.bytes = lane_ws_bytes;   // (8 MiB unless a caller asked for more: lanes mostly carry small problems)
         void* p = arena.get(l.ws.bytes);
         owned.push_back(p);
         l.ws.ptr = (double*)p;

@@ -54,6 +54,7 @@ struct Recorder {
         // OPAQUE: a kernel of the solver launched as it is (on the context's stream at replay time)
         std::function<void(Context&)> fn;
         int nlaunch = 1;           // kernels that function launches (afesp_ccsd_iteration_launches)
+        bool heavy = false;        // a product with a tiled launch of its own: the heavy ones of a stage run side by side on the context's lanes
     };
     std::vector<Op> ops;
     bool failed = false;

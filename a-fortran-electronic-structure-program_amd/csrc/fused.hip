@@ -250,7 +250,8 @@ void Recorder::product(const GettProblem& g, int64_t a_span, int64_t b_span, int
         std::vector<FusedRange> rd = {frange(g.A, a_span), frange(g.B, b_span)};
         if (g.beta != 0.0) rd.push_back(frange(g.C, c_span));
         const GettProblem gp = g;
-        opaque(rd, {frange(g.C, c_span)}, [gp](Context& c) { AFESP_HIP(gett_launch(gp, c.ws, c.stream)); });
+        opaque(rd, {frange(g.C, c_span)}, [gp](Context& c) { AFESP_HIP(gett_launch(gp, c.ws, c.stream)); }, 2);
+        ops.back().heavy = true;
         return;
     }
     if ((int64_t)g.M * g.N != c_span) return fail("product into a strided view");
@@ -316,6 +317,7 @@ struct FusedProgram {
         const EwBlk* blks = nullptr;
         int nblk = 0;
         std::vector<std::function<void(Context&)>> opaque;
+        std::vector<std::function<void(Context&)>> heavy;   // opaque products with a tiled launch of their own (independent inside the stage)
         std::vector<std::pair<int, int>> per_op;   // diagnostic (AFESP_FUSED_PER_OP=1): (first item, count) of each product, launched alone
     };
     std::vector<Stage> stages;
@@ -563,7 +565,7 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
                 const Recorder::Op& o = ops[x];
                 if (o.stage != s) continue;
                 if (o.kind == Recorder::OPAQUE) {
-                    st.opaque.push_back(o.fn);
+                    (o.heavy ? st.heavy : st.opaque).push_back(o.fn);
                     P->launches += o.nlaunch;
                 } else if (o.kind == Recorder::ELEMENTWISE) {
                     EwOp e{};
@@ -616,7 +618,8 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
                     fprintf(stderr, "      M %6d N %6d K %6d  tile %d  slices %2d  alpha %+.2f beta %.0f -> %p\n", ops[x].g.M, ops[x].g.N, ops[x].g.K,
                             tilecode[x], slices[x], ops[x].g.alpha, ops[x].g.beta, (void*)ops[x].g.C);
             } else {
-                fprintf(stderr, "  stage %d: %d elementwise blocks, %zu opaque kernels\n", s, st.nblk, st.opaque.size());
+                fprintf(stderr, "  stage %d: %d elementwise blocks, %zu opaque kernels, %zu products on their own tiled launch\n", s, st.nblk, st.opaque.size(),
+                        st.heavy.size());
             }
         }
     }
@@ -643,6 +646,22 @@ void fused_run(Context& cx, const FusedProgram* P)
                 AFESP_HIP(hipGetLastError());
             }
             for (auto& fn : st.opaque) fn(cx);
+            // The products that keep a tiled launch of their own are independent inside a stage, and at the sizes where they occur
+            // (o ~ 10, v ~ 100) none of them fills the device: they run side by side on the context's lanes (each lane with a
+            // split-K workspace of its own), the main stream waits for all of them.  AFESP_FUSED_LANES=0: one after the other.
+            static const bool lanes_on = !(getenv("AFESP_FUSED_LANES") && getenv("AFESP_FUSED_LANES")[0] == '0');
+            if (st.heavy.size() >= 2 && lanes_on) {
+                const int nl = (int)std::min<size_t>(st.heavy.size(), 4);
+                cx.lane_ws_bytes = std::max(cx.lane_ws_bytes, (size_t)64 << 20);
+                cx.fork(nl);
+                for (size_t i = 0; i < st.heavy.size(); ++i) {
+                    cx.use_lane((int)(i % (size_t)nl));
+                    st.heavy[i](cx);
+                }
+                cx.join();
+            } else {
+                for (auto& fn : st.heavy) fn(cx);
+            }
         }
     }
 }

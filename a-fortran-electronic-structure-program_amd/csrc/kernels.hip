@@ -668,6 +668,8 @@ struct TailArgs {
     int64_t stride;
     int ny, slot;
 };
+// NYT = the history rows a thread reads per element (ny rounded up to 0 / 4 / 8 / 16): rows past ny are clamped duplicates
+template <int NYT>
 __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p)
 {
     __shared__ double sm[18 * 4];
@@ -676,13 +678,9 @@ __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p
     double acc[18];
 #pragma unroll
     for (int j = 0; j < 18; ++j) acc[j] = 0.0;
-    // every load of an element is issued before anything is computed from one: the history rows (clamped past ny; a harmless
-    // address when there is no DIIS) and the t1 part (clamped past o v) do not wait for the division of the t2 part -- a load
-    // behind a branch or behind a use costs a memory round trip of its own
-    const double* hist = ny ? p.hist_e : p.voovv;
-    const double* amps = ny ? p.amp_s : p.voovv;
     const int nyc = ny ? ny - 1 : 0;
-    const int64_t hstride = ny ? p.stride : 0, hbase = ny ? n1 : 0;
+    // t2 part.  Every load of an element is issued before anything is computed from one (a load behind a use costs a memory
+    // round trip of its own).
     GRID_STRIDE(x, n)
     {
         const int i = (int)(x % o);
@@ -693,16 +691,15 @@ __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p
         const int64_t y = j + (int64_t)o * (i + (int64_t)o * (b + (int64_t)v * a));
         const int64_t lad = (a <= b) ? i + (int64_t)o * (j + (int64_t)o * ((int64_t)b * (b + 1) / 2 + a))
                                      : j + (int64_t)o * (i + (int64_t)o * ((int64_t)a * (a + 1) / 2 + b));
-        const int64_t x1 = x < n1 ? x : n1 - 1;
         const double r2x = p.r2[x], r2y = p.r2[y], ppv = p.pp[lad], vx0 = p.voovv[x], d2 = p.D2[x];
         const double ria = p.r1[i + o * a], dia = p.D1[i + o * a], rjb = p.r1[j + o * b], djb = p.D1[j + o * b];
         const double vx = p.voovv[i + (int64_t)o * (j + (int64_t)o * (b + (int64_t)v * a))];
-        const double told = p.t2_old[x], as2 = amps[hbase + x], r1x = p.r1[x1], d1x = p.D1[x1], as1 = amps[x1];
-        double h[16], h1[16];
+        const double told = p.t2_old[x];
+        double as2 = 0.0, h[NYT > 0 ? NYT : 1];
+        if (NYT > 0) {
+            as2 = p.amp_s[n1 + x];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            h[q] = hist[(int64_t)min(q, nyc) * hstride + hbase + x];
-            h1[q] = hist[(int64_t)min(q, nyc) * hstride + x1];
+            for (int q = 0; q < NYT; ++q) h[q] = p.hist_e[(int64_t)min(q, nyc) * p.stride + n1 + x];
         }
         const double t = (r2x + r2y + ppv + vx0) / d2;
         const double tia = ria / dia, tjb = rjb / djb;
@@ -711,23 +708,32 @@ __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p
         acc[17] += d * d;
         p.t2_old[x] = t;
         p.t2[x] = t;
-        if (ny) {
+        if (NYT > 0) {
             const double e = t - as2;
             p.ht[n1 + x] = t;
             p.he[n1 + x] = e;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] += q < ny ? e * (q == slot ? e : h[q]) : 0.0;
+            for (int q = 0; q < NYT; ++q) acc[q] += q < ny ? e * (q == slot ? e : h[q]) : 0.0;
         }
-        if (x < n1) {
-            const double t1v = r1x / d1x;
-            p.t1[x] = t1v;
-            if (ny) {
-                const double e = t1v - as1;
-                p.ht[x] = t1v;
-                p.he[x] = e;
+    }
+    // t1 part: o v elements, the first blocks only
+    GRID_STRIDE(x, n1)
+    {
+        const double r1x = p.r1[x], d1x = p.D1[x];
+        double as1 = 0.0, h[NYT > 0 ? NYT : 1];
+        if (NYT > 0) {
+            as1 = p.amp_s[x];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] += q < ny ? e * (q == slot ? e : h1[q]) : 0.0;
-            }
+            for (int q = 0; q < NYT; ++q) h[q] = p.hist_e[(int64_t)min(q, nyc) * p.stride + x];
+        }
+        const double t1v = r1x / d1x;
+        p.t1[x] = t1v;
+        if (NYT > 0) {
+            const double e = t1v - as1;
+            p.ht[x] = t1v;
+            p.he[x] = e;
+#pragma unroll
+            for (int q = 0; q < NYT; ++q) acc[q] += q < ny ? e * (q == slot ? e : h[q]) : 0.0;
         }
     }
     block_sum<18>(acc, sm);
@@ -824,7 +830,10 @@ void k_cc_tail(Context& cx, const CCTail& a)
     p.t2 = a.t2; p.t1 = a.t1; p.r2 = a.r2; p.r1 = a.r1; p.voovv = a.voovv; p.D2 = a.D2; p.D1 = a.D1; p.pp = a.pp; p.t2_old = a.t2_old;
     p.o = a.o; p.v = a.v; p.ht = a.ht; p.he = a.he; p.amp_s = a.amp_s; p.hist_e = a.hist_e; p.stride = a.stride; p.ny = a.ny; p.slot = a.slot;
     const int nblk = (int)grid_for((int64_t)a.o * a.o * a.v * a.v, RED_BLOCKS);   // (only blocks that have elements write partials)
-    LAUNCH(cc_tail_kernel, dim3(nblk), partials(cx), p);
+    if (a.ny == 0) LAUNCH(cc_tail_kernel<0>, dim3(nblk), partials(cx), p);
+    else if (a.ny <= 4) LAUNCH(cc_tail_kernel<4>, dim3(nblk), partials(cx), p);
+    else if (a.ny <= 8) LAUNCH(cc_tail_kernel<8>, dim3(nblk), partials(cx), p);
+    else LAUNCH(cc_tail_kernel<16>, dim3(nblk), partials(cx), p);
     LAUNCH(cc_finalize_kernel, dim3(1), cx.scal, cx.res_dev, (double)a.seq, a.bmat, partials(cx), nblk, a.ny, a.nerr, a.slot);
 }
 void k_mp2_energy(Context& cx, double* out1, const double* v_oovv, const double* D2, int o, int v)

@@ -4,7 +4,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 OUT="$(realpath -m "$1")"
 export TMPDIR=/tmp
 cd /tmp && rm -rf /tmp/kt_small
-AFESP_GRAPH_AFTER=${AFESP_GRAPH_AFTER:-3} rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_small -- python3 "$HERE/tools/prof_run.py" --o 5 --v 53 --iters 12 --triples 0 --scale 0.02 ${PROF_EXTRA:-} > /tmp/kt_small.log 2>&1 || { tail -5 /tmp/kt_small.log; exit 1; }
+AFESP_GRAPH_AFTER=${AFESP_GRAPH_AFTER:-3} rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_small -- python3 "$HERE/tools/prof_run.py" --o ${PROF_O:-5} --v ${PROF_V:-53} --iters 12 --triples 0 --scale 0.02 ${PROF_EXTRA:-} > /tmp/kt_small.log 2>&1 || { tail -5 /tmp/kt_small.log; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 rows = []
