@@ -230,7 +230,8 @@ void diis_check_flag(Context& cx, const double* host_scal);   // throws the refe
 void k_unpack_half(Context& cx, double* u, const double* packed, int n, int64_t c_begin = 0, int64_t c_end = -1);   // slab of (kl) pairs
 void k_pair_transpose(Context& cx, double* out, const double* in, int n);
 // out(:,:,S) = C in(:,:,S) C^T for npairs symmetric n x n blocks, n <= 64: both quarter transforms of a pair index in one launch
-void k_pair_xform(Context& cx, double* out, const double* in, const double* C, int n, int64_t npairs);
+void k_pair_xform(Context& cx, double* out, const double* in, const double* C, int n, int64_t npairs, int mode = 0);   // modes: kernels.hip
+void k_square_transpose(Context& cx, double* out, const double* in, int64_t n);                                        // out(y, x) = in(x, y)
 void k_pair_square_packed(Context& cx, double* out, const double* g, int n, int64_t c_begin, int64_t c_end);   // out(k,l,P) = g(P, tri(k,l))
 void k_tri_pack(Context& cx, double* g, const double* half, int n, int64_t k_begin, int64_t k_end);           // g(PQ,K) = half(q,p,K)
 void k_pack_pairs(Context& cx, double* packed, const double* full, int n, int64_t p_begin = 0, int64_t p_end = -1);

@@ -503,12 +503,14 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
             // (16 doubles of slack behind each: the LDS-DMA GEMM reads whole 16-element K steps, i.e. up to Kc - n elements past a
             // column's end -- the next column's, finite, times the zero padding of C -- and past the tensor's end behind the last one)
             Tensor Ta = view(cx.scratch("ao2mo_a", n * n * np + 16), {n, n, np}), Tb = view(cx.scratch("ao2mo_b", n * n * np + 16), {n, n, np});
-            if (!have_u) k_unpack_half(cx, Ta.d, ao, (int)n);            // (ij|KL), ij squared up
-            ctx->half_n = 0;                                             // the transform overwrites it
             // the LDS-DMA GEMM: even n, and from n = 96 on (its tile has 128 rows: below that most of a tile is padding and
             // the transform is launch-bound anyway); AFESP_AO2MO_TG=0 / 1: never / for every even n >= 16 (tests, A/B runs)
             const char* tg_env = getenv("AFESP_AO2MO_TG");
             const bool use_tg = n % 2 == 0 && n >= 16 && (tg_env ? tg_env[0] == '1' : n >= 96);
+            // up to 64 basis functions: the LDS-resident pair transform (AFESP_AO2MO_PAIR=0: the gather-GEMM form)
+            const bool pair_path = n <= 64 && !use_tg && !(getenv("AFESP_AO2MO_PAIR") && getenv("AFESP_AO2MO_PAIR")[0] == '0');
+            if (!have_u && !pair_path) k_unpack_half(cx, Ta.d, ao, (int)n);   // (ij|KL), ij squared up
+            ctx->half_n = 0;                                             // the transform overwrites it
             if (use_tg) {
                 AFESP_HIP(hipMemsetAsync(Ta.d + n * n * np, 0, 16 * sizeof(double), cx.stream));
                 AFESP_HIP(hipMemsetAsync(Tb.d + n * n * np, 0, 16 * sizeof(double), cx.stream));
@@ -533,14 +535,15 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
                 ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, ps, np, n, 1);
                 k_pack_pairs(cx, packed, Tb.d, (int)n);                  // mp2.f90:388-410
                 cx.sync();                                               // (the descriptors' host copies die with tg)
-            } else if (n <= 64 && !(getenv("AFESP_AO2MO_PAIR") && getenv("AFESP_AO2MO_PAIR")[0] == '0')) {
+            } else if (pair_path) {
                 // up to 64 basis functions (every bundled input, the H2O/cc-pVTZ shape): both quarter transforms of a pair index in one
                 // kernel with the n x n block resident in LDS -- five launches for the whole transform (AFESP_AO2MO_PAIR=0: the
                 // gather-GEMM form below)
-                k_pair_xform(cx, Tb.d, Ta.d, Cm.d, (int)n, np);              // (ij|K) -> (pq|K)         mp2.f90:321-348
-                k_pair_transpose(cx, Ta.d, Tb.d, (int)n);                    // (kl|PQ), kl squared up, p >= q
-                k_pair_xform(cx, Tb.d, Ta.d, Cm.d, (int)n, np);              // (kl|P) -> (rs|P)         mp2.f90:357-385
-                k_pack_pairs(cx, packed, Tb.d, (int)n);                      // mp2.f90:388-410
+                // straight from the packed AO integrals to pair columns, one transposition of the npair x npair matrix, straight into
+                // the packed MO integrals: three launches, no squared-up copy (Ta / Tb hold the two npair^2 matrices)
+                k_pair_xform(cx, Tb.d, ao, Cm.d, (int)n, np, 1);             // (ij|K) -> g(PQ, K)       mp2.f90:321-348
+                k_square_transpose(cx, Ta.d, Tb.d, np);                      // g(K, PQ)
+                k_pair_xform(cx, packed, Ta.d, Cm.d, (int)n, np, 2);         // (kl|P) -> (rs|P), RS <= P  mp2.f90:357-410
             } else {
                 contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
                 contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348

@@ -961,14 +961,18 @@ void k_unpack_half(Context& cx, double* u, const double* packed, int n, int64_t 
 // requested before the first product starts.  No intermediate touches HBM: the two gather-GEMM launches per pair, their K-slice
 // reductions and 2 x 8 n^2 npair bytes of traffic become one launch.
 constexpr int PX = 64, PXS = 66;   // padded extent, LDS row stride
+// MODE 0: in = u(a, b, S) squares (n x n per pair), out = squares            (the transform between the layout kernels)
+// MODE 1: in = the 8-fold packed AO integrals, block S gathered through the packed index; out = pair columns g(PQ, S), p >= q
+// MODE 2: in = pair columns h(KL, S);  out = the packed MO integrals, run S: packed[S (S + 1) / 2 + RS], RS <= S
+// -- with modes 1 and 2 and one transposition of the npair x npair matrix between them the whole AO->MO transform of a small basis
+// is three launches and moves 8 (2 neri + 4 npair^2) bytes: no squared-up copy of the integrals exists at any point.
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void pair_xform_kernel(double* __restrict__ out, const double* __restrict__ in, const double* __restrict__ C,
                                                             int n)
 {
     typedef double v4d_t __attribute__((ext_vector_type(4)));
     __shared__ double S[PX * PXS];
-    const int64_t nn = (int64_t)n * n;
-    const double* __restrict__ u = in + nn * blockIdx.x;
-    double* __restrict__ o = out + nn * blockIdx.x;
+    const int64_t nn = (int64_t)n * n, np = (int64_t)n * (n + 1) / 2, blk = blockIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1, lm = lane & 15, lk = lane >> 4;
     // coefficient fragments: as A operand of the first product (row p, k = i) and as B operand of the second (column q, k = j)
     double ca[16][2], cb[16][2];
@@ -987,8 +991,10 @@ __global__ __launch_bounds__(256, 2) void pair_xform_kernel(double* __restrict__
     double ur[PX * PX / 256];
 #pragma unroll
     for (int r = 0; r < PX * PX / 256; ++r) {
-        const int e = t + 256 * r, a = e & 63, b = e >> 6;
-        ur[r] = u[min(a, n - 1) + (int64_t)n * min(b, n - 1)];
+        const int e = t + 256 * r, a = min(e & 63, n - 1), b = min(e >> 6, n - 1);
+        if (MODE == 0) ur[r] = in[nn * blk + a + (int64_t)n * b];
+        else if (MODE == 1) ur[r] = in[tri(tri(a, b), blk)];
+        else ur[r] = in[np * blk + tri(a, b)];
     }
 #pragma unroll
     for (int r = 0; r < PX * PX / 256; ++r) {
@@ -1036,7 +1042,8 @@ __global__ __launch_bounds__(256, 2) void pair_xform_kernel(double* __restrict__
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], cb[s][j], acc[i][j], 0, 0, 0);
     }
-    // out(q, p) = T2(p, q) = T2(q, p): the lanes of a store run along q
+    // T2 is symmetric: (row, col) of an accumulator is written as element (col, row) so that the lanes of a store run along the
+    // fastest index of the destination -- squares: out(q, p); pair columns / packed runs: the pair (p, q) for q <= p
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1045,17 +1052,48 @@ __global__ __launch_bounds__(256, 2) void pair_xform_kernel(double* __restrict__
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int q = 32 * wn + 16 * j + lm;
-                if (p < n && q < n) o[q + (int64_t)n * p] = acc[i][j][r];
+                if (MODE == 0) {
+                    if (p < n && q < n) out[nn * blk + q + (int64_t)n * p] = acc[i][j][r];
+                } else if (MODE == 1) {
+                    if (p < n && q <= p) out[np * blk + (int64_t)p * (p + 1) / 2 + q] = acc[i][j][r];
+                } else {
+                    const int64_t rs = (int64_t)p * (p + 1) / 2 + q;
+                    if (p < n && q <= p && rs <= blk) out[blk * (blk + 1) / 2 + rs] = acc[i][j][r];
+                }
             }
         }
 }
-void k_pair_xform(Context& cx, double* out, const double* in, const double* C, int n, int64_t npairs)
+// out(y, x) = in(x, y), n x n: 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void square_transpose_kernel(double* __restrict__ out, const double* __restrict__ in, int64_t n)
+{
+    __shared__ double tile[32][33];
+    const int64_t tiles = (n + 31) / 32, bx = blockIdx.x % tiles, by = blockIdx.x / tiles;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t x = bx * 32 + tx, y = by * 32 + ty + 8 * r;
+        if (x < n && y < n) tile[ty + 8 * r][tx] = in[x + n * y];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t y = by * 32 + tx, x = bx * 32 + ty + 8 * r;
+        if (x < n && y < n) out[y + n * x] = tile[tx][ty + 8 * r];
+    }
+}
+void k_pair_xform(Context& cx, double* out, const double* in, const double* C, int n, int64_t npairs, int mode)
 {
     if (n > PX) throw Error(3, "k_pair_xform: more than 64 basis functions");
-    if (npairs > 0) {
-        hipLaunchKernelGGL(pair_xform_kernel, dim3((unsigned)npairs), dim3(256), 0, cx.stream, out, in, C, n);
-        AFESP_HIP(hipGetLastError());
-    }
+    if (npairs <= 0) return;
+    if (mode == 0) hipLaunchKernelGGL(pair_xform_kernel<0>, dim3((unsigned)npairs), dim3(256), 0, cx.stream, out, in, C, n);
+    else if (mode == 1) hipLaunchKernelGGL(pair_xform_kernel<1>, dim3((unsigned)npairs), dim3(256), 0, cx.stream, out, in, C, n);
+    else hipLaunchKernelGGL(pair_xform_kernel<2>, dim3((unsigned)npairs), dim3(256), 0, cx.stream, out, in, C, n);
+    AFESP_HIP(hipGetLastError());
+}
+void k_square_transpose(Context& cx, double* out, const double* in, int64_t n)
+{
+    const int64_t tiles = (n + 31) / 32;
+    if (n > 0) LAUNCH(square_transpose_kernel, dim3((unsigned)(tiles * tiles)), out, in, n);
 }
 void k_pair_transpose(Context& cx, double* out, const double* in, int n)
 {

@@ -11,7 +11,7 @@ n, o = int("${1:-58}"), int("${2:-5}")
 with Engine(0) as eng:
     print(bench.time_ao2mo(eng, o, n - o, 5))
 PY
-rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_ao -- python3 /tmp/ao_run.py > /tmp/kt_ao.log 2>&1; tail -1 /tmp/kt_ao.log
+rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_ao -- python3 /tmp/ao_run.py > /tmp/kt_ao.log 2>&1; grep nbasis /tmp/kt_ao.log
 python3 - <<'PY'
 import csv, glob
 rows = []
