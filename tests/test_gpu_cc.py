@@ -191,15 +191,18 @@ def test_pp_ladder_split_form_on_ragged_extents(eng, o, v, monkeypatch):
     assert np.max(np.abs(h2 - g2)) < 1e-13
 
 
-@pytest.mark.parametrize("blocked", ["0", "1"])
-@pytest.mark.parametrize("n,o", [(2, 1), (3, 2), (7, 3), (13, 4), (24, 5), (33, 16), (58, 5)])
+@pytest.mark.parametrize("blocked", ["0", "1", "gather"])
+@pytest.mark.parametrize("n,o", [(2, 1), (3, 2), (7, 3), (13, 4), (24, 5), (33, 16), (58, 5), (64, 9), (66, 9)])
 def test_ao2mo_pair_symmetric_transform(eng, n, o, blocked, monkeypatch):
     """AO->MO over the unique pairs (kl), then (pq): every packed MO integral and E(MP2) against the restatement of the four
     quarter transforms (src/mp2.f90:321-410), with a general (non-orthogonal) coefficient matrix and odd extents -- the whole
-    tensor at once (what small bases run) and slab by slab through the pair-packed half-transformed array (what large bases
-    run; forced here), the latter also starting from the (ij|KL) copy a Fock build leaves on the device."""
+    tensor at once (up to 64 functions: the LDS-resident pair transform, three launches; "gather": the gather-GEMM form it
+    replaced, which bases of 65...95 functions still run) and slab by slab through the pair-packed half-transformed array (what
+    large bases run; forced here), the latter also starting from the (ij|KL) copy a Fock build leaves on the device."""
     from afesp_amd import inputs
-    monkeypatch.setenv("AFESP_AO2MO_BLOCKED", blocked)
+    monkeypatch.setenv("AFESP_AO2MO_BLOCKED", "0" if blocked == "gather" else blocked)
+    if blocked == "gather":
+        monkeypatch.setenv("AFESP_AO2MO_PAIR", "0")
     rng = np.random.default_rng(100 * n + o)
     eri = rng.standard_normal(inputs.neri(n))
     c = rng.standard_normal((n, n))
