@@ -364,7 +364,7 @@ struct Ao2moTg {
 };
 
 // tables and the padded transpose of the coefficient matrix for basis size n (cached scratch: rebuilt per call, microseconds)
-Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_t np)
+static Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_t np)
 {
     Ao2moTg t;
     t.n = n;
@@ -413,7 +413,7 @@ Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_t np)
 
 // one quarter transform over the pairs S in [s_begin, s_end) of `in` (n x n x np), rows row0 <= m < row0 + M of the result only;
 // cols: 0 every column (x2, S), 1 only x2 <= p(S), 2 only x2 < 128 (the rest of `out` is left untouched)
-void ao2mo_tg_xform(Context& cx, Ao2moTg& t, const double* in, double* out, int64_t s_begin, int64_t s_end, int64_t M, int cols,
+static void ao2mo_tg_xform(Context& cx, Ao2moTg& t, const double* in, double* out, int64_t s_begin, int64_t s_end, int64_t M, int cols,
                     int64_t row0 = 0)
 {
     if (s_end <= s_begin || M <= 0) return;
