@@ -168,16 +168,20 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
 // GRP = true: grouped launch (gett.h); a separate instantiation so that the plain kernels keep their register allocation
 // RAG = false: the K range of every workgroup is whole K steps, which compiles the K-tail masking (8 v_cndmask per
 // 16-byte LDS store, 48 of the ~65 VALU instructions of a K step of the 256x128 tile) out of the loop
-template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int W, bool GRP = false, bool RAG = !GRP>
+// TS >= TN: column fragments STAGED per wave (the B image is 16 WN TS columns wide) while TN of them are multiplied -- tiles of 112
+// or 96 columns (TN = 7 / 6, TS = 8, one wave column) for the pair products whose 210 / 190 columns fill 82 % / 74 % of two
+// 128-column tiles: the staging map needs a power of two, the accumulators do not.
+template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int W, bool GRP = false, bool RAG = !GRP, int TS = TN>
 // Occupancy bound of the 4-wave tiles: two waves per SIMD, i.e. a budget of 256 registers.  With more than that hipcc keeps
 // the accumulators in AGPRs, and on gfx950 v_mfma_f64_16x16x4_f64 with AGPR accumulators issues every 138 cycles instead of
 // every 64 (tools/mfma_peak.hip: 34.7 against 77.7 TFLOP/s, one wave per SIMD, sixteen independent accumulators).
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AFESP_GETT_VARIANT_ & 2048)) ? 2 : 1) void gett_kernel(GettKernelArgs a)
 {
     constexpr int NT = 64 * WM * WN;
-    constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
+    constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN, BNS = 16 * WN * TS;
+    static_assert(TS == TN || (TS > TN && WN == 1), "a narrower tile than its image: one wave column only");
     using TA = TileImg<BM, AKC, NT, W>;
-    using TB = TileImg<BN, BKC, NT, W>;
+    using TB = TileImg<BNS, BKC, NT, W>;
     __shared__ double lds[2 * (TA::SIZE + TB::SIZE)];
     constexpr int STAGE = TA::SIZE + TB::SIZE;   // buffer b: A image at lds + b*STAGE, B image right behind it
 
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
     // data cursor leaves a tile the row/column offsets of the next tile are reloaded in place (they are dead until the
     // next fetch, three MFMA groups later).
     Stager<BM, AKC, NT, W> stA;
-    Stager<BN, BKC, NT, W> stB;
+    Stager<BNS, BKC, NT, W> stB;
     int fkt = 0, ftile = 0, kok = 0;
     {
         int m0, n0;
@@ -595,30 +599,30 @@ static int resident_blocks(Kern kern, int threads)
     return cus * occ;
 }
 
-template <int WM, int WN, int TM, int TN, bool AK, bool BK_, int W, bool GRP = false, bool RAG = !GRP>
+template <int WM, int WN, int TM, int TN, bool AK, bool BK_, int W, bool GRP = false, bool RAG = !GRP, int TS = TN>
 static void launch_one(const GettKernelArgs& a, dim3 grid, hipStream_t st)
 {
-    static const int cap = resident_blocks(gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG>, 64 * WM * WN);
+    static const int cap = resident_blocks(gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG, TS>, 64 * WM * WN);
     // persistent grid: no more workgroups than the device holds at once, the rest of the tiles are walked in-kernel
     int per = cap / (int)(grid.y * grid.z);
     if (per < 1) per = 1;
     if (g_dbg & 2) per = 1 << 30;   // measurement only: one tile per workgroup
     if (g_dbg & 4) per = per / 4 > 0 ? per / 4 : 1;   // measurement only: a quarter of the device (tools/burst_probe.py)
     if ((int)grid.x > per) grid.x = (unsigned)per;
-    hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG>), grid, dim3(64 * WM * WN), 0, st, a);
+    hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG, TS>), grid, dim3(64 * WM * WN), 0, st, a);
 }
 
-template <int WM, int WN, int TM, int TN, int W>
+template <int WM, int WN, int TM, int TN, int W, int TS = TN>
 static void launch_cfg(const GettKernelArgs& a, dim3 grid, hipStream_t st)
 {
     const bool ak = a.p.a_kcontig, bk = a.p.b_kcontig;
     // (RAG = false for the plain 8-wave tiles with whole K steps was A/B-measured at -2...3 % on the ring, pp-ladder and
     // K=224/3520 products although it removes 48 VALU instructions per step and spills nothing: the plain kernels keep the
     // masking; in the grouped kernel the same change gains 4 %)
-    if (ak && bk) launch_one<WM, WN, TM, TN, true, true, W>(a, grid, st);
-    else if (ak) launch_one<WM, WN, TM, TN, true, false, W>(a, grid, st);
-    else if (bk) launch_one<WM, WN, TM, TN, false, true, W>(a, grid, st);
-    else launch_one<WM, WN, TM, TN, false, false, W>(a, grid, st);
+    if (ak && bk) launch_one<WM, WN, TM, TN, true, true, W, false, true, TS>(a, grid, st);
+    else if (ak) launch_one<WM, WN, TM, TN, true, false, W, false, true, TS>(a, grid, st);
+    else if (bk) launch_one<WM, WN, TM, TN, false, true, W, false, true, TS>(a, grid, st);
+    else launch_one<WM, WN, TM, TN, false, false, W, false, true, TS>(a, grid, st);
 }
 
 #ifdef AFESP_GETT_GROUPED_TU
@@ -683,8 +687,19 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
                 const double sc = score(128, 64, s, ksteps >= 256 ? 0.82 : 0.97, 512);
                 if (sc > best * 1.02) { best = sc; tm = 4; tn = 2; wq_split = s; }
             }
+        // 256 x 112 / 256 x 96 (eight waves one above the other, 2 x 7 / 2 x 6 accumulators each under a 128-column image): the
+        // same staging for 7/8 resp. 6/8 of the MFMAs, i.e. 0.93 of the big tile's rate on what it multiplies -- worth it where
+        // the columns end just past a multiple of 112 or 96 (the pair products at o = 20: 210 = 2 x 112 - 14, 190 = 2 x 96 - 2;
+        // tools/ladder_tiles.py: 6.87 -> 6.21 ms per ladder)
+        for (int cols = 112; cols >= 96; cols -= 16)
+            for (int s = 1; s <= 4; ++s) {
+                if (s > 1 && (force_split > 0 || ksteps / s < 32)) continue;
+                const double sc = score(256, cols, s, 0.93, 256);
+                if (sc > best * 1.02) { best = sc; tm = 16; tn = cols / 16; wq_split = s; }
+            }
     }
-    const int BM = tm == 16 ? 256 : tm == 8 ? 128 : 32 * tm, BN = tn == 16 ? 256 : tn == 8 ? 128 : 32 * tn;
+    if (tn == 6 || tn == 7) tm = 16;   // (the narrow tiles exist under 256 rows only)
+    const int BM = tm == 16 ? 256 : tm == 8 ? 128 : 32 * tm, BN = tn == 16 ? 256 : tn == 8 ? 128 : tn == 7 ? 112 : tn == 6 ? 96 : 32 * tn;
     a.mtiles = (p.M + BM - 1) / BM;
     a.ntiles = (p.N + BN - 1) / BN;
     const int64_t tiles = (int64_t)a.mtiles * a.ntiles * p.nbatch;
@@ -733,6 +748,9 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     AFESP_CFG(4, 1, 2, 2, 4, 1) AFESP_CFG(4, 2, 2, 2, 4, 2) AFESP_CFG(4, 4, 2, 4, 4, 2)
     AFESP_CFG(8, 8, 2, 2, 4, 4) AFESP_CFG(16, 8, 4, 2, 4, 4) AFESP_CFG(8, 16, 2, 4, 4, 4)
 #undef AFESP_CFG
+    // 256 x 112 / 256 x 96: eight waves one above the other, 2 x 7 / 2 x 6 accumulators each, a 128-column image
+    if (tm == 16 && tn == 7) { if (wide) launch_cfg<8, 1, 2, 7, 2, 8>(a, grid, stream); else launch_cfg<8, 1, 2, 7, 1, 8>(a, grid, stream); }
+    if (tm == 16 && tn == 6) { if (wide) launch_cfg<8, 1, 2, 6, 2, 8>(a, grid, stream); else launch_cfg<8, 1, 2, 6, 1, 8>(a, grid, stream); }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     if (a.ksplit > 1) {
