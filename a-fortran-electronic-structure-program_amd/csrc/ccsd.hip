@@ -174,7 +174,9 @@ bool ccsd_uses_lanes(const CCState& s) { return lanes_pay(s); }
 static bool lanes_pay(const CCState& s)
 {
     static const bool off = [] { const char* e = getenv("AFESP_NO_LANES"); return e && e[0] == '1'; }();
-    return !off && !s.sharded && s.t2.size() <= ((int64_t)1 << 20);
+    // (tuning knob AFESP_SMALL_MAX: the largest o^2 v^2 that still takes the small-system paths)
+    static const int64_t small_max = [] { const char* e = getenv("AFESP_SMALL_MAX"); return e ? (int64_t)atof(e) : (int64_t)1 << 20; }();
+    return !off && !s.sharded && s.t2.size() <= small_max;
 }
 
 // Rank split of one iteration ("next"): with a communicator of more than one rank the o^3 v^3 ring products and
@@ -319,7 +321,14 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
 //   pp(ijab) = sum_{e<=f}' 1/2 c+ V+  +  sum_{e<f} 1/2 c- V-  =  Ps(ij,ab) + Pa(ij,ab),    pp(jiab) = Ps - Pa   (i <= j, a <= b),
 // two products over pair indices only -- [o(o+1)/2] x [v(v+1)/2]^2 and [o(o-1)/2] x [v(v-1)/2]^2, a quarter of the
 // reference's dgemm.  V+- are built once (the integrals are immutable), c+- per iteration.
-static int tile_cols(int64_t n) { return n <= 32 ? 32 : n <= 64 ? 64 : (int)((n + 127) / 128 * 128); }
+// columns the launcher's tiles cover for n of them: 32 / 64 / multiples of 128, or of 112 / 96 at 0.93 of the wide tile's rate (gett.hip)
+static int tile_cols(int64_t n)
+{
+    if (n <= 32) return 32;
+    if (n <= 64) return 64;
+    const int64_t wide = (n + 127) / 128 * 128, n7 = (int64_t)((double)((n + 111) / 112 * 112) / 0.93), n6 = (int64_t)((double)((n + 95) / 96 * 96) / 0.93);
+    return (int)std::min(wide, std::min(n7, n6));
+}
 bool pp_sym_pays(int64_t O, int64_t V)
 {
     if (const char* e = getenv("AFESP_PP_SYM")) return e[0] == '1';
