@@ -94,13 +94,18 @@ def test_completely_renormalised_triples_match_bundled_outputs(eng, name):
     assert np.max(np.abs(parts - out)) < 1e-12
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [1, 0, "large"])
 @pytest.mark.parametrize("o,v", [(4, 9), (12, 72)])
-def test_one_iteration_term_by_term(eng, o, v, fused):
+def test_one_iteration_term_by_term(eng, o, v, fused, monkeypatch):
     """Every intermediate and both residuals after one update from non-trivial amplitudes (t1 != 0).  The second size is
     the largest the oracle does in seconds and is past the thresholds where the launcher switches to the kernels config 5
     runs on: 256x128 / 128x128 tiles with 16-byte staging, K slicing by the wave-quantisation score, re-laid-out operands,
-    the pp-ladder in its symmetric/antisymmetric pair form with M = v(v+1)/2 = 2628 rows."""
+    the pp-ladder in its symmetric/antisymmetric pair form with M = v(v+1)/2 = 2628 rows.  "large": the single stream of
+    whole-tensor products that o^2 v^2 > 2^20 takes (AFESP_SMALL_MAX=0 sends these sizes down it): there the t1 term of I_vv comes
+    from the m = i diagonals of the two <eb|ia> products instead of a pass over 2<eb|ma> - <be|ma>."""
+    if fused == "large":
+        monkeypatch.setenv("AFESP_SMALL_MAX", "0")
+        fused = 0
     if o * v > 100:
         from afesp_amd import inputs
         n = o + v
