@@ -243,6 +243,8 @@ void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1
 void k_build_fock(Context& cx, double* fock, const double* hcore, const double* dens, const double* u, double* work, int n);
 int64_t k_build_fock_work(int n);
 double* host_scalars(Context& cx, int n);
+double* host_scalars_slot(Context& cx, double* seq);          // a kernel of the caller publishes itself (contract.hip); nullptr: use host_scalars
+double* host_scalars_wait(Context& cx, int n, double seq);     // polls for that sequence number, returns the n values on the host
 
 // Code-object preload: the runtime loads a translation unit's device code on the first use of one of its kernels (55-70 ms for
 // the GEMM instantiations alone).  Each unit names one of its kernels here; afesp_ctx_create asks for their attributes on a

@@ -349,6 +349,25 @@ double* host_scalars(Context& cx, int n)
     const double want = (double)++cx.pub_seq;
     hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, cx.stream, cx.res_dev + PUB, cx.scal, n, want);
     AFESP_HIP(hipGetLastError());
+    return host_scalars_wait(cx, n, want);
+}
+
+// where a kernel of the caller's own may publish up to 64 values itself (values first, then the sequence number *seq into slot 64
+// with release semantics at system scope, as publish_scalars_kernel does); nullptr: not available, use host_scalars
+double* host_scalars_slot(Context& cx, double* seq)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (!cx.res_dev || hipStreamIsCapturing(cx.stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    *seq = (double)++cx.pub_seq;
+    return cx.res_dev + 8 + 256;
+}
+
+double* host_scalars_wait(Context& cx, int n, double want)
+{
+    constexpr int PUB = 8 + 256;
     bool seen = false;
     for (int spin = 0; spin < 400000; ++spin) {
         if (__atomic_load_n((const int64_t*)&cx.res_host[PUB + 64], __ATOMIC_ACQUIRE) == *(const int64_t*)&want) { seen = true; break; }

@@ -53,6 +53,31 @@ __global__ __launch_bounds__(256) void triples_sum_kernel(double* out, const dou
     }
 }
 
+// Small systems (one chunk, few partials): the ordered sums of all nq quantities and their publication to the host in ONE block --
+// scal[q] = dst[q] = sum_b partial[q][b], then the sequence number (host_scalars_slot, contract.hip).  Replaces a fill, a sum and a
+// publishing launch (three of the eight launches of a plain (T) at o = 5, v = 53).
+__global__ __launch_bounds__(256) void triples_sum_publish_kernel(double* __restrict__ scal, double* __restrict__ dst, double seq,
+                                                                  const double* __restrict__ partial, int nq, int nblk)
+{
+    __shared__ double sm[6][4];
+    for (int q = 0; q < nq; ++q) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += blockDim.x) s += partial[(int64_t)q * nblk + b];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) sm[q][threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 6) {
+        const double val = (int)threadIdx.x < nq ? sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3] : 0.0;
+        scal[threadIdx.x] = val;
+        dst[threadIdx.x] = val;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&dst[64], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // diagnostic builds (-DAFESP_ORBIT_STAMPS): reads and clears the orbit kernel's phase sums (triples_orbit.h)
 hipError_t triples_read_orbit_stamps(unsigned long long* out, int n)
 {
@@ -76,6 +101,7 @@ void preload_triples()
 {
     hipFuncAttributes at;
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_sum_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_sum_publish_kernel));
     (void)hipGetLastError();
     preload_tgemm();
 }
@@ -927,7 +953,11 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     cx.t_ops_amp = s.amp_epoch;
     cx.t_ops_scratch = cx.scratch_epoch;
     const int nq = cr ? 6 : want_d ? 4 : 2;
-    k_fill(cx, cx.scal, 6, 0.0);
+    // one chunk, few partials, no base term behind it: the sums and their way to the host are one launch (triples_sum_publish_kernel)
+    const bool dbase = t_begin == 0 && want_d;
+    double pub_seq = 0.0;
+    double* pub = (p->chunks.size() == 1 && !dbase && (int64_t)p->norb * p->chunks[0].nt <= 8192 && !cx.prof) ? host_scalars_slot(cx, &pub_seq) : nullptr;
+    if (!pub) k_fill(cx, cx.scal, 6, 0.0);
     TriplesIn in{s.e, s.t1.d, vs.d, ts.d, s.t2.d, o, v};
     double* Xpool = p->pool0 ? p->pool0 : cx.scratch("t_xpool", p->nb * vp3);
     int64_t max_nt = 1;
@@ -1023,15 +1053,20 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             cx.prof_orbit_launches += 1;
             cx.prof_orbit_bytes += 8.0 * 3.0 * (double)v3 * ch.nt;
         }
-        sum_partials(cx, cx.scal, partial, nq, p->norb * ch.nt, sum_tmp);
+        if (pub) {
+            hipLaunchKernelGGL(triples_sum_publish_kernel, dim3(1), dim3(256), 0, cx.stream, cx.scal, pub, pub_seq, partial, nq, p->norb * ch.nt);
+            AFESP_HIP(hipGetLastError());
+        } else {
+            sum_partials(cx, cx.scal, partial, nq, p->norb * ch.nt, sum_tmp);
+        }
     }
-    if (t_begin == 0 && want_d) {
+    if (dbase) {
         hipLaunchKernelGGL(triples_dbase_kernel, dim3(256), dim3(256), 0, cx.stream, partial, in, 256);
         AFESP_HIP(hipGetLastError());
         hipLaunchKernelGGL(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, 256);
         AFESP_HIP(hipGetLastError());
     }
-    double* h = host_scalars(cx, 6);
+    double* h = pub ? host_scalars_wait(cx, 6, pub_seq) : host_scalars(cx, 6);
     for (size_t q = 0; q + 2 < evs.size(); q += 3) {
         float a = 0.f, b = 0.f;
         AFESP_HIP(hipEventElapsedTime(&a, evs[q], evs[q + 1]));
