@@ -46,6 +46,7 @@ struct Plan {
     int64_t *offAm, *offAk, *offBk, *offBn, *offCm, *offCn;
     int M, N, K;
     bool swapped, a_kc, b_kc, wide;
+    bool a_mu = false, b_nu = false;   // consecutive m (n) are consecutive in A (B): its leading free label has unit stride there
     int repack = 0;                 // 1/2: caller's first/second operand is re-laid-out into scratch before the product
     int64_t repack_stride[6] = {0, 0, 0, 0, 0, 0};
     // the copy in the plan's scratch buffer is the re-laid-out tensor (frozen id, address) as of this scratch epoch: not made again

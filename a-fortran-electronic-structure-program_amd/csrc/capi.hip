@@ -12,6 +12,7 @@
 #include "tgemm.h"
 #include "comm.h"
 #include "fused.h"
+#include "tall.h"
 
 using namespace afesp;
 
@@ -1489,6 +1490,7 @@ int afesp_ccsd_t_block_size(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr,
 // diagnostic builds of the GEMM kernel (AFESP_GETT_VARIANT bit 64): the per-wave cycle stamps of the last launch
 int afesp_debug_stamps(unsigned long long* out, int n)
 {
+    if (n == -1000) { out[0] = tall_launch_count(); return 0; }                   // launches of the streamed tall x skinny kernel (tests)
     if (n < 0) return triples_read_orbit_stamps(out, -n) == hipSuccess ? 0 : 1;   // the (T) orbit kernel's phase sums
     if (getenv("AFESP_STAMPS_GROUPED")) return gett_read_stamps_grouped(out, n) == hipSuccess ? 0 : 1;
     return gett_read_stamps(out, n) == hipSuccess ? 0 : 1;

@@ -9,6 +9,7 @@
 
 #include "afesp_internal.h"
 #include "fused.h"
+#include "tall.h"
 
 namespace afesp {
 
@@ -601,6 +602,15 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
         if (it == cx.plans.end()) {
         p.a_kc = !K.empty() && K[0].c == afast && K[0].sa == 1;
         p.b_kc = !K.empty() && K[0].c == bfast && K[0].sb == 1;
+        {
+            auto lead_unit = [](const std::vector<Lab>& g, int which) {
+                for (auto& l : g)
+                    if (l.dim > 1) return (which == 0 ? l.sa : l.sb) == 1;
+                return true;
+            };
+            p.a_mu = lead_unit(M, 0);
+            p.b_nu = lead_unit(N, 1);
+        }
         const std::vector<Lab>* grp[6] = {&M, &K, &K, &N, &M, &N};
         const int whichs[6] = {0, 0, 1, 1, 2, 2};   // offAm, offAk, offBk, offBn, offCm, offCn
         int64_t nn[6];
@@ -718,6 +728,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
     g.batchB = p.swapped ? bA0 : bB0;
     g.batchC = bC;
     g.a_kcontig = p.a_kc; g.b_kcontig = p.b_kc;
+    g.a_munit = p.a_mu; g.b_nunit = p.b_nu;
     g.wide = p.wide && ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0);
     if (cx.rec) {   // launch-fused path: the product joins the recording instead of being launched
         auto span = [](const Tensor& t) {
@@ -730,8 +741,11 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
     }
     // AFESP_CONTRACT_TRACE=1 (tools/contract_trace.py): every product alone on the device, its labels, extents and time on stderr
     static const bool trace = getenv("AFESP_CONTRACT_TRACE") != nullptr;
+    // tall x skinny (one extent of C at most 32, K a few hundred: the products of t1 with a four-index array): streamed, tall.h
+    const bool tall = !force_split && !force_tm && !force_tn && tall_eligible(g);
+    auto launch = [&]() { return tall ? tall_launch(g, cx.stream) : gett_launch(g, cx.ws, cx.stream, force_split, force_tm, force_tn); };
     if (!trace) {
-        AFESP_HIP(gett_launch(g, cx.ws, cx.stream, force_split, force_tm, force_tn));
+        AFESP_HIP(launch());
         return;
     }
     hipEvent_t e0, e1;
@@ -739,7 +753,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
     AFESP_HIP(hipEventCreate(&e1));
     AFESP_HIP(hipDeviceSynchronize());
     AFESP_HIP(hipEventRecord(e0, cx.stream));
-    AFESP_HIP(gett_launch(g, cx.ws, cx.stream, force_split, force_tm, force_tn));
+    AFESP_HIP(launch());
     AFESP_HIP(hipEventRecord(e1, cx.stream));
     AFESP_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -748,7 +762,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
     (void)hipEventDestroy(e1);
     const double fl = 2.0 * g.M * (double)g.N * g.K * nbatch, by = 8.0 * (A0.size() + B0.size() + C.size());
     fprintf(stderr, "contract %-6s,%-6s>%-6s M %7d N %7d K %7d akc %d bkc %d wide %d %9.1f us %6.2f TF %7.1f GB/s%s\n", la0, lb0, lc, g.M, g.N,
-            g.K, (int)g.a_kcontig, (int)g.b_kcontig, (int)g.wide, ms * 1e3, fl / ms * 1e-9, by / ms * 1e-6, cx.in_repack ? "  (repacked)" : "");
+            g.K, (int)g.a_kcontig, (int)g.b_kcontig, (int)g.wide, ms * 1e3, fl / ms * 1e-9, by / ms * 1e-6, cx.in_repack ? "  (repacked)" : tall ? "  (tall)" : "");
 }
 
 // ------------------------------------------------------------------ permute_add

@@ -36,6 +36,8 @@ struct GettProblem {
     // every operand offset is even and the contiguous direction of both operands advances in unit-stride pairs:
     // 16-byte loads/stores are legal (set by the planner after checking the tables)
     bool wide = false;
+    // consecutive m are consecutive elements of A / consecutive n of B (the planner's view of the leading free label; tall.h)
+    bool a_munit = false, b_nunit = false;
 };
 
 // Grouped launch: several products that share M, K, B, C, the row tables and the K tables, but differ in the A panel, the

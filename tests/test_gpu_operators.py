@@ -78,6 +78,51 @@ def test_contract_gemv_shapes(eng):
     assert np.max(np.abs(got - np.einsum("miea,me->ai", w, t1))) < 1e-12
 
 
+# (o, v): the skinny extent S = o and the summed extent K = v of the streamed products (csrc/tall.hip): one and two 16-column
+# fragments, K a multiple of 4 and not, K below / at / above one chunk of 16 loads, a tall extent that is not a multiple of 16
+@pytest.mark.parametrize("o,v", [(3, 37), (16, 24), (20, 50), (32, 21), (1, 130), (7, 64)])
+@pytest.mark.parametrize("beta", [0.0, 1.0, -0.5])
+def test_tall_skinny_products_of_the_iteration(eng, o, v, beta, monkeypatch):
+    """The products of t1 with a four-index array that stream their large operand (tall x skinny, csrc/tall.hip): the label forms of
+    src/ccsd.f90:1165-1191, :1275-1290, :1700, :1255-1272 at extents past the kernel's thresholds, both orientations of C (lanes along
+    the tall or along the skinny index), summed index contiguous or strided, accumulating or not -- against numpy and against
+    the gather kernel on the same operands (AFESP_TALL is read once: the gather kernel is forced through its tile arguments)."""
+    monkeypatch.setenv("AFESP_TALL_MIN", "8192")   # (the default threshold is 2^17 rows)
+    rng = np.random.default_rng(100 * o + v)
+    n_ia = -(-9000 // v)                        # enough (i, a) pairs for 8192 rows (b, i, a) of the tall index
+    oi, va = (n_ia, 1) if n_ia <= 40 else (40, -(-n_ia // 40))
+    t1 = _rand(rng, o, v)
+    g = _rand(rng, v, v, oi, va)               # <eb|ia>-shaped: (v, v, o', v')
+    cases = [
+        ("je", t1, "ebia", g, "jbia", (o, v, oi, va)),     # t(j,e) <eb|ia>: summed index fastest in the tall operand, C lanes along j
+        ("beia", g, "je", t1, "bjia", (v, o, oi, va)),     # <be|ia> t(j,e): summed index second, C lanes along b (the tall side)
+        ("ie", t1, "baje", np.asfortranarray(g.transpose(0, 1, 2, 3)), "ijab", None),   # filled in below
+    ]
+    h = _rand(rng, v, va, oi, v)               # <ab|je>-shaped (b, a, j, e): summed index slowest
+    cases[2] = ("ie", t1, "baje", h, "ijab", (o, oi, va, v))
+    import ctypes
+    count = (ctypes.c_ulonglong * 1)()
+    eng.L.afesp_debug_stamps(count, -1000)
+    before = count[0]
+    for la, A, lb, B, lc, shape in cases:
+        C0 = _rand(rng, *shape)
+        ref = beta * C0 + 1.5 * np.einsum(f"{la},{lb}->{lc}", A, B)
+        got = eng.contract(1.5, A, la, B, lb, beta, C0.copy(order="F"), lc)
+        assert np.max(np.abs(got - ref)) < 1e-11, (la, lb, lc)
+        gather = eng.contract(1.5, A, la, B, lb, beta, C0.copy(order="F"), lc, force_tm=1, force_tn=1)
+        assert np.max(np.abs(got - gather)) < 1e-11, (la, lb, lc)
+    eng.L.afesp_debug_stamps(count, -1000)
+    # (o = 1: C(i,j,a,b) then runs along j first, across the fastest index of <ab|je> -- that one stays with the gather kernel)
+    taken = count[0] - before
+    assert taken == (3 if o > 1 else 2), "the streamed kernel did not take these products"
+    # a product that reads its tall operand across its fastest index stays with the gather kernel
+    m = _rand(rng, o, v, oi * va, v)           # <mb|ie>-shaped (m, b, i, e)
+    got = eng.contract(1.0, t1, "je", m, "mbie", 0.0, np.zeros((oi * va, o, o, v), order="F"), "ijmb")
+    assert np.max(np.abs(got - np.einsum("je,mbie->ijmb", t1, m))) < 1e-11
+    eng.L.afesp_debug_stamps(count, -1000)
+    assert count[0] - before == taken
+
+
 @pytest.mark.parametrize("order", ["".join(p) for p in itertools.permutations("1234")])
 def test_omp_reshape_all_24_orders(eng, order):
     rng = np.random.default_rng(11)
