@@ -493,7 +493,11 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     C(1.0, s.asym, "mief", s.v_vvov, "efma", 1.0, r1b, "ia");
     lane(1);
     // ---- T2, Eq. 44                                                    ccsd.f90:1637-1716
-    C(1.0, s.t2, "ijae", s.I_vv, "eb", 0.0, s.r2, "ijab");                 // :1647
+    // (large-system path: the streamed product over <ab|ej> opens the residual instead of accumulating into it -- an accumulating
+    // launch of tall_kernel fetches the old values at every tile's end)
+    const bool open_with_vvov = !par && !cx.rec;
+    if (open_with_vvov) C(1.0, s.t1, "ie", s.v_vvov, "baje", 0.0, s.r2, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
+    C(1.0, s.t2, "ijae", s.I_vv, "eb", open_with_vvov ? 1.0 : 0.0, s.r2, "ijab");   // :1647
     C(-1.0, s.t2, "miba", s.I_oo, "jm", 1.0, s.r2, "ijab");                // :1654-1664
     lane(4);
     ccsd_pp_ladder(cx, s);                                                 // :1669  particle-particle ladder
@@ -510,7 +514,7 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     }
     lane(3);
     if (!sh) C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
-    C(1.0, s.t1, "ie", s.v_vvov, "baje", 1.0, r2c, "ijab");                // :1700, bare part: t(i,e) <ab|ej>
+    if (!open_with_vvov) C(1.0, s.t1, "ie", s.v_vvov, "baje", 1.0, r2c, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
     C(-1.0, s.t1, "ma", s.z_ooov, "ijmb", 1.0, r2c, "ijab");               // :1705-1715 and the t1-dressed parts of :1700 (ccsd_intermediates)
     if (par) cx.join();   // (the partial residuals r1b, r2b, r2c are added up by the update kernel below)
     if (sh) {
