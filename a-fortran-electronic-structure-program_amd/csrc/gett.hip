@@ -15,6 +15,7 @@
 // result register r of lane l is C[m = (l>>4) + 4r][n = l&15]  (cdna_hip_programming.md section 3).
 #include "gett.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace afesp {
@@ -736,6 +737,10 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     a.gm = g_group_m > 0 ? g_group_m : (a.ntiles >= 8 ? 4 : a.ntiles >= 4 ? 8 : a.ntiles >= 2 ? 16 : 32);
     if (a.gm > a.mtiles) a.gm = a.mtiles;
     dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)a.ksplit, (unsigned)p.nbatch);
+    static const bool gett_debug = getenv("AFESP_GETT_DEBUG") != nullptr;   // every launch: extents, tile codes, K slices
+    if (gett_debug)
+        fprintf(stderr, "gett_launch M %d N %d K %d batch %d akc %d bkc %d wide %d -> tm %d tn %d tiles %d x %d split %d (steps per slice %d)\n", p.M, p.N, p.K,
+                p.nbatch, (int)p.a_kcontig, (int)p.b_kcontig, (int)wide, tm, tn, a.mtiles, a.ntiles, a.ksplit, a.kchunk / BK);
     // tile code (tm,tn) -> wave grid x per-wave MFMA grid.  (4,4) is the 8-wave 128x128 tile: two waves per SIMD share
     // the matrix pipe, so one wave's gather/LDS phases are covered by the other's MFMAs.
 #define AFESP_CFG(TM_, TN_, WM_, WN_, PM_, PN_) \

@@ -956,7 +956,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     // one chunk, few partials, no base term behind it: the sums and their way to the host are one launch (triples_sum_publish_kernel)
     const bool dbase = t_begin == 0 && want_d;
     double pub_seq = 0.0;
-    double* pub = (p->chunks.size() == 1 && !dbase && (int64_t)p->norb * p->chunks[0].nt <= 8192 && !cx.prof) ? host_scalars_slot(cx, &pub_seq) : nullptr;
+    double* pub = (p->chunks.size() == 1 && !dbase && (int64_t)p->norb * p->chunks[0].nt <= 8192) ? host_scalars_slot(cx, &pub_seq) : nullptr;
     if (!pub) k_fill(cx, cx.scal, 6, 0.0);
     TriplesIn in{s.e, s.t1.d, vs.d, ts.d, s.t2.d, o, v};
     double* Xpool = p->pool0 ? p->pool0 : cx.scratch("t_xpool", p->nb * vp3);
