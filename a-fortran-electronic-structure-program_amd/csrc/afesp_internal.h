@@ -79,7 +79,15 @@ struct Context {
     int cc_split_mode = -1;               // afesp_ccsd_set_split: 1 split the CCSD iteration over the ranks, 0 replicas, -1 environment (default off)
     int test_throw = 0;                   // test hook (afesp_test_inject): the next laned amplitude update throws
     int fused_mode = -1;                  // afesp_ccsd_set_fused: 1 launch-fused small-system path on, 0 off, -1 environment (default on)
-    std::vector<std::vector<int64_t>> pending_host;   // host images of plan tables whose uploads are still in flight (recording only)
+    // Recording (fused.h): the offset tables of the plans made meanwhile are not uploaded one by one -- their host images wait here
+    // (destination, image) and go to the device in as few copies as their destinations are contiguous (plan_alloc hands out
+    // consecutive pieces of a slab: normally ONE copy for the 43 plans of an iteration).  plan_uploads_issue: the copies, no wait;
+    // the images stay alive until plan_uploads_done (after a stream synchronisation).
+    struct PendingTables { int64_t* dst; std::vector<int64_t> img; };
+    std::vector<PendingTables> pending_host;
+    std::vector<std::vector<int64_t>> pending_merged;
+    void plan_uploads_issue();
+    void plan_uploads_done() { pending_host.clear(); pending_merged.clear(); }
     Recorder* rec = nullptr;              // set while a call sequence is being recorded for the launch-fused path (fused.h): nothing is launched
     hipStream_t stream = nullptr;
     Arena arena;                          // every device allocation of the context goes through it

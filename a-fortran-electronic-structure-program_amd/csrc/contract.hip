@@ -173,6 +173,29 @@ int64_t* Context::plan_alloc(size_t n)
     plan_slab_left -= n;
     return p;
 }
+void Context::plan_uploads_issue()
+{
+    std::vector<PendingTables*> v;
+    for (auto& t : pending_host)
+        if (t.dst && !t.img.empty()) v.push_back(&t);
+    std::sort(v.begin(), v.end(), [](const PendingTables* a, const PendingTables* b) { return a->dst < b->dst; });
+    for (size_t i = 0; i < v.size();) {
+        size_t j = i + 1;
+        int64_t* end = v[i]->dst + v[i]->img.size();
+        while (j < v.size() && v[j]->dst == end) { end += v[j]->img.size(); ++j; }
+        if (j == i + 1) {
+            AFESP_HIP(hipMemcpyAsync(v[i]->dst, v[i]->img.data(), v[i]->img.size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        } else {
+            std::vector<int64_t> merged;
+            merged.reserve((size_t)(end - v[i]->dst));
+            for (size_t k = i; k < j; ++k) merged.insert(merged.end(), v[k]->img.begin(), v[k]->img.end());
+            pending_merged.push_back(std::move(merged));
+            AFESP_HIP(hipMemcpyAsync(v[i]->dst, pending_merged.back().data(), pending_merged.back().size() * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        }
+        for (size_t k = i; k < j; ++k) v[k]->dst = nullptr;   // issued
+        i = j;
+    }
+}
 void Context::plan_clear()
 {
     if (stream) (void)hipStreamSynchronize(stream);
@@ -656,14 +679,34 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
                     small.insert(small.end(), t.begin(), t.end());
                 }
             }
-            for (size_t r = 0; r < runs.size(); ++r) {
-                const size_t len = (r + 1 < runs.size() ? runs[r + 1].first : small.size()) - runs[r].first;
-                if (len)
-                    AFESP_HIP(hipMemcpyAsync(base + runs[r].second, small.data() + runs[r].first, len * sizeof(int64_t), hipMemcpyHostToDevice,
-                                             cx.stream));
+            if (runs.size() == 6) {
+                // all six host-built (every plan of a small system): one image of the allocation, ONE copy -- six copies per plan
+                // were 0.8 of the 1.0 ms that recording the 43 calls of a small iteration took
+                std::vector<int64_t> image(total, 0);
+                for (size_t r = 0; r < 6; ++r) {
+                    const size_t len = (r + 1 < 6 ? runs[r + 1].first : small.size()) - runs[r].first;
+                    std::copy(small.begin() + runs[r].first, small.begin() + runs[r].first + len, image.begin() + runs[r].second);
+                }
+                small.swap(image);
+                if (cx.rec && !verify) {   // recording: the image waits for plan_uploads_issue (fused_compile, or the way out of a failed recording)
+                    cx.pending_host.push_back({base, std::move(small)});
+                    small.clear();
+                } else if (total) {
+                    AFESP_HIP(hipMemcpyAsync(base, small.data(), total * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
+                }
+            } else {
+                for (size_t r = 0; r < runs.size(); ++r) {
+                    const size_t len = (r + 1 < runs.size() ? runs[r + 1].first : small.size()) - runs[r].first;
+                    if (len)
+                        AFESP_HIP(hipMemcpyAsync(base + runs[r].second, small.data() + runs[r].first, len * sizeof(int64_t), hipMemcpyHostToDevice,
+                                                 cx.stream));
+                }
             }
-            if (cx.rec && !verify) cx.pending_host.push_back(std::move(small));   // recording: ONE wait for all the uploads (fused_compile)
-            else AFESP_HIP(hipStreamSynchronize(cx.stream));                      // `small` is a temporary
+            if (cx.rec && !verify) {   // recording: ONE wait for all the uploads (fused_compile)
+                if (!small.empty()) cx.pending_host.push_back({nullptr, std::move(small)});   // (copies already issued from it: kept alive only)
+            } else {
+                AFESP_HIP(hipStreamSynchronize(cx.stream));                      // `small` is a temporary
+            }
             if (verify) {
                 auto pairs = [](const std::vector<int64_t>& t) {
                     if (t.size() % 2) return false;

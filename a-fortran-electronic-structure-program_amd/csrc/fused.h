@@ -107,8 +107,10 @@ inline bool fused_exec(Context& cx, FusedSlot& slot, Body body)
             body();
         } catch (...) {
             cx.rec = nullptr;
+            // (the plans made so far stay in the context: their tables must still reach the device)
+            try { cx.plan_uploads_issue(); } catch (...) {}
             (void)hipStreamSynchronize(cx.stream);
-            cx.pending_host.clear();
+            cx.plan_uploads_done();
             throw;
         }
         cx.rec = nullptr;

@@ -359,10 +359,20 @@ bool fused_enabled(const Context& cx)
 
 FusedProgram* fused_compile(Context& cx, Recorder& r)
 {
-    if (!cx.pending_host.empty()) {   // the plan tables built while recording: their uploads share this one wait
-        AFESP_HIP(hipStreamSynchronize(cx.stream));
-        cx.pending_host.clear();
-    }
+    // The plan tables built while recording are still on their way to the device (cx.pending_host holds their host images): they
+    // share the ONE wait of this function -- the one behind the upload of the program's own descriptors -- or, on a way out
+    // without a program, the guard's.
+    struct PendingGuard {
+        Context& cx;
+        bool synced = false;
+        ~PendingGuard()
+        {
+            if (cx.pending_host.empty()) return;
+            if (!synced) (void)hipStreamSynchronize(cx.stream);
+            cx.plan_uploads_done();
+        }
+    } pending{cx};
+    cx.plan_uploads_issue();   // (whatever becomes of the program: the plans stay in the context and need their tables)
     if (r.failed) return nullptr;
     auto& ops = r.ops;
     const bool debug = getenv("AFESP_FUSED_DEBUG") != nullptr;
@@ -597,6 +607,7 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
     P->desc = cx.alloc_raw((int64_t)(img.size() / 8 + 2));
     AFESP_HIP(hipMemcpyAsync(P->desc, img.data(), img.size(), hipMemcpyHostToDevice, cx.stream));
     AFESP_HIP(hipStreamSynchronize(cx.stream));   // img is a temporary
+    pending.synced = true;
     for (int s = 0; s < nstage; ++s) {
         FusedProgram::Stage& st = P->stages[(size_t)s];
         const char* base = (const char*)P->desc;
