@@ -39,14 +39,20 @@ struct EwBlk {
 constexpr int EW_PER_BLOCK = 512;   // thread-elements a workgroup of 256 threads handles (two passes)
 constexpr int KOFS_PAD = 256;       // entries behind K that repeat the last offset: the pipeline reads ahead without clamping
 
-// the planner's two K tables (element offsets, int64) as one table of 32-bit byte offsets, (A, B) interleaved
-__global__ __launch_bounds__(256) void build_kofs_kernel(uint32_t* __restrict__ dst, const int64_t* __restrict__ offAk,
-                                                         const int64_t* __restrict__ offBk, int K, int Kpad)
+// the planner's two K tables (element offsets, int64) as one table of 32-bit byte offsets, (A, B) interleaved: all products of a
+// program in one launch, blockIdx.y = product (one launch per product was 0.1 ms of host time for the 43 of an iteration)
+struct KofsJob {
+    uint32_t* dst;
+    const int64_t *offAk, *offBk;
+    int K, Kpad;
+};
+__global__ __launch_bounds__(256) void build_kofs_kernel(const KofsJob* __restrict__ jobs)
 {
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < Kpad; k += gridDim.x * blockDim.x) {
-        const int kk = min(k, K - 1);
-        dst[2 * k] = (uint32_t)(offAk[kk] << 3);
-        dst[2 * k + 1] = (uint32_t)(offBk[kk] << 3);
+    const KofsJob j = jobs[blockIdx.y];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < j.Kpad; k += gridDim.x * blockDim.x) {
+        const int kk = min(k, j.K - 1);
+        j.dst[2 * k] = (uint32_t)(j.offAk[kk] << 3);
+        j.dst[2 * k + 1] = (uint32_t)(j.offBk[kk] << 3);
     }
 }
 
@@ -489,7 +495,6 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
     }
     FusedProgram* P = new FusedProgram();
     P->epoch = r.uses_scratch ? cx.scratch_epoch : -2;
-    P->slabs = cx.alloc_raw(std::max<int64_t>(slab_total, 1));
     // the K-offset tables of the products in the form the kernel reads (32-bit byte offsets, interleaved, padded)
     std::vector<int64_t> ktab_at(ops.size(), 0);
     int64_t ktab_total = 0;
@@ -499,13 +504,17 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
         ktab_total += 2 * ((int64_t)ops[x].g.K + KOFS_PAD);
         ktab_total = (ktab_total + 7) & ~(int64_t)7;   // every table starts on a 32-byte boundary
     }
-    P->ktab = (uint32_t*)cx.alloc_raw(ktab_total / 2 + 4);
+    // (slabs and tables in one block: every first allocation of a context is a driver call)
+    const int64_t slab_len = (std::max<int64_t>(slab_total, 1) + 3) & ~(int64_t)3;
+    P->slabs = cx.alloc_raw(slab_len + ktab_total / 2 + 4);
+    P->ktab = (uint32_t*)(P->slabs + slab_len);
+    std::vector<KofsJob> kjobs;
+    int kmax = 1;
     for (size_t x = 0; x < ops.size(); ++x) {
         if (ops[x].kind != Recorder::PRODUCT) continue;
         const int Kpad = ops[x].g.K + KOFS_PAD;
-        hipLaunchKernelGGL(build_kofs_kernel, dim3((unsigned)std::min(64, (Kpad + 255) / 256)), dim3(256), 0, cx.stream, P->ktab + ktab_at[x],
-                           ops[x].g.offAk, ops[x].g.offBk, ops[x].g.K, Kpad);
-        AFESP_HIP(hipGetLastError());
+        kjobs.push_back(KofsJob{P->ktab + ktab_at[x], ops[x].g.offAk, ops[x].g.offBk, ops[x].g.K, Kpad});
+        kmax = std::max(kmax, Kpad);
     }
     // ---- descriptors: one host image, one upload
     std::vector<char> img;
@@ -604,8 +613,14 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
             }
         }
     }
+    const size_t kjobs_at = kjobs.empty() ? 0 : put(kjobs.data(), kjobs.size() * sizeof(KofsJob));
     P->desc = cx.alloc_raw((int64_t)(img.size() / 8 + 2));
     AFESP_HIP(hipMemcpyAsync(P->desc, img.data(), img.size(), hipMemcpyHostToDevice, cx.stream));
+    if (!kjobs.empty()) {
+        hipLaunchKernelGGL(build_kofs_kernel, dim3((unsigned)std::min(16, (kmax + 255) / 256), (unsigned)kjobs.size()), dim3(256), 0, cx.stream,
+                           (const KofsJob*)((const char*)P->desc + kjobs_at));
+        AFESP_HIP(hipGetLastError());
+    }
     AFESP_HIP(hipStreamSynchronize(cx.stream));   // img is a temporary
     pending.synced = true;
     for (int s = 0; s < nstage; ++s) {
@@ -680,8 +695,7 @@ void fused_run(Context& cx, const FusedProgram* P)
 void fused_free(Context& cx, FusedProgram* P)
 {
     if (!P) return;
-    cx.release(P->slabs);
-    cx.release(P->ktab);
+    cx.release(P->slabs);   // (the K tables sit behind the slabs in the same block)
     cx.release(P->desc);
     delete P;
 }
