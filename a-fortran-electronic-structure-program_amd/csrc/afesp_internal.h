@@ -262,6 +262,7 @@ double* host_scalars_wait(Context& cx, int n, double seq);     // polls for that
 void preload_gett();
 void preload_contract();
 void preload_kernels();
+void preload_small_path_kernels();   // kernels.hip: per-kernel first-use resolution of what a small system launches
 void preload_ccsd_so();
 void preload_fused();
 void preload_triples();   // copies cx.scal[0..n) to pinned host memory and synchronises

@@ -1,4 +1,5 @@
 // capi.hip -- extern "C" boundary (include/afesp.h), the AO->MO transform, and the synthetic-input generators.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -263,12 +264,24 @@ int afesp_ctx_create(int device, afesp_ctx** out)
                     if (st) (void)hipStreamDestroy(st);
                     (void)hipGetLastError();
                 }
-                preload_kernels();
-                preload_contract();
-                preload_gett();
-                preload_fused();
-                preload_triples();
-                preload_ccsd_so();
+                const bool dbg = getenv("AFESP_PRELOAD_DEBUG") != nullptr;   // time per translation unit on stderr
+                auto timed = [dbg](const char* what, void (*fn)()) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    fn();
+                    if (dbg) fprintf(stderr, "afesp preload %-10s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                };
+                // (the gather kernel's module -- 10 ms to load, a hundred instantiations -- is not asked for: a small system never
+                // launches it, and whatever loads here holds the runtime's lock against the caller's own first launches, e.g. the
+                // Fock builds of the SCF that els_amd starts at once; a large system loads it with its first product.
+                // AFESP_PRELOAD_GETT=1 restores it.)
+                timed("kernels", preload_kernels);
+                timed("fused", preload_fused);
+                timed("contract", preload_contract);
+                timed("small path", preload_small_path_kernels);
+                timed("triples", preload_triples);
+                timed("ccsd_so", preload_ccsd_so);
+                const char* pg = getenv("AFESP_PRELOAD_GETT");
+                if (pg && pg[0] == '1') timed("gett", preload_gett);
             });
     });
     if (rc) {

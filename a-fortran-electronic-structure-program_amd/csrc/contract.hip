@@ -881,6 +881,8 @@ void preload_contract()
     hipFuncAttributes at;
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(permute_add_kernel));
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(plan_table_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(permute_add_tiled_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(publish_scalars_kernel));
     (void)hipGetLastError();
 }
 

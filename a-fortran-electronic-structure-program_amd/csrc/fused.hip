@@ -241,6 +241,7 @@ void preload_fused()
     hipFuncAttributes at;
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(fused_gemm_kernel));
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(fused_ew_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(build_kofs_kernel));
     (void)hipGetLastError();
 }
 

@@ -341,6 +341,7 @@ void preload_kernels()
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(fill_kernel));
     (void)hipGetLastError();
 }
+
 void k_fill(Context& cx, double* x, int64_t n, double val)
 {
     if (cx.rec) {
@@ -1157,4 +1158,24 @@ int64_t k_build_fock_work(int n)
     return np + FOCK_CHUNKS * n2 + 2 * np * n;
 }
 
+}  // namespace afesp
+
+namespace afesp {
+// the kernels of a small system's AO->MO transform, iteration tail and set-up: the runtime resolves a kernel function on its first
+// use (0.1 - 0.7 ms each) -- three milliseconds of a process's first iteration otherwise
+void preload_small_path_kernels()
+{
+    hipFuncAttributes at;
+    const void* fns[] = {reinterpret_cast<const void*>(asym_c_kernel), reinterpret_cast<const void*>(c_sympack_kernel),
+                         reinterpret_cast<const void*>(denominators_kernel), reinterpret_cast<const void*>(mp2_energy_kernel),
+                         reinterpret_cast<const void*>(cc_energy_kernel), reinterpret_cast<const void*>(final_sum_kernel),
+                         reinterpret_cast<const void*>(cc_tail_kernel<0>), reinterpret_cast<const void*>(cc_tail_kernel<4>),
+                         reinterpret_cast<const void*>(cc_tail_kernel<8>), reinterpret_cast<const void*>(cc_finalize_kernel),
+                         reinterpret_cast<const void*>(lincomb_vals_kernel), reinterpret_cast<const void*>(slice_phys_kernel),
+                         reinterpret_cast<const void*>(antisym_pair_kernel), reinterpret_cast<const void*>(pp_expand_kernel),
+                         reinterpret_cast<const void*>(pair_expand_add_kernel), reinterpret_cast<const void*>(pair_xform_kernel<1>),
+                         reinterpret_cast<const void*>(pair_xform_kernel<2>), reinterpret_cast<const void*>(square_transpose_kernel)};
+    for (const void* f : fns) (void)hipFuncGetAttributes(&at, f);
+    (void)hipGetLastError();
+}
 }  // namespace afesp

@@ -97,14 +97,6 @@ hipError_t triples_read_orbit_stamps(unsigned long long* out, int n)
 #endif
 }
 
-void preload_triples()
-{
-    hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_sum_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_sum_publish_kernel));
-    (void)hipGetLastError();
-    preload_tgemm();
-}
 
 // out[q] += sum of partial[q][0..nblk) for q < nq, two stages when there are many partials; `tmp` holds nq * 128 doubles
 static void sum_partials(Context& cx, double* out, const double* partial, int nq, int nblk, double* tmp)
@@ -1174,6 +1166,21 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
     }
     double* h = host_scalars(cx, 1);
     return h[0];
+}
+
+void preload_triples()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_sum_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_sum_publish_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_build_vt_tiled_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_build_tt_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_dbase_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_orbit_kernel<false, true, false>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_orbit_kernel<false, true, true>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_orbit_kernel<true, true, true>));
+    (void)hipGetLastError();
+    preload_tgemm();
 }
 
 }  // namespace afesp
