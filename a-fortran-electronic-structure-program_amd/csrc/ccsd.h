@@ -58,6 +58,7 @@ struct CCState : DiisRing {
     // bumped by every entry point that may change t1 / t2 (resp. the CR intermediates): what is derived from them -- the (T)
     // operand copies, triples.hip -- is rebuilt only when these have moved on
     int64_t amp_epoch = 0, cr_epoch = 0;
+    int64_t frozen_id = 0;   // what ccsd_init stamped the immutable integral slices with (contract() keeps re-laid-out copies of those)
 };
 void triples_plan_free(CCState& s);
 

@@ -33,7 +33,7 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     s.pp_sym = pp_sym_pays(O, V);
     s.eri_src = eri_mo_dev;
     if (!s.pp_sym) s.v_vvvv = cx.tensor({V, V, V, V});   // the plain ladder reads <ef|ab>; the pair form is built from the packed array
-    s.w_oovv = cx.tensor({O, O, V, V}); s.w_vvov = cx.tensor({V, V, O, V}); s.w_oovo = cx.tensor({O, O, V, O});
+    s.w_oovv = cx.tensor({O, O, V, V}); s.w_oovo = cx.tensor({O, O, V, O});   // (w_vvov: on first use, ccsd_need_w_vvov)
     // ccsd.f90:496-512: <pq|rs> = (pr|qs), virtual offsets removed
     k_slice_phys(cx, s.v_oovv.d, eri_mo_dev, o, o, v, v, 0, 0, o, o);
     k_slice_phys(cx, s.v_ovov.d, eri_mo_dev, o, v, o, v, 0, o, 0, o);
@@ -42,11 +42,11 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     k_slice_phys(cx, s.v_oooo.d, eri_mo_dev, o, o, o, o, 0, 0, 0, 0);
     if (!s.pp_sym) k_slice_phys(cx, s.v_vvvv.d, eri_mo_dev, v, v, v, v, o, o, o, o);
     k_antisym_pair(cx, s.w_oovv.d, s.v_oovv.d, O, O, V, V, 1);   // 2<ij|ab> - <ij|ba>   (ccsd.f90:1089)
-    k_antisym_pair(cx, s.w_vvov.d, s.v_vvov.d, V, V, O, V, 0);   // 2<ab|ic> - <ba|ic>   (ccsd.f90:1101)
     k_antisym_pair(cx, s.w_oovo.d, s.v_oovo.d, O, O, V, O, 0);   // 2<ij|ak> - <ji|ak>   (ccsd.f90:1121)
     // nothing writes these again while the state lives: contract() keeps the re-laid-out copies it makes of them
     const int64_t fid = ++cx.amp_clock;
-    for (Tensor* t : {&s.v_oovv, &s.v_ovov, &s.v_vvov, &s.v_oovo, &s.v_oooo, &s.w_oovv, &s.w_vvov, &s.w_oovo}) t->frozen = fid;
+    for (Tensor* t : {&s.v_oovv, &s.v_ovov, &s.v_vvov, &s.v_oovo, &s.v_oooo, &s.w_oovv, &s.w_oovo}) t->frozen = fid;
+    s.frozen_id = fid;
     s.D1 = cx.tensor({O, V}); s.D2 = cx.tensor({O, O, V, V});
     k_denominators(cx, s.D1.d, s.D2.d, s.e, o, v);
     s.nvec = ov + o2v2;
@@ -125,6 +125,17 @@ void ccsd_need_vvvv(Context& cx, CCState& s)
     const int64_t V = s.v;
     s.v_vvvv = cx.tensor({V, V, V, V});
     k_slice_phys(cx, s.v_vvvv.d, s.eri_src, s.v, s.v, s.v, s.v, s.o, s.o, s.o, s.o);
+}
+
+// 2<ab|ic> - <ba|ic> (ccsd.f90:1101), the o v^3 companion of <ab|ic>: only the product form of I_vv's t1 term reads it (small systems,
+// the rank-split iteration) -- the large-system path takes that term from the diagonals of two products (ccsd_intermediates) and never
+// allocates it (1.3 GB at o = 20, v = 200; 15 GB at o = 40, v = 360)
+static void ccsd_need_w_vvov(Context& cx, CCState& s)
+{
+    if (s.w_vvov.d) return;
+    s.w_vvov = cx.tensor({(int64_t)s.v, (int64_t)s.v, (int64_t)s.o, (int64_t)s.v});
+    k_antisym_pair(cx, s.w_vvov.d, s.v_vvov.d, s.v, s.v, s.o, s.v, 0);
+    s.w_vvov.frozen = s.frozen_id;
 }
 
 void ccsd_free(Context& cx, CCState& s)
@@ -234,7 +245,10 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     // pass over the 2x - x^T companion of <eb|ia> (o v^3 elements: 0.34 of 25 ms at o = 20, v = 200) is not made: y is written
     // first, into the empty I_ovov, and k_ivv_diag picks both diagonals up below.
     const bool ivv_diag = !par && !fused && !s.sharded && s.o >= 2;
-    if (!ivv_diag) C(1.0, s.w_vvov, "ebma", s.t1, "me", 0.0, s.I_vv, "ba");
+    if (!ivv_diag) {
+        ccsd_need_w_vvov(cx, s);
+        C(1.0, s.w_vvov, "ebma", s.t1, "me", 0.0, s.I_vv, "ba");
+    }
     C(-1.0, s.w_oovv, "mneb", s.c, "mnea", ivv_diag ? 0.0 : 1.0, s.I_vv, "ba");
     lane(0);
     // I_oo_p(j,i)                                                        ccsd.f90:1115-1132
