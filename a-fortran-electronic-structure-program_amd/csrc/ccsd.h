@@ -75,7 +75,8 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update = false);   // d
 void ccsd_tail_launch(Context& cx, CCState& s);
 int ccsd_tail_read(Context& cx, CCState& s, double e_tol, double t_tol);
 void ccsd_pp_ladder(Context& cx, CCState& s);
-void ccsd_ooov_pair_form(Context& cx, CCState& s);
+// out = nullptr: into I_ooov_p, all rows; otherwise the rows (i, a) with a in [a0, a1) into out(j,k,i,a) (the split iteration's slice)
+void ccsd_ooov_pair_form(Context& cx, CCState& s, double* out = nullptr, int64_t a0 = 0, int64_t a1 = 0);
 void ccsd_build_I_vovv_p(Context& cx, CCState& s, const Tensor& out);   // out(c,i,a,b), dense v x o x v x v
 bool pp_sym_pays(int64_t o, int64_t v);   // whether ccsd_init chooses the split form (AFESP_PP_SYM=0/1 overrides)
 // updates s.energy / s.energy_old / s.rms (un-rooted, as ccsd.f90:1806); returns 1 if converged

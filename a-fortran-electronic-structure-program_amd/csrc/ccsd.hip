@@ -325,8 +325,24 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     lane(5);
     // I_ooov_p(j,k,i,a)                                                  ccsd.f90:1302-1308
     permute_add(cx, 1.0, s.v_oovo, "kjai", 0.0, s.I_ooov_p, "jkia");
-    if (s.pp_sym) ccsd_ooov_pair_form(cx, s);   // t2(jk,ef) <ef|ia> over pair indices, as the pp-ladder
-    else C(1.0, s.t2, "jkef", s.v_vvov, "efia", 1.0, s.I_ooov_p, "jkia");
+    if (s.sharded) {
+        // split iteration: the t2 <ef|ia> term for this rank's slice of a only, into a buffer of its own -- ccsd_amplitudes
+        // contracts that slice with t1 into the rank-partial residual (the term is 1.3 of the iteration's 24.5 ms at o = 20, v = 200;
+        // I_ooov_p itself then lacks it on every rank)
+        Tensor osh = view(cx.scratch("ooov_sh", s.I_ooov_p.size()), {(int64_t)s.o, (int64_t)s.o, (int64_t)s.o, (int64_t)s.v});
+        if (v1 > v0) {
+            if (s.pp_sym) {
+                AFESP_HIP(hipMemsetAsync(osh.d + osh.stride[3] * v0, 0, sizeof(double) * osh.stride[3] * (v1 - v0), cx.stream));
+                ccsd_ooov_pair_form(cx, s, osh.d, v0, v1);
+            } else {
+                C(1.0, s.t2, "jkef", sl(s.v_vvov, 3), "efia", 0.0, sl(osh, 3), "jkia");
+            }
+        }
+    } else if (s.pp_sym) {
+        ccsd_ooov_pair_form(cx, s);   // t2(jk,ef) <ef|ia> over pair indices, as the pp-ladder
+    } else {
+        C(1.0, s.t2, "jkef", s.v_vvov, "efia", 1.0, s.I_ooov_p, "jkia");
+    }
     if (par) cx.wait(x_voov_ready);
     C(1.0, s.t1, "je", s.x_voov, "ekia", 1.0, s.I_ooov_p, "jkia");
     if (par) cx.join();
@@ -431,10 +447,13 @@ void ccsd_pp_ladder(Context& cx, CCState& s)
 // of c under j <-> k together with e <-> f, so with t+- = t2(jkef) +- t2(jkfe) and W+- = <ef|ia> +- <fe|ia> the product is
 // Ts + Ta for j <= k and Ts - Ta for k < j, two products over pair indices (half the work).  W+- are built at init, the c+- and
 // P+- buffers of the ladder hold t+- and the two results (the ladder runs later in the iteration).
-void ccsd_ooov_pair_form(Context& cx, CCState& s)
+void ccsd_ooov_pair_form(Context& cx, CCState& s, double* out, int64_t a0, int64_t a1)
 {
+    if (!out) { out = s.I_ooov_p.d; a0 = 0; a1 = s.v; }
+    if (a1 <= a0) return;
+    // rows m = (i,a), a the slow index: the range [a0, a1) of a is the contiguous row range [o a0, o a1)
     const int64_t O = s.o, V = s.v, np = V * (V + 1) / 2, npa = V * (V - 1) / 2, ks = s.pp_ks, ka = s.pp_ka, ns = s.pp_ns, na = s.pp_na,
-                  nm = s.pp_nm, M = O * V;
+                  nm = s.pp_nm, M = O * (a1 - a0), m0 = O * a0;
     const int64_t* t = s.pp_tab;
     const int64_t* u = t + s.pp_kn;
     k_c_sympack(cx, s.pp_cs, s.pp_ca, s.t2.d, s.o, s.v, ns, na);
@@ -452,19 +471,19 @@ void ccsd_ooov_pair_form(Context& cx, CCState& s)
         return (int)std::max<int64_t>(1, std::min<int64_t>(sp, 16));
     };
     gp.A = s.ov_ws; gp.B = s.pp_cs; gp.C = s.pp_ps;
-    gp.offAm = u; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * ks;
+    gp.offAm = u + m0; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * ks + m0;
     gp.M = (int)M; gp.N = (int)ns; gp.K = (int)ks;
-    if (cx.rec) cx.rec->product(gp, ks * M, ns * ks, ns * M);
+    if (cx.rec) cx.rec->product(gp, ks * O * V, ns * ks, ns * O * V);
     else AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, slices(ns, ks)));
     if (s.ov_wa) {
         gp.A = s.ov_wa; gp.B = s.pp_ca; gp.C = s.pp_pa;
-        gp.offAm = u + nm; gp.offBk = u + 2 * nm + ks; gp.offCm = u + 3 * nm + 2 * ks;
+        gp.offAm = u + nm + m0; gp.offBk = u + 2 * nm + ks; gp.offCm = u + 3 * nm + 2 * ks + m0;
         gp.M = (int)M; gp.N = (int)na; gp.K = (int)ka;
-        if (cx.rec) cx.rec->product(gp, ka * M, na * ka, na * M);
+        if (cx.rec) cx.rec->product(gp, ka * O * V, na * ka, na * O * V);
         else AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, slices(na, ka)));
     }
     (void)np; (void)npa;
-    k_pair_expand_add(cx, s.I_ooov_p.d, s.pp_ps, s.ov_wa ? s.pp_pa : nullptr, s.o, M, ns, na);
+    k_pair_expand_add(cx, out + O * O * m0, s.pp_ps + ns * m0, s.ov_wa ? s.pp_pa + na * m0 : nullptr, s.o, M, ns, na);
 }
 
 void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
@@ -525,6 +544,9 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
         C(-1.0, s.t2, "mjae", sl(s.I_ovov, 3), "iemb", 1.0, sl(r2s, 3), "ijab");
         C(-1.0, sl(s.I_ovov, 3), "iema", s.t2, "mjeb", 1.0, sl(r2s, 2), "ijab");
         C(1.0, s.asym, "miea", sl(s.I_voov, 3), "ejmb", 1.0, sl(r2s, 3), "ijab");
+        // -t(m,a) [t2 <ef|mb>](i,j,m,b) for this rank's b (the part of z_ooov that ccsd_intermediates built per slice)
+        Tensor osh = view(cx.scratch("ooov_sh", s.I_ooov_p.size()), {(int64_t)s.o, (int64_t)s.o, (int64_t)s.o, (int64_t)s.v});
+        C(-1.0, s.t1, "ma", sl(osh, 3), "ijmb", 1.0, sl(r2s, 3), "ijab");
     }
     lane(3);
     if (!sh) C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
