@@ -209,6 +209,13 @@ void ccsd_refresh_sharding(Context& cx, CCState& s)
     s.sh_rank = cx.comm ? cx.comm->rank : 0;
     const bool on = cx.cc_split_mode >= 0 ? cx.cc_split_mode == 1 : env == 1;
     s.sharded = world > 1 && on && env != 0;
+    // measurement only (tools/split_slice_time.py): AFESP_CC_TIME_SLICE="rank,world" without a communicator -- the iteration does a
+    // rank's share of the split form and skips the exchange; the amplitudes that come out are NOT the iteration's
+    if (!cx.comm)
+        if (const char* e = getenv("AFESP_CC_TIME_SLICE")) {
+            int r = 0, w = 1;
+            if (sscanf(e, "%d,%d", &r, &w) == 2 && w > 1 && r >= 0 && r < w) { s.sharded = true; s.sh_rank = r; s.sh_world = w; }
+        }
 }
 
 static Tensor slice_axis(Tensor t, int axis, int64_t lo, int64_t hi)
@@ -285,7 +292,9 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     }
     lane(3);
     // x_voov(b,j,i,a) = <be|ia> t(j,e)                                   ccsd.f90:1275-1290
-    C(1.0, s.v_vvov, "beia", s.t1, "je", 0.0, s.x_voov, "bjia");
+    // (split iteration: only this rank's slice of a is ever read -- by I_voov and by the x_voov term of I_ooov_p below)
+    if (s.sharded) { if (v1 > v0) C(1.0, sl(s.v_vvov, 3), "beia", s.t1, "je", 0.0, sl(s.x_voov, 3), "bjia"); }
+    else C(1.0, s.v_vvov, "beia", s.t1, "je", 0.0, s.x_voov, "bjia");
     if (ivv_diag) {
         k_ivv_diag(cx, s.I_vv.d, s.I_ovov.d, s.x_voov.d, s.o, s.v);
         k_axpby(cx, s.I_ovov.d, 1.0, s.v_ovov.d, 1.0, s.I_ovov.size());
@@ -337,6 +346,8 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
             } else {
                 C(1.0, s.t2, "jkef", sl(s.v_vvov, 3), "efia", 0.0, sl(osh, 3), "jkia");
             }
+            if (par) cx.wait(x_voov_ready);
+            C(1.0, s.t1, "je", sl(s.x_voov, 3), "ekia", 1.0, sl(osh, 3), "jkia");   // (the x_voov term too: its slice only)
         }
     } else if (s.pp_sym) {
         ccsd_ooov_pair_form(cx, s);   // t2(jk,ef) <ef|ia> over pair indices, as the pp-ladder
@@ -344,7 +355,7 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
         C(1.0, s.t2, "jkef", s.v_vvov, "efia", 1.0, s.I_ooov_p, "jkia");
     }
     if (par) cx.wait(x_voov_ready);
-    C(1.0, s.t1, "je", s.x_voov, "ekia", 1.0, s.I_ooov_p, "jkia");
+    if (!s.sharded) C(1.0, s.t1, "je", s.x_voov, "ekia", 1.0, s.I_ooov_p, "jkia");
     if (par) cx.join();
     if (fused) {
         // z_ooov = y_ooov + y_oovo + I_ooov_p with every term of I_ooov_p added to it directly (the consumer of z_ooov then waits for
@@ -528,7 +539,7 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     // ---- T2, Eq. 44                                                    ccsd.f90:1637-1716
     // (large-system path: the streamed product over <ab|ej> opens the residual instead of accumulating into it -- an accumulating
     // launch of tall_kernel fetches the old values at every tile's end)
-    const bool open_with_vvov = !par && !cx.rec;
+    const bool open_with_vvov = !par && !cx.rec && !sh;   // (split iteration: that product goes per slice of b into the partial residual, below)
     if (open_with_vvov) C(1.0, s.t1, "ie", s.v_vvov, "baje", 0.0, s.r2, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
     C(1.0, s.t2, "ijae", s.I_vv, "eb", open_with_vvov ? 1.0 : 0.0, s.r2, "ijab");   // :1647
     C(-1.0, s.t2, "miba", s.I_oo, "jm", 1.0, s.r2, "ijab");                // :1654-1664
@@ -547,10 +558,11 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
         // -t(m,a) [t2 <ef|mb>](i,j,m,b) for this rank's b (the part of z_ooov that ccsd_intermediates built per slice)
         Tensor osh = view(cx.scratch("ooov_sh", s.I_ooov_p.size()), {(int64_t)s.o, (int64_t)s.o, (int64_t)s.o, (int64_t)s.v});
         C(-1.0, s.t1, "ma", sl(osh, 3), "ijmb", 1.0, sl(r2s, 3), "ijab");
+        C(1.0, s.t1, "ie", slice_axis(s.v_vvov, 0, v0, v1), "baje", 1.0, sl(r2s, 3), "ijab");   // :1700, bare part, this rank's b
     }
     lane(3);
     if (!sh) C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
-    if (!open_with_vvov) C(1.0, s.t1, "ie", s.v_vvov, "baje", 1.0, r2c, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
+    if (!open_with_vvov && !sh) C(1.0, s.t1, "ie", s.v_vvov, "baje", 1.0, r2c, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
     C(-1.0, s.t1, "ma", s.z_ooov, "ijmb", 1.0, r2c, "ijab");               // :1705-1715 and the t1-dressed parts of :1700 (ccsd_intermediates)
     if (par) cx.join();   // (the partial residuals r1b, r2b, r2c are added up by the update kernel below)
     if (sh) {
