@@ -541,12 +541,16 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     // launch of tall_kernel fetches the old values at every tile's end)
     const bool open_with_vvov = !par && !cx.rec && !sh;   // (split iteration: that product goes per slice of b into the partial residual, below)
     if (open_with_vvov) C(1.0, s.t1, "ie", s.v_vvov, "baje", 0.0, s.r2, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
-    C(1.0, s.t2, "ijae", s.I_vv, "eb", open_with_vvov ? 1.0 : 0.0, s.r2, "ijab");   // :1647
-    C(-1.0, s.t2, "miba", s.I_oo, "jm", 1.0, s.r2, "ijab");                // :1654-1664
+    // (split iteration: every term of the T2 residual is evaluated for this rank's slice of b -- or of a, where that is the index the
+    // sliced intermediate carries -- into the zeroed partial residual: the replicated residual has no terms of its own)
+    if (!sh) {
+        C(1.0, s.t2, "ijae", s.I_vv, "eb", open_with_vvov ? 1.0 : 0.0, s.r2, "ijab");   // :1647
+        C(-1.0, s.t2, "miba", s.I_oo, "jm", 1.0, s.r2, "ijab");                // :1654-1664
+    }
     lane(4);
     ccsd_pp_ladder(cx, s);                                                 // :1669  particle-particle ladder
     lane(1);
-    C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");              // :1673  hole-hole ladder
+    if (!sh) C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");     // :1673  hole-hole ladder
     lane(2);
     if (!sh) {
         C(-1.0, s.t2, "mjae", s.I_ovov, "iemb", par ? 0.0 : 1.0, r2b, "ijab");   // :1680-1695 ring terms
@@ -559,17 +563,21 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
         Tensor osh = view(cx.scratch("ooov_sh", s.I_ooov_p.size()), {(int64_t)s.o, (int64_t)s.o, (int64_t)s.o, (int64_t)s.v});
         C(-1.0, s.t1, "ma", sl(osh, 3), "ijmb", 1.0, sl(r2s, 3), "ijab");
         C(1.0, s.t1, "ie", slice_axis(s.v_vvov, 0, v0, v1), "baje", 1.0, sl(r2s, 3), "ijab");   // :1700, bare part, this rank's b
+        C(1.0, s.t2, "ijae", slice_axis(s.I_vv, 1, v0, v1), "eb", 1.0, sl(r2s, 3), "ijab");       // :1647
+        C(-1.0, slice_axis(s.t2, 2, v0, v1), "miba", s.I_oo, "jm", 1.0, sl(r2s, 3), "ijab");      // :1654-1664
+        C(0.5, s.I_oooo, "ijmn", sl(s.c, 3), "mnab", 1.0, sl(r2s, 3), "ijab");                    // :1673
+        C(-1.0, s.t1, "ma", sl(s.z_ooov, 3), "ijmb", 1.0, sl(r2s, 3), "ijab");                    // :1705-1715
     }
     lane(3);
     if (!sh) C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
     if (!open_with_vvov && !sh) C(1.0, s.t1, "ie", s.v_vvov, "baje", 1.0, r2c, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
-    C(-1.0, s.t1, "ma", s.z_ooov, "ijmb", 1.0, r2c, "ijab");               // :1705-1715 and the t1-dressed parts of :1700 (ccsd_intermediates)
+    if (!sh) C(-1.0, s.t1, "ma", s.z_ooov, "ijmb", 1.0, r2c, "ijab");      // :1705-1715 and the t1-dressed parts of :1700 (ccsd_intermediates)
     if (par) cx.join();   // (the partial residuals r1b, r2b, r2c are added up by the update kernel below)
     if (sh) {
         // the one exchange of a split iteration: sum over ranks of [PP | r2_sh] (64 + 128 MB at o = 20, v = 200), in place
         const int64_t np = (int64_t)s.v * (s.v + 1) / 2;
         comm_allreduce_dev(cx, cx.comm, s.pp, (int64_t)s.o * s.o * np + s.r2.size());
-        k_axpby(cx, s.r2.d, 1.0, s.r2_sh, 1.0, s.r2.size());
+        k_copy(cx, s.r2.d, s.r2_sh, s.r2.size());   // (the residual the update kernel and afesp_ccsd_get_tensor read)
     }
     if (defer_update) return;
     // P(ia/jb), + v_oovv, Jacobi divide                                  ccsd.f90:1720-1728
