@@ -207,6 +207,7 @@ void k_pair_expand_add(Context& cx, double* out, const double* ps, const double*
 void k_cc_energy(Context& cx, double* out2, const double* v_oovv, const double* t1, const double* t2, double* t2_old,
                  int o, int v);
 void k_mp2_energy(Context& cx, double* out1, const double* v_oovv, const double* D2, int o, int v);
+double k_mp2_packed(Context& cx, const double* eri_packed, const double* e_host, int o, int v);   // the same from the packed MO integrals (device), one launch, result on the host; e_host: the n orbital energies
 void k_dots(Context& cx, double* out, const double* x, const double* ybase, int64_t ystride, int ny, int64_t n,
             bool accumulate);   // out[j] (+)= <x, ybase + j*ystride>
 void k_lincomb(Context& cx, double* out, const double* xbase, int64_t xstride, const double* coef_dev, int nx,

@@ -600,15 +600,21 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         ctx->eri_mo_dev = packed;
         ctx->eri_mo_n = n;
         // MP2 energy on the <ij|ab> slice (mp2.f90:418-440)
-        Tensor voovv = view(cx.scratch("ao2mo_v", o * o * v * v), {o, o, v, v}), D1 = view(cx.scratch("ao2mo_d1", o * v), {o, v}),
-               D2 = view(cx.scratch("ao2mo_d2", o * o * v * v), {o, o, v, v});
-        double* e_dev = cx.scratch("ao2mo_e", n);
-        AFESP_HIP(hipMemcpyAsync(e_dev, canon_levels, sizeof(double) * n, hipMemcpyHostToDevice, cx.stream));
-        k_slice_phys(cx, voovv.d, packed, (int)o, (int)o, (int)v, (int)v, 0, 0, (int)o, (int)o);
-        k_denominators(cx, D1.d, D2.d, e_dev, (int)o, (int)v);
-        k_mp2_energy(cx, cx.scal, voovv.d, D2.d, (int)o, (int)v);
-        double* h = host_scalars(cx, 1);
-        if (e_mp2) *e_mp2 = h[0];
+        double emp2 = 0.0;
+        if (o * o * v * v <= ((int64_t)1 << 22)) {
+            // small systems: one launch, straight from the packed array (the slice and the denominators are formed on the fly)
+            emp2 = k_mp2_packed(cx, packed, canon_levels, (int)o, (int)v);
+        } else {
+            double* e_dev = cx.scratch("ao2mo_e", n);
+            AFESP_HIP(hipMemcpyAsync(e_dev, canon_levels, sizeof(double) * n, hipMemcpyHostToDevice, cx.stream));
+            Tensor voovv = view(cx.scratch("ao2mo_v", o * o * v * v), {o, o, v, v}), D1 = view(cx.scratch("ao2mo_d1", o * v), {o, v}),
+                   D2 = view(cx.scratch("ao2mo_d2", o * o * v * v), {o, o, v, v});
+            k_slice_phys(cx, voovv.d, packed, (int)o, (int)o, (int)v, (int)v, 0, 0, (int)o, (int)o);
+            k_denominators(cx, D1.d, D2.d, e_dev, (int)o, (int)v);
+            k_mp2_energy(cx, cx.scal, voovv.d, D2.d, (int)o, (int)v);
+            emp2 = host_scalars(cx, 1)[0];
+        }
+        if (e_mp2) *e_mp2 = emp2;
         if (eri_mo_packed) {
             AFESP_HIP(hipMemcpyAsync(eri_mo_packed, packed, sizeof(double) * ne, hipMemcpyDeviceToHost, cx.stream));
             cx.sync();
