@@ -601,7 +601,8 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         ctx->eri_mo_n = n;
         // MP2 energy on the <ij|ab> slice (mp2.f90:418-440)
         double emp2 = 0.0;
-        if (o * o * v * v <= ((int64_t)1 << 22)) {
+        const char* mpk = getenv("AFESP_MP2_PACKED");   // 0: the five-launch form at every size (A/B runs)
+        if (o * o * v * v <= ((int64_t)1 << 22) && !(mpk && mpk[0] == '0')) {
             // small systems: one launch, straight from the packed array (the slice and the denominators are formed on the fly)
             emp2 = k_mp2_packed(cx, packed, canon_levels, (int)o, (int)v);
         } else {
