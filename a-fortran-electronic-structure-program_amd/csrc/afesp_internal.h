@@ -186,7 +186,7 @@ void permute_add(Context& cx, double alpha, const Tensor& in, const char* li, do
 void k_fill(Context& cx, double* x, int64_t n, double val);
 void k_copy(Context& cx, double* dst, const double* src, int64_t n);
 void k_axpby(Context& cx, double* y, double a, const double* x, double b, int64_t n);   // y = a x + b y
-void k_ivv_diag(Context& cx, double* ivv, const double* y, const double* x, int o, int v);   // I_vv(b,a) += 2 sum_m y(m,b,m,a) - sum_m x(b,m,m,a)
+void k_ivv_diag(Context& cx, double* ivv, const double* y, const double* x, int o, int v, int a0, int a1);   // columns a in [a0, a1):   // I_vv(b,a) += 2 sum_m y(m,b,m,a) - sum_m x(b,m,m,a)
 void k_div(Context& cx, double* out, const double* num, const double* den, int64_t n);
 void k_antisym_pair(Context& cx, double* out, const double* in, int64_t d0, int64_t d1, int64_t d2, int64_t d3,
                     int which);   // which=0: 2x - x(swap idx 0,1)   which=1: 2x - x(swap idx 2,3)

@@ -34,6 +34,7 @@ struct CCState : DiisRing {
     double* pp = nullptr;          // packed particle-particle ladder PP(i,j,p), p over a <= b; the sharded ring terms' partial
                                    // residual r2_sh (o^2 v^2) sits right behind it: one all-reduce covers both
     double* r2_sh = nullptr;
+    double* r1_sh = nullptr;       // ... and the rank-partial r1 (o v) behind that
     // rank split of the iteration's large products (afesp_comm_init with world > 1; ccsd_refresh_sharding)
     bool sharded = false;
     int sh_rank = 0, sh_world = 1;

@@ -62,8 +62,9 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     // pp-ladder (ccsd.f90:1669) over the symmetry-unique column pairs a <= b
     {
         const int64_t np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
-        s.pp = cx.alloc(N2 * np + O * O * V * V);
+        s.pp = cx.alloc(N2 * np + O * O * V * V + O * V);   // [PP | r2_sh | r1_sh]: the one exchange buffer of a split iteration
         s.r2_sh = s.pp + N2 * np;
+        s.r1_sh = s.r2_sh + O * O * V * V;
         std::vector<int64_t> tab;
         if (!s.pp_sym) {
             // rows p of <ef|ab> viewed as [ef x ab], all (i,j) columns
@@ -251,12 +252,14 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     // over <eb|ia> that the iteration forms anyway -- y(j,b,i,a) = t(j,e) <eb|ia> (the last term of I_ovov) and x_voov -- so the
     // pass over the 2x - x^T companion of <eb|ia> (o v^3 elements: 0.34 of 25 ms at o = 20, v = 200) is not made: y is written
     // first, into the empty I_ovov, and k_ivv_diag picks both diagonals up below.
-    const bool ivv_diag = !par && !fused && !s.sharded && s.o >= 2;
+    // (split iteration: the same, per slice of a -- every reader of I_vv then takes this rank's columns only, ccsd_amplitudes)
+    const bool ivv_diag = !par && !fused && s.o >= 2;
     if (!ivv_diag) {
         ccsd_need_w_vvov(cx, s);
         C(1.0, s.w_vvov, "ebma", s.t1, "me", 0.0, s.I_vv, "ba");
     }
-    C(-1.0, s.w_oovv, "mneb", s.c, "mnea", ivv_diag ? 0.0 : 1.0, s.I_vv, "ba");
+    if (!s.sharded) C(-1.0, s.w_oovv, "mneb", s.c, "mnea", ivv_diag ? 0.0 : 1.0, s.I_vv, "ba");
+    else if (v1 > v0) C(-1.0, s.w_oovv, "mneb", sl(s.c, 3), "mnea", 0.0, slice_axis(s.I_vv, 1, v0, v1), "ba");
     lane(0);
     // I_oo_p(j,i)                                                        ccsd.f90:1115-1132
     C(1.0, s.w_oovo, "miej", s.t1, "me", 0.0, s.I_oo_p, "ji");
@@ -282,7 +285,9 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     // (a split iteration only ever reads this rank's slice of I_ovov / I_voov: every term is built for the slice only -- the last
     // index is the slowest one, a slice is one contiguous range)
     const int64_t a_len = s.I_ovov.stride[3], a_off = v0 * a_len, a_cnt = (v1 - v0) * a_len;
-    if (ivv_diag) {
+    if (ivv_diag && s.sharded) {
+        if (v1 > v0) C(1.0, s.t1, "je", sl(s.v_vvov, 3), "ebia", 0.0, sl(s.I_ovov, 3), "jbia");
+    } else if (ivv_diag) {
         C(1.0, s.t1, "je", s.v_vvov, "ebia", 0.0, s.I_ovov, "jbia");
     } else if (v1 > v0) {
         k_copy(cx, s.I_ovov.d + a_off, s.v_ovov.d + a_off, a_cnt);
@@ -295,11 +300,11 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     // (split iteration: only this rank's slice of a is ever read -- by I_voov and by the x_voov term of I_ooov_p below)
     if (s.sharded) { if (v1 > v0) C(1.0, sl(s.v_vvov, 3), "beia", s.t1, "je", 0.0, sl(s.x_voov, 3), "bjia"); }
     else C(1.0, s.v_vvov, "beia", s.t1, "je", 0.0, s.x_voov, "bjia");
-    if (ivv_diag) {
-        k_ivv_diag(cx, s.I_vv.d, s.I_ovov.d, s.x_voov.d, s.o, s.v);
-        k_axpby(cx, s.I_ovov.d, 1.0, s.v_ovov.d, 1.0, s.I_ovov.size());
-        C(-0.5, s.v_oovv, "mibe", s.c, "mjae", 1.0, s.I_ovov, "jbia");   // (o^3 v^3)
-        C(-1.0, s.v_oovo, "mibj", s.t1, "ma", 1.0, s.I_ovov, "jbia");
+    if (ivv_diag && v1 > v0) {
+        k_ivv_diag(cx, s.I_vv.d, s.I_ovov.d, s.x_voov.d, s.o, s.v, (int)v0, (int)v1);
+        k_axpby(cx, s.I_ovov.d + a_off, 1.0, s.v_ovov.d + a_off, 1.0, a_cnt);
+        C(-0.5, s.v_oovv, "mibe", sl(s.c, 2), "mjae", 1.0, sl(s.I_ovov, 3), "jbia");   // (o^3 v^3)
+        C(-1.0, s.v_oovo, "mibj", sl(s.t1, 1), "ma", 1.0, sl(s.I_ovov, 3), "jbia");
     }
     const int x_voov_ready = par ? cx.mark() : 0;
     // I_voov(b,j,i,a)                                                    ccsd.f90:1193-1252
@@ -513,7 +518,7 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     if (sh) {
         r2s.d = s.r2_sh;
         const int64_t np = (int64_t)s.v * (s.v + 1) / 2;
-        AFESP_HIP(hipMemsetAsync(s.pp, 0, sizeof(double) * ((int64_t)s.o * s.o * np + s.r2.size()), cx.stream));   // [PP | r2_sh]
+        AFESP_HIP(hipMemsetAsync(s.pp, 0, sizeof(double) * ((int64_t)s.o * s.o * np + s.r2.size() + s.r1.size()), cx.stream));   // [PP | r2_sh | r1_sh]
     }
     if (par) {
         r2b.d = cx.scratch("r2_lane2", s.r2.size());
@@ -523,8 +528,10 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     }
     lane(0);
     // ---- T1, Eq. 43                                                    ccsd.f90:1569-1631
-    C(1.0, s.t1, "ie", s.I_vv, "ea", 0.0, s.r1, "ia");
-    C(-1.0, s.I_oo_p, "im", s.t1, "ma", 1.0, s.r1, "ia");
+    // (split iteration: the two terms that read a sliced quantity -- I_vv, <ef|ma> -- go per slice of a into r1_sh, which rides behind
+    // [PP | r2_sh] in the one exchange)
+    if (!sh) C(1.0, s.t1, "ie", s.I_vv, "ea", 0.0, s.r1, "ia");
+    C(-1.0, s.I_oo_p, "im", s.t1, "ma", sh ? 0.0 : 1.0, s.r1, "ia");
     C(1.0, s.asym, "miea", s.I_vo, "em", 1.0, s.r1, "ia");
     C(2.0, s.v_oovv, "miea", s.t1, "me", 1.0, s.r1, "ia");
     lane(5);
@@ -534,7 +541,7 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     }
     C(-1.0, s.v_ovov, "maie", s.t1, "me", par ? 0.0 : 1.0, r1b, "ia");
     C(-1.0, s.v_oovo, "mien", s.asym, "mnea", 1.0, r1b, "ia");
-    C(1.0, s.asym, "mief", s.v_vvov, "efma", 1.0, r1b, "ia");
+    if (!sh) C(1.0, s.asym, "mief", s.v_vvov, "efma", 1.0, r1b, "ia");
     lane(1);
     // ---- T2, Eq. 44                                                    ccsd.f90:1637-1716
     // (large-system path: the streamed product over <ab|ej> opens the residual instead of accumulating into it -- an accumulating
@@ -567,6 +574,10 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
         C(-1.0, slice_axis(s.t2, 2, v0, v1), "miba", s.I_oo, "jm", 1.0, sl(r2s, 3), "ijab");      // :1654-1664
         C(0.5, s.I_oooo, "ijmn", sl(s.c, 3), "mnab", 1.0, sl(r2s, 3), "ijab");                    // :1673
         C(-1.0, s.t1, "ma", sl(s.z_ooov, 3), "ijmb", 1.0, sl(r2s, 3), "ijab");                    // :1705-1715
+        Tensor r1s = s.r1;
+        r1s.d = s.r1_sh;
+        C(1.0, s.t1, "ie", slice_axis(s.I_vv, 1, v0, v1), "ea", 1.0, slice_axis(r1s, 1, v0, v1), "ia");
+        C(1.0, s.asym, "mief", sl(s.v_vvov, 3), "efma", 1.0, slice_axis(r1s, 1, v0, v1), "ia");
     }
     lane(3);
     if (!sh) C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
@@ -576,8 +587,9 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     if (sh) {
         // the one exchange of a split iteration: sum over ranks of [PP | r2_sh] (64 + 128 MB at o = 20, v = 200), in place
         const int64_t np = (int64_t)s.v * (s.v + 1) / 2;
-        comm_allreduce_dev(cx, cx.comm, s.pp, (int64_t)s.o * s.o * np + s.r2.size());
+        comm_allreduce_dev(cx, cx.comm, s.pp, (int64_t)s.o * s.o * np + s.r2.size() + s.r1.size());
         k_copy(cx, s.r2.d, s.r2_sh, s.r2.size());   // (the residual the update kernel and afesp_ccsd_get_tensor read)
+        k_axpby(cx, s.r1.d, 1.0, s.r1_sh, 1.0, s.r1.size());
     }
     if (defer_update) return;
     // P(ia/jb), + v_oovv, Jacobi divide                                  ccsd.f90:1720-1728

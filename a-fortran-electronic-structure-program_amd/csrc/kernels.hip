@@ -430,11 +430,11 @@ void k_div(Context& cx, double* out, const double* num, const double* den, int64
 }
 // I_vv(b,a) += 2 sum_m y(m,b,m,a) - sum_m x(b,m,m,a): the t1 term of I_vv (ccsd.f90:1096-1101) from the two products over
 // <eb|ia> the iteration forms anyway, y(j,b,i,a) = t(j,e) <eb|ia> and x(b,j,i,a) = <be|ia> t(j,e) (ccsd.hip)
-__global__ __launch_bounds__(256) void ivv_diag_kernel(double* ivv, const double* y, const double* x, int o, int v)
+__global__ __launch_bounds__(256) void ivv_diag_kernel(double* ivv, const double* y, const double* x, int o, int v, int a0, int a1)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)v * v) return;
-    const int64_t b = idx % v, a = idx / v;
+    const int64_t idx0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx0 >= (int64_t)v * (a1 - a0)) return;
+    const int64_t b = idx0 % v, a = a0 + idx0 / v, idx = b + (int64_t)v * a;
     double sy = 0.0, sx = 0.0;
     for (int m = 0; m < o; ++m) {
         sy += y[m + (int64_t)o * (b + (int64_t)v * (m + (int64_t)o * a))];
@@ -442,10 +442,10 @@ __global__ __launch_bounds__(256) void ivv_diag_kernel(double* ivv, const double
     }
     ivv[idx] += 2.0 * sy - sx;
 }
-void k_ivv_diag(Context& cx, double* ivv, const double* y, const double* x, int o, int v)
+void k_ivv_diag(Context& cx, double* ivv, const double* y, const double* x, int o, int v, int a0, int a1)
 {
     if (cx.rec) throw Error(2, "k_ivv_diag: not part of a recorded sequence");
-    LAUNCH(ivv_diag_kernel, dim3(grid_for((int64_t)v * v)), ivv, y, x, o, v);
+    if (a1 > a0) LAUNCH(ivv_diag_kernel, dim3(grid_for((int64_t)v * (a1 - a0))), ivv, y, x, o, v, a0, a1);
 }
 void k_sub(Context& cx, double* out, const double* a, const double* b, int64_t n) { if (n > 0) LAUNCH(sub_kernel, dim3(grid_for(n)), out, a, b, n); }
 void k_antisym_pair(Context& cx, double* out, const double* in, int64_t d0, int64_t d1, int64_t d2, int64_t d3, int which)
