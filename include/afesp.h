@@ -166,8 +166,12 @@ int afesp_comm_init(afesp_ctx* ctx, int rank, int world, int transport, const ch
 int afesp_comm_destroy(afesp_ctx* ctx);
 /* in-place sum over the ranks of n host doubles (every rank passes the same n) */
 int afesp_allreduce_sum(afesp_ctx* ctx, double* inout, int64_t n);
-/* The CCSD iteration's o^3 v^3 ring products and pp-ladder split over the ranks of the communicator, one all-reduce of
- * [PP | partial residual] per iteration (replaces nothing in the reference: its iteration is one process, src/ccsd.f90:340-395).
+/* The CCSD iteration split over the ranks of the communicator: the o^3 v^3 ring products, the pp-ladder and every other term that
+ * carries a virtual index which can be sliced (the whole T2 residual, the <eb|ia> products, I_vv, two T1 terms) are evaluated for
+ * the rank's slice of that index; one all-reduce of [PP | partial T2 residual | partial T1 residual] per iteration; amplitudes,
+ * DIIS history and energies stay replicated and identical on every rank (replaces nothing in the reference: its iteration is
+ * one process, src/ccsd.f90:340-395).  While the split is on, afesp_ccsd_get_tensor returns sliced intermediates as a rank built
+ * them (I_vv, I_ovov, I_voov, x_voov: the rank's slice; I_ooov_p without its t2 <ef|ia> and x_voov terms).
  * Opt-in: mode 1 = split, 0 = replicas, -1 = as the environment says (AFESP_CC_SHARD=1 splits; default replicas;
  * AFESP_CC_SHARD=0 keeps replicas whatever mode says).  *split of afesp_ccsd_is_split = what the next iteration will do. */
 int afesp_ccsd_set_split(afesp_ctx* ctx, int mode);
