@@ -669,11 +669,14 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
             const int64_t work = (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nbatch * s;
             const int64_t rounds = (work + slots - 1) / slots;
             const double waste = (double)((p.M + bm - 1) / bm * bm) * ((p.N + bn - 1) / bn * bn) / ((double)p.M * p.N);
-            return rate * (double)work / (double)(rounds * slots) / waste * (s > 1 ? 0.96 : 1.0);
+            return rate * (double)work / (double)(rounds * slots) / waste * (s > 4 ? 0.93 : s > 1 ? 0.96 : 1.0);
         };
+        // (K slices offered: 1 ... 4, and up to 16 for products of few tiles and a long summation index -- a rank's row range of the
+        // pp-ladder in a split iteration is 20 tiles of 1257 K steps: four slices left two thirds of the device idle)
+        static const int slice_opts[] = {1, 2, 3, 4, 6, 8, 12, 16};
         double best = 0.0;
         for (int big = 0; big < 2; ++big)
-            for (int s = 1; s <= 4; ++s) {
+            for (int s : slice_opts) {
                 if (s > 1 && (force_split > 0 || ksteps / s < 32)) continue;
                 const double sc = score(big ? 256 : 128, 128, s, big ? 1.0 : 0.89, 256);
                 if (sc > best * 1.02) { best = sc; tm = big ? 16 : 4; tn = big ? 8 : 4; wq_split = s; }
@@ -683,7 +686,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
         // of the big tile's rate (3.41 -> 3.11 ms there).  A short product is mostly tile prologue and epilogue, where the small tile
         // loses nothing (I_oooo(ijmn) c(mnab) -> r2, K = 400, 400 columns: 321 -> 274 us); in between it is not offered.
         if (ksteps >= 256 || ksteps < 64)
-            for (int s = 1; s <= 4; ++s) {
+            for (int s : slice_opts) {
                 if (s > 1 && (force_split > 0 || ksteps / s < 32)) continue;
                 const double sc = score(128, 64, s, ksteps >= 256 ? 0.82 : 0.97, 512);
                 if (sc > best * 1.02) { best = sc; tm = 4; tn = 2; wq_split = s; }
@@ -693,7 +696,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
         // the columns end just past a multiple of 112 or 96 (the pair products at o = 20: 210 = 2 x 112 - 14, 190 = 2 x 96 - 2;
         // tools/ladder_tiles.py: 6.87 -> 6.21 ms per ladder)
         for (int cols = 112; cols >= 96; cols -= 16)
-            for (int s = 1; s <= 4; ++s) {
+            for (int s : slice_opts) {
                 if (s > 1 && (force_split > 0 || ksteps / s < 32)) continue;
                 const double sc = score(256, cols, s, 0.93, 256);
                 if (sc > best * 1.02) { best = sc; tm = 16; tn = cols / 16; wq_split = s; }
