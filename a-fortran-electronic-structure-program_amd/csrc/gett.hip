@@ -714,6 +714,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
         split = wq_split;
     } else if (tiles < g_split_below && ksteps >= 2 * g_split_min_steps) {
         // too few tiles to fill 256 CUs: slice K, at least 4 K steps per slice, aim for ~2 blocks per CU
+        // (8 per CU for the 32 x 32 tile of a long-K product was measured: 108 -> 170 us for 20 x 20 results over 800 000 summed indices)
         split = (int)((512 + tiles - 1) / tiles);
         if (split > ksteps / g_split_min_steps) split = ksteps / g_split_min_steps;
     } else if (tiles < 1024 && ksteps >= 64 && (int64_t)p.M * p.N * 16 <= ((int64_t)p.M + p.N) * p.K) {
