@@ -597,8 +597,11 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
             // asym(m,i,e,f) <ef|ma> -> r1(i,a) at o = 20, v = 200 reads 1.28 GB of integrals against 128 MB of amplitudes that it
             // would otherwise gather 8 bytes at a time -- 0.76 -> 0.45 ms)
             if (nbatch == 1 && !bA0 && !bB0 && !norepack) {
-                if (!b_ok && (Md >= 512 || A.size() >= 8 * B.size()) && B.size() <= limit) which = 2;
-                else if (!a_ok && (Nd >= 512 || B.size() >= 8 * A.size()) && A.size() <= limit) which = 1;
+                // (the other operand's free extent from which the copy pays: 256 -- a rank's 500-row slice of a ring product in a split
+                // iteration runs 0.52 ms from the operand as it lies, 0.29 + 0.07 from its copy; tuning knob AFESP_REPACK_MIN)
+                static const int64_t rp_min = [] { const char* e = getenv("AFESP_REPACK_MIN"); return e ? (int64_t)atoll(e) : (int64_t)256; }();
+                if (!b_ok && (Md >= rp_min || A.size() >= 8 * B.size()) && B.size() <= limit) which = 2;
+                else if (!a_ok && (Nd >= rp_min || B.size() >= 8 * A.size()) && A.size() <= limit) which = 1;
             }
             if (which) {
                 const Tensor& T = which == 1 ? A : B;
