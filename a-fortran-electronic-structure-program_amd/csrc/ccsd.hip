@@ -495,7 +495,7 @@ void ccsd_ooov_pair_form(Context& cx, CCState& s, double* out, int64_t a0, int64
         const int64_t tiles = ((M + 255) / 256) * ((n + 127) / 128), ksteps = (k + 15) / 16;
         int64_t sp = (256 + tiles - 1) / tiles;
         while (sp > 1 && ksteps / sp < 32) --sp;
-        return (int)std::max<int64_t>(1, std::min<int64_t>(sp, 16));
+        return (int)std::max<int64_t>(1, std::min<int64_t>(sp, 32));
     };
     gp.A = s.ov_ws; gp.B = s.pp_cs; gp.C = s.pp_ps;
     gp.offAm = u + m0; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * ks + m0;
