@@ -492,6 +492,7 @@ void ccsd_ooov_pair_form(Context& cx, CCState& s, double* out, int64_t a0, int64
     gp.offAk = t; gp.offBn = gp.offCn = t;
     // few tiles (o v rows x o-pair columns), long K: slice K until the device is full
     auto slices = [&](int64_t n, int64_t k) {
+        if (M >= 2048) return 0;   // (the launcher's own score: 256 x 112 / 256 x 96 tiles in as many slices as fill the device)
         const int64_t tiles = ((M + 255) / 256) * ((n + 127) / 128), ksteps = (k + 15) / 16;
         int64_t sp = (256 + tiles - 1) / tiles;
         while (sp > 1 && ksteps / sp < 32) --sp;

@@ -669,7 +669,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
             const int64_t work = (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.nbatch * s;
             const int64_t rounds = (work + slots - 1) / slots;
             const double waste = (double)((p.M + bm - 1) / bm * bm) * ((p.N + bn - 1) / bn * bn) / ((double)p.M * p.N);
-            return rate * (double)work / (double)(rounds * slots) / waste * (s > 4 ? 0.93 : s > 1 ? 0.96 : 1.0);
+            return rate * (double)work / (double)(rounds * slots) / waste * (s > 1 ? 1.0 - 0.012 * s : 1.0);   // (a slab to write and to sum per slice)
         };
         // (K slices offered: 1 ... 4, and up to 16 for products of few tiles and a long summation index -- a rank's row range of the
         // pp-ladder in a split iteration is 20 tiles of 1257 K steps: four slices left two thirds of the device idle)
