@@ -14,9 +14,9 @@ with Engine(0) as eng:
     eng.synthetic_ao(n, 0.02, 777)
     for rep in range(3):
         for mode in ("1", "0"):
-            os.environ["AFESP_MP2_PACKED"] = mode
+            os.environ[os.environ.get("AB_KNOB", "AFESP_MP2_PACKED")] = mode
             for _ in range(5): emp2, _ = eng.do_mp2_spatial(n, o, q, e, None, want_eri_mo=False)
             ts = []
             for _ in range(41):
                 t0 = time.perf_counter(); emp2, _ = eng.do_mp2_spatial(n, o, q, e, None, want_eri_mo=False); ts.append(time.perf_counter() - t0)
-            print(f"AFESP_MP2_PACKED={mode}: median {np.median(ts)*1e6:7.1f} us  min {min(ts)*1e6:7.1f} us  E(MP2) {emp2:.12f}", flush=True)
+            print(f"{os.environ.get('AB_KNOB', 'AFESP_MP2_PACKED')}={mode}: median {np.median(ts)*1e6:7.1f} us  min {min(ts)*1e6:7.1f} us  E(MP2) {emp2:.12f}", flush=True)
