@@ -192,8 +192,10 @@ void k_antisym_pair(Context& cx, double* out, const double* in, int64_t d0, int6
                     int which);   // which=0: 2x - x(swap idx 0,1)   which=1: 2x - x(swap idx 2,3)
 void k_asym_c(Context& cx, double* asym, double* c, const double* t1, const double* t2, int o, int v);
 // t2 = (P(ia/jb)[r2 + r2b + r2c] + pp + v_oovv) / D2 and t1 = (r1 + r1b) / D1 (ccsd.f90:1720-1728); r2b, r2c, r1b may be null
+// r2y: a partial residual held with i and j exchanged, r2y(j,i,a,b) (ring.hip), or null
 void k_t2_update(Context& cx, double* t2, const double* r2, const double* r2b, const double* r2c, const double* v_oovv, const double* D2,
-                 const double* pp, int o, int v, double* t1, const double* r1, const double* r1b, const double* D1);
+                 const double* pp, int o, int v, double* t1, const double* r1, const double* r1b, const double* D1, const double* r2y = nullptr);
+void k_add_swapped(Context& cx, double* out, const double* y, int o, int v);   // out(i,j,a,b) += y(j,i,a,b)
 void k_r2_full(Context& cx, double* out, const double* r2, const double* pp, int o, int v);
 void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v);
 // symmetric / antisymmetric operands of the pp-ladder (pairs x <= y indexed y(y+1)/2 + x, pairs x < y indexed y(y-1)/2 + x)

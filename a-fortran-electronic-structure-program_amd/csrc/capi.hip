@@ -802,16 +802,27 @@ int afesp_ccsd_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t
                 AFESP_HIP(hipSetDevice(ctx->cx.device));
                 const double* src = e.t->d;
                 // the residuals of a laned iteration lie in partial buffers that the update kernel adds up (ccsd_amplitudes)
+                // (only what the LAST amplitudes call left there: a launch-fused or large-system call after a laned one has none)
                 auto add_partial = [&](double* dst, const char* buf) {
                     auto it = ctx->cx.cache.find(buf);
-                    if (ccsd_uses_lanes(s) && it != ctx->cx.cache.end()) k_axpby(ctx->cx, dst, 1.0, (const double*)it->second.first, 1.0, e.t->size());
+                    if (s.partials_live && it != ctx->cx.cache.end()) k_axpby(ctx->cx, dst, 1.0, (const double*)it->second.first, 1.0, e.t->size());
                 };
                 if (!strcmp(name, "r2")) {   // the reference's tmp_t2 before P(ia/jb) includes 1/2 pp; it is kept packed here
                     double* full = ctx->cx.scratch("r2_full", e.t->size());
                     k_r2_full(ctx->cx, full, s.r2.d, s.pp, s.o, s.v);
                     add_partial(full, "r2_lane2");
                     add_partial(full, "r2_lane3");
+                    if (ring_res_live(s)) {   // the ring terms of a large system's residual (ring.hip)
+                        k_axpby(ctx->cx, full, 1.0, ring_R(s), 1.0, e.t->size());
+                        k_add_swapped(ctx->cx, full, ring_Y(s), s.o, s.v);
+                    }
                     src = full;
+                } else if (ring_live(s) && (!strcmp(name, "I_ovov") || !strcmp(name, "I_voov"))) {
+                    // a large system's iteration holds these two in the layout its ring products read (ring.hip): turned back on request
+                    const int64_t O = s.o, V = s.v;
+                    Tensor io = view(ctx->cx.scratch("ring_I_ovov", e.t->size()), {O, V, O, V}), iv = view(ctx->cx.scratch("ring_I_voov", e.t->size()), {V, O, O, V});
+                    ring_tg_materialize(ctx->cx, s, io, iv);
+                    src = !strcmp(name, "I_ovov") ? io.d : iv.d;
                 } else if (!strcmp(name, "r1")) {
                     double* full = ctx->cx.scratch("r1_full", e.t->size());
                     k_copy(ctx->cx, full, s.r1.d, e.t->size());

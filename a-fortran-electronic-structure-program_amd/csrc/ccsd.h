@@ -59,9 +59,24 @@ struct CCState : DiisRing {
     // bumped by every entry point that may change t1 / t2 (resp. the CR intermediates): what is derived from them -- the (T)
     // operand copies, triples.hip -- is rebuilt only when these have moved on
     int64_t amp_epoch = 0, cr_epoch = 0;
+    void* ring = nullptr;       // the ring products' operands and descriptors on the LDS-DMA GEMM (ring.hip), large systems
+    bool partials_live = false; // the last amplitudes call left terms of r2 / r1 in the laned partial buffers (afesp_ccsd_get_tensor)
     int64_t frozen_id = 0;   // what ccsd_init stamped the immutable integral slices with (contract() keeps re-laid-out copies of those)
 };
 void triples_plan_free(CCState& s);
+
+// ring.hip: the six o^3 v^3 ring products of a large system's iteration as two launches of the LDS-DMA GEMM
+bool ring_tg_applies(const CCState& s);
+void ring_tg_intermediates(Context& cx, CCState& s);   // I_ovov' / I_voov' from the small terms left in I_ovov / I_voov
+void ring_tg_residual(Context& cx, CCState& s);        // the three ring terms of r2 into ring_R (i,j,a,b) and ring_Y (j,i,a,b)
+void ring_tg_materialize(Context& cx, CCState& s, const Tensor& I_ovov_out, const Tensor& I_voov_out);   // the reference's layout (tests)
+bool ring_live(const CCState& s);        // the intermediates of the current iteration live in the ring buffers
+bool ring_res_live(const CCState& s);    // ... and ring terms of the current residual in ring_R / ring_Y
+void ring_res_clear(CCState& s);
+void ring_invalidate(CCState& s);
+const double* ring_R(const CCState& s);
+const double* ring_Y(const CCState& s);
+void ring_free(Context& cx, CCState& s);
 
 // eri_mo_dev: packed chemist MO integrals ON DEVICE (length neri(o+v)); e_host: orbital energies (host)
 void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, const double* e_host, int diis_nerr);

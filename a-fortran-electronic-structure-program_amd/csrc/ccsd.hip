@@ -156,6 +156,7 @@ void ccsd_free(Context& cx, CCState& s)
     if (cx.plans.size() > 1024 || cx.plan_bytes > ((size_t)4 << 30)) cx.plan_clear();
     cx.drop_scratch();
     triples_plan_free(s);
+    ring_free(cx, s);
     s = CCState();
 }
 
@@ -252,6 +253,10 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     // I_voov (same lane) and the last term of I_ooov_p (explicit event).
     const bool par = lanes_pay(s) && !cx.rec;   // (a recorded sequence is levelled by the compiler of fused.h instead)
     const bool fused = cx.rec != nullptr;
+    // large systems: the three o^3 v^3 products of I_ovov / I_voov in one launch of the LDS-DMA GEMM (ring.hip) -- the small terms are
+    // formed here as always, the products are skipped
+    const bool ring = !par && !fused && ring_tg_applies(s);
+    if (!ring) ring_invalidate(s);
     auto lane = [&](int i) { if (par) cx.use_lane(i); };
     if (par) cx.fork(6);
     lane(0);
@@ -270,7 +275,8 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
         C(1.0, s.w_vvov, "ebma", s.t1, "me", 0.0, s.I_vv, "ba");
     }
     if (!s.sharded) C(-1.0, s.w_oovv, "mneb", s.c, "mnea", ivv_diag ? 0.0 : 1.0, s.I_vv, "ba");
-    else if (v1 > v0) C(-1.0, s.w_oovv, "mneb", sl(s.c, 3), "mnea", 0.0, slice_axis(s.I_vv, 1, v0, v1), "ba");
+    // (split iteration with o == 1: the product form of the t1 term above has written all of I_vv -- this rank's columns add to it)
+    else if (v1 > v0) C(-1.0, s.w_oovv, "mneb", sl(s.c, 3), "mnea", ivv_diag ? 0.0 : 1.0, slice_axis(s.I_vv, 1, v0, v1), "ba");
     lane(0);
     // I_oo_p(j,i)                                                        ccsd.f90:1115-1132
     C(1.0, s.w_oovo, "miej", s.t1, "me", 0.0, s.I_oo_p, "ji");
@@ -302,7 +308,7 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
         C(1.0, s.t1, "je", s.v_vvov, "ebia", 0.0, s.I_ovov, "jbia");
     } else if (v1 > v0) {
         k_copy(cx, s.I_ovov.d + a_off, s.v_ovov.d + a_off, a_cnt);
-        C(-0.5, s.v_oovv, "mibe", sl(s.c, 2), "mjae", 1.0, sl(s.I_ovov, 3), "jbia");   // (o^3 v^3)
+        if (!ring) C(-0.5, s.v_oovv, "mibe", sl(s.c, 2), "mjae", 1.0, sl(s.I_ovov, 3), "jbia");   // (o^3 v^3)
         C(-1.0, s.v_oovo, "mibj", sl(s.t1, 1), "ma", 1.0, sl(s.I_ovov, 3), "jbia");
         C(1.0, s.t1, "je", sl(s.v_vvov, 3), "ebia", 1.0, sl(s.I_ovov, 3), "jbia");
     }
@@ -314,7 +320,7 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     if (ivv_diag && v1 > v0) {
         k_ivv_diag(cx, s.I_vv.d, s.I_ovov.d, s.x_voov.d, s.o, s.v, (int)v0, (int)v1);
         k_axpby(cx, s.I_ovov.d + a_off, 1.0, s.v_ovov.d + a_off, 1.0, a_cnt);
-        C(-0.5, s.v_oovv, "mibe", sl(s.c, 2), "mjae", 1.0, sl(s.I_ovov, 3), "jbia");   // (o^3 v^3)
+        if (!ring) C(-0.5, s.v_oovv, "mibe", sl(s.c, 2), "mjae", 1.0, sl(s.I_ovov, 3), "jbia");   // (o^3 v^3)
         C(-1.0, s.v_oovo, "mibj", sl(s.t1, 1), "ma", 1.0, sl(s.I_ovov, 3), "jbia");
     }
     const int x_voov_ready = par ? cx.mark() : 0;
@@ -324,10 +330,13 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
         // (launch-fused path: x_voov's product a second time, straight into I_voov, instead of adding the finished x_voov a level later)
         if (fused) C(1.0, s.v_vvov, "beia", s.t1, "je", 1.0, s.I_voov, "bjia");
         else k_axpby(cx, s.I_voov.d + a_off, 1.0, s.x_voov.d + a_off, 1.0, a_cnt);
-        C(0.5, s.w_oovv, "imbe", sl(s.t2, 3), "mjea", 1.0, sl(s.I_voov, 3), "bjia");           // (o^3 v^3 each)
-        C(-0.5, s.v_oovv, "imbe", sl(s.c, 2), "mjae", 1.0, sl(s.I_voov, 3), "bjia");
+        if (!ring) {
+            C(0.5, s.w_oovv, "imbe", sl(s.t2, 3), "mjea", 1.0, sl(s.I_voov, 3), "bjia");       // (o^3 v^3 each)
+            C(-0.5, s.v_oovv, "imbe", sl(s.c, 2), "mjae", 1.0, sl(s.I_voov, 3), "bjia");
+        }
         C(-1.0, s.v_oovo, "imbj", sl(s.t1, 1), "ma", 1.0, sl(s.I_voov, 3), "bjia");
     }
+    if (ring) ring_tg_intermediates(cx, s);
     lane(4);
     // (the copy of the amplitudes the DIIS error vector is taken against, ccsd.f90:342-343: nothing writes them before the update
     // at the end of ccsd_amplitudes, so it rides on a lane instead of standing in front of the iteration)
@@ -522,6 +531,9 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     // in three groups; all but the first group of each go into partial buffers that are added after the join
     ccsd_refresh_sharding(cx, s);
     const bool par = lanes_pay(s) && !cx.rec, sh = s.sharded;
+    const bool ring = !par && !cx.rec && !sh && ring_live(s);   // the ring terms through the buffers ccsd_intermediates left (ring.hip)
+    s.partials_live = par;
+    ring_res_clear(s);
     int64_t v0, v1;
     slice_bounds(s, &v0, &v1);
     auto sl = [&](const Tensor& t, int axis) { return slice_axis(t, axis, v0, v1); };
@@ -572,7 +584,9 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     lane(1);
     if (!sh) C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");     // :1673  hole-hole ladder
     lane(2);
-    if (!sh) {
+    if (ring) {
+        ring_tg_residual(cx, s);                                                 // :1680-1695 ring terms, all three
+    } else if (!sh) {
         C(-1.0, s.t2, "mjae", s.I_ovov, "iemb", par ? 0.0 : 1.0, r2b, "ijab");   // :1680-1695 ring terms
         C(-1.0, s.I_ovov, "iema", s.t2, "mjeb", 1.0, r2b, "ijab");
     } else if (v1 > v0) {           // the slice of I_ovov / I_voov this rank built, into the zeroed partial residual
@@ -593,7 +607,7 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
         C(1.0, s.asym, "mief", sl(s.v_vvov, 3), "efma", 1.0, slice_axis(r1s, 1, v0, v1), "ia");
     }
     lane(3);
-    if (!sh) C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
+    if (!sh && !ring) C(1.0, s.asym, "miea", s.I_voov, "ejmb", par ? 0.0 : 1.0, r2c, "ijab");
     if (!open_with_vvov && !sh) C(1.0, s.t1, "ie", s.v_vvov, "baje", 1.0, r2c, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
     if (!sh) C(-1.0, s.t1, "ma", s.z_ooov, "ijmb", 1.0, r2c, "ijab");      // :1705-1715 and the t1-dressed parts of :1700 (ccsd_intermediates)
     if (par) cx.join();   // (the partial residuals r1b, r2b, r2c are added up by the update kernel below)
@@ -606,8 +620,8 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     }
     if (defer_update) return;
     // P(ia/jb), + v_oovv, Jacobi divide                                  ccsd.f90:1720-1728
-    k_t2_update(cx, s.t2.d, s.r2.d, par ? r2b.d : nullptr, par ? r2c.d : nullptr, s.v_oovv.d, s.D2.d, s.pp, s.o, s.v, s.t1.d, s.r1.d,
-                par ? r1b.d : nullptr, s.D1.d);
+    k_t2_update(cx, s.t2.d, s.r2.d, ring ? ring_R(s) : par ? r2b.d : nullptr, par ? r2c.d : nullptr, s.v_oovv.d, s.D2.d, s.pp, s.o, s.v, s.t1.d,
+                s.r1.d, par ? r1b.d : nullptr, s.D1.d, ring ? ring_Y(s) : nullptr);
 }
 
 // The intermediate of ccsd.f90:1255-1272 as a tensor (tests / afesp_ccsd_get_tensor); the iteration never forms it.

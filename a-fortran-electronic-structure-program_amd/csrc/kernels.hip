@@ -95,7 +95,8 @@ __global__ void asym_c_kernel(double* asym, double* c, const double* t1, const d
 // sum_ef c(ij,ef) <ef|ab> satisfies pp(ijab) = pp(jiba), so it is computed for a <= b only and stored packed as
 // PP(i,j,p), p = b(b+1)/2 + a; its contribution to r2(ijab) + r2(jiba) is 2 * 1/2 * pp = PP (ccsd.f90:1669).
 __global__ void t2_update_kernel(double* t2, const double* r2, const double* r2b, const double* r2c, const double* voovv, const double* D2,
-                                 const double* pp, int o, int v, double* t1, const double* r1, const double* r1b, const double* D1)
+                                 const double* pp, int o, int v, double* t1, const double* r1, const double* r1b, const double* D1,
+                                 const double* r2y)
 {
     // (r2b, r2c, r1b: the partial residuals of the laned iteration, null otherwise; t1 = (r1 + r1b) / D1 rides along)
     const int64_t n = (int64_t)o * o * v * v, n1 = (int64_t)o * v;
@@ -112,6 +113,10 @@ __global__ void t2_update_kernel(double* t2, const double* r2, const double* r2b
         double rx = r2[x], ry = r2[y];
         if (r2b) { rx += r2b[x]; ry += r2b[y]; }
         if (r2c) { rx += r2c[x]; ry += r2c[y]; }
+        if (r2y) {   // (held with i and j exchanged: the same 8 o^2 bytes of memory as x resp. y)
+            rx += r2y[j + (int64_t)o * (i + (int64_t)o * (a + (int64_t)v * b))];
+            ry += r2y[i + (int64_t)o * (j + (int64_t)o * (b + (int64_t)v * a))];
+        }
         t2[x] = (rx + ry + pp[lad] + voovv[x]) / D2[x];
         if (x < n1) t1[x] = (r1[x] + (r1b ? r1b[x] : 0.0)) / D1[x];
     }
@@ -463,10 +468,24 @@ void k_asym_c(Context& cx, double* asym, double* c, const double* t1, const doub
     }
     LAUNCH(asym_c_kernel, dim3(grid_for((int64_t)o * o * v * v)), asym, c, t1, t2, o, v);
 }
+__global__ void add_swapped_kernel(double* out, const double* y, int o, int64_t n)
+{
+    GRID_STRIDE(x, n)
+    {
+        const int i = (int)(x % o), j = (int)((x / o) % o);
+        out[x] += y[x + (int64_t)(j - i) * (1 - o)];   // (j + o i) - (i + o j) = (j - i)(1 - o)
+    }
+}
+void k_add_swapped(Context& cx, double* out, const double* y, int o, int v)
+{
+    const int64_t n = (int64_t)o * o * v * v;
+    LAUNCH(add_swapped_kernel, dim3(grid_for(n)), out, y, o, n);
+}
 void k_t2_update(Context& cx, double* t2, const double* r2, const double* r2b, const double* r2c, const double* v_oovv, const double* D2,
-                 const double* pp, int o, int v, double* t1, const double* r1, const double* r1b, const double* D1)
+                 const double* pp, int o, int v, double* t1, const double* r1, const double* r1b, const double* D1, const double* r2y)
 {
     if (cx.rec) {
+        if (r2y) throw Error(2, "k_t2_update: the exchanged partial residual is not part of a recorded sequence");
         const int64_t n2 = (int64_t)o * o * v * v, n1 = (int64_t)o * v, np = (int64_t)o * o * ((int64_t)v * (v + 1) / 2);
         std::vector<FusedRange> rd = {frange(r2, n2), frange(v_oovv, n2), frange(D2, n2), frange(pp, np), frange(r1, n1), frange(D1, n1)};
         if (r2b) rd.push_back(frange(r2b, n2));
@@ -476,7 +495,7 @@ void k_t2_update(Context& cx, double* t2, const double* r2, const double* r2b, c
                        [=](Context& c_) { k_t2_update(c_, t2, r2, r2b, r2c, v_oovv, D2, pp, o, v, t1, r1, r1b, D1); });
         return;
     }
-    LAUNCH(t2_update_kernel, dim3(grid_for((int64_t)o * o * v * v)), t2, r2, r2b, r2c, v_oovv, D2, pp, o, v, t1, r1, r1b, D1);
+    LAUNCH(t2_update_kernel, dim3(grid_for((int64_t)o * o * v * v)), t2, r2, r2b, r2c, v_oovv, D2, pp, o, v, t1, r1, r1b, D1, r2y);
 }
 // r2_full(ijab) = r2(ijab) + 1/2 pp(ijab): the residual before P(ia/jb) (tests / get_tensor) -- the reference's tmp_t2 up to terms that are
 // held as their images under (i <-> j, a <-> b) (ccsd.hip, z_ooov): r2_full(ijab) + r2_full(jiba) is what equals the reference's

@@ -94,8 +94,8 @@ def test_completely_renormalised_triples_match_bundled_outputs(eng, name):
     assert np.max(np.abs(parts - out)) < 1e-12
 
 
-@pytest.mark.parametrize("fused", [1, 0, "large"])
-@pytest.mark.parametrize("o,v", [(4, 9), (12, 72)])
+@pytest.mark.parametrize("fused", [1, 0, "large", "ring"])
+@pytest.mark.parametrize("o,v", [(4, 9), (12, 72), (5, 13)])
 def test_one_iteration_term_by_term(eng, o, v, fused, monkeypatch):
     """Every intermediate and both residuals after one update from non-trivial amplitudes (t1 != 0).  The second size is
     the largest the oracle does in seconds and is past the thresholds where the launcher switches to the kernels config 5
@@ -103,8 +103,11 @@ def test_one_iteration_term_by_term(eng, o, v, fused, monkeypatch):
     the pp-ladder in its symmetric/antisymmetric pair form with M = v(v+1)/2 = 2628 rows.  "large": the single stream of
     whole-tensor products that o^2 v^2 > 2^20 takes (AFESP_SMALL_MAX=0 sends these sizes down it): there the t1 term of I_vv comes
     from the m = i diagonals of the two <eb|ia> products instead of a pass over 2<eb|ma> - <be|ma>."""
-    if fused == "large":
+    if fused in ("large", "ring"):
         monkeypatch.setenv("AFESP_SMALL_MAX", "0")
+        # "ring": the large-system path as config 5 runs it -- the six o^3 v^3 ring products as two launches of the LDS-DMA GEMM
+        # (csrc/ring.hip; from o v = 2048 by itself); "large": the same path with those products on the gather kernel
+        monkeypatch.setenv("AFESP_RING_TG_MIN", "1" if fused == "ring" else "1000000")
         fused = 0
     if o * v > 100:
         from afesp_amd import inputs
