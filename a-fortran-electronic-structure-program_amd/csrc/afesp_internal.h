@@ -233,6 +233,7 @@ struct CCTail {
     int ny, slot, nerr;
     double *coef, *bmat;
     int64_t seq;
+    const double* r2y = nullptr;   // a partial residual held with i and j exchanged (ring.hip), or null
 };
 void k_cc_tail(Context& cx, const CCTail& a);
 // out = sum_j coef[j] x_j with the coefficients handed over by value (the host solved for them)

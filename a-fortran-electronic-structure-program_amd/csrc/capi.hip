@@ -202,6 +202,16 @@ static bool ccsd_iteration_body(afesp_ctx* ctx)   // true: the launch-fused prog
             ccsd_tail_launch(ctx->cx, ctx->cc);
         }))
         return true;
+    // Large systems (one stream, whole-tensor products): the same two-kernel tail -- P(ia/jb) + division, the energy / rms sums and the
+    // DIIS history push in ONE pass over the residual instead of three (update, energy, push: 26 against 23 passes over o^2 v^2 elements at
+    // eight history vectors, and no host wait between the energy and the push); the <= 17 x 17 system is then solved on the host.
+    // AFESP_LARGE_TAIL=0: the three kernels.
+    if (!ccsd_uses_lanes(ctx->cc) && !(getenv("AFESP_LARGE_TAIL") && getenv("AFESP_LARGE_TAIL")[0] == '0')) {
+        ccsd_intermediates(ctx->cx, ctx->cc, true);
+        ccsd_amplitudes(ctx->cx, ctx->cc, true);
+        ccsd_tail_launch(ctx->cx, ctx->cc);
+        return true;
+    }
     ctx->cc.tail_pending = false;
     replay(ctx, ctx->graph_cc, ccsd_uses_lanes(ctx->cc), [&] {
         ccsd_intermediates(ctx->cx, ctx->cc, true);
@@ -812,10 +822,7 @@ int afesp_ccsd_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t
                     k_r2_full(ctx->cx, full, s.r2.d, s.pp, s.o, s.v);
                     add_partial(full, "r2_lane2");
                     add_partial(full, "r2_lane3");
-                    if (ring_res_live(s)) {   // the ring terms of a large system's residual (ring.hip)
-                        k_axpby(ctx->cx, full, 1.0, ring_R(s), 1.0, e.t->size());
-                        k_add_swapped(ctx->cx, full, ring_Y(s), s.o, s.v);
-                    }
+                    if (ring_res_live(s)) k_add_swapped(ctx->cx, full, ring_Y(s), s.o, s.v);   // a ring term of a large system's residual (ring.hip)
                     src = full;
                 } else if (ring_live(s) && (!strcmp(name, "I_ovov") || !strcmp(name, "I_voov"))) {
                     // a large system's iteration holds these two in the layout its ring products read (ring.hip): turned back on request

@@ -68,13 +68,12 @@ void triples_plan_free(CCState& s);
 // ring.hip: the six o^3 v^3 ring products of a large system's iteration as two launches of the LDS-DMA GEMM
 bool ring_tg_applies(const CCState& s);
 void ring_tg_intermediates(Context& cx, CCState& s);   // I_ovov' / I_voov' from the small terms left in I_ovov / I_voov
-void ring_tg_residual(Context& cx, CCState& s);        // the three ring terms of r2 into ring_R (i,j,a,b) and ring_Y (j,i,a,b)
+void ring_tg_residual(Context& cx, CCState& s);        // the three ring terms: two OPEN r2 (i,j,a,b), one into ring_Y (j,i,a,b)
 void ring_tg_materialize(Context& cx, CCState& s, const Tensor& I_ovov_out, const Tensor& I_voov_out);   // the reference's layout (tests)
 bool ring_live(const CCState& s);        // the intermediates of the current iteration live in the ring buffers
-bool ring_res_live(const CCState& s);    // ... and ring terms of the current residual in ring_R / ring_Y
+bool ring_res_live(const CCState& s);    // ... and a ring term of the current residual in ring_Y
 void ring_res_clear(CCState& s);
 void ring_invalidate(CCState& s);
-const double* ring_R(const CCState& s);
 const double* ring_Y(const CCState& s);
 void ring_free(Context& cx, CCState& s);
 

@@ -572,7 +572,12 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     // (large-system path: the streamed product over <ab|ej> opens the residual instead of accumulating into it -- an accumulating
     // launch of tall_kernel fetches the old values at every tile's end)
     const bool open_with_vvov = !par && !cx.rec && !sh;   // (split iteration: that product goes per slice of b into the partial residual, below)
-    if (open_with_vvov) C(1.0, s.t1, "ie", s.v_vvov, "baje", 0.0, s.r2, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
+    // ... and that product is x_voov again: <ba|je> = (bj|ae) = (bj|ea) = <be|ja> (real orbitals), so sum_e t(i,e) <ba|je> = x_voov(b,i,j,a),
+    // which ccsd_intermediates formed from the same t1 -- a transposing copy of o^2 v^2 elements instead of a third pass over the
+    // o v^3 integrals (0.32 -> 0.08 ms at o = 20, v = 200)
+    // (ring.hip: two of the three ring terms open the residual -- the LDS-DMA GEMM stores, it does not accumulate -- and everything else adds to them)
+    if (ring) ring_tg_residual(cx, s);                                              // :1680-1695 ring terms, all three
+    if (open_with_vvov) permute_add(cx, 1.0, s.x_voov, "bija", ring ? 1.0 : 0.0, s.r2, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
     // (split iteration: every term of the T2 residual is evaluated for this rank's slice of b -- or of a, where that is the index the
     // sliced intermediate carries -- into the zeroed partial residual: the replicated residual has no terms of its own)
     if (!sh) {
@@ -585,7 +590,6 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     if (!sh) C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");     // :1673  hole-hole ladder
     lane(2);
     if (ring) {
-        ring_tg_residual(cx, s);                                                 // :1680-1695 ring terms, all three
     } else if (!sh) {
         C(-1.0, s.t2, "mjae", s.I_ovov, "iemb", par ? 0.0 : 1.0, r2b, "ijab");   // :1680-1695 ring terms
         C(-1.0, s.I_ovov, "iema", s.t2, "mjeb", 1.0, r2b, "ijab");
@@ -620,8 +624,8 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     }
     if (defer_update) return;
     // P(ia/jb), + v_oovv, Jacobi divide                                  ccsd.f90:1720-1728
-    k_t2_update(cx, s.t2.d, s.r2.d, ring ? ring_R(s) : par ? r2b.d : nullptr, par ? r2c.d : nullptr, s.v_oovv.d, s.D2.d, s.pp, s.o, s.v, s.t1.d,
-                s.r1.d, par ? r1b.d : nullptr, s.D1.d, ring ? ring_Y(s) : nullptr);
+    k_t2_update(cx, s.t2.d, s.r2.d, par ? r2b.d : nullptr, par ? r2c.d : nullptr, s.v_oovv.d, s.D2.d, s.pp, s.o, s.v, s.t1.d, s.r1.d,
+                par ? r1b.d : nullptr, s.D1.d, ring ? ring_Y(s) : nullptr);
 }
 
 // The intermediate of ccsd.f90:1255-1272 as a tensor (tests / afesp_ccsd_get_tensor); the iteration never forms it.
@@ -641,6 +645,7 @@ void ccsd_tail_launch(Context& cx, CCState& s)
         CCTail a;
         a.t2 = st->t2.d; a.t1 = st->t1.d; a.r2 = st->r2.d; a.r1 = st->r1.d; a.voovv = st->v_oovv.d; a.D2 = st->D2.d; a.D1 = st->D1.d;
         a.pp = st->pp; a.t2_old = st->t2_old.d; a.o = st->o; a.v = st->v;
+        a.r2y = ring_res_live(*st) ? ring_Y(*st) : nullptr;   // (large systems: one ring term lies in a buffer of its own, ring.hip)
         a.nerr = st->nerr;
         a.ny = 0; a.slot = 0;
         a.ht = a.he = nullptr; a.amp_s = a.hist_e = nullptr; a.stride = st->nvec;

@@ -758,9 +758,10 @@ struct TailArgs {
     const double *amp_s, *hist_e;
     int64_t stride;
     int ny, slot;
+    const double* r2y;             // YSW: a partial residual held with i and j exchanged (large systems, ring.hip)
 };
 // NYT = the history rows a thread reads per element (ny rounded up to 0 / 4 / 8 / 16): rows past ny are clamped duplicates
-template <int NYT>
+template <int NYT, bool YSW = false>
 __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p)
 {
     __shared__ double sm[18 * 4];
@@ -782,7 +783,12 @@ __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p
         const int64_t y = j + (int64_t)o * (i + (int64_t)o * (b + (int64_t)v * a));
         const int64_t lad = (a <= b) ? i + (int64_t)o * (j + (int64_t)o * ((int64_t)b * (b + 1) / 2 + a))
                                      : j + (int64_t)o * (i + (int64_t)o * ((int64_t)a * (a + 1) / 2 + b));
-        const double r2x = p.r2[x], r2y = p.r2[y], ppv = p.pp[lad], vx0 = p.voovv[x], d2 = p.D2[x];
+        double r2x = p.r2[x], r2y = p.r2[y];
+        const double ppv = p.pp[lad], vx0 = p.voovv[x], d2 = p.D2[x];
+        if (YSW) {   // (i and j exchanged: the same 8 o^2 bytes of memory as x resp. y)
+            r2x += p.r2y[j + (int64_t)o * (i + (int64_t)o * (a + (int64_t)v * b))];
+            r2y += p.r2y[i + (int64_t)o * (j + (int64_t)o * (b + (int64_t)v * a))];
+        }
         const double ria = p.r1[i + o * a], dia = p.D1[i + o * a], rjb = p.r1[j + o * b], djb = p.D1[j + o * b];
         const double vx = p.voovv[i + (int64_t)o * (j + (int64_t)o * (b + (int64_t)v * a))];
         const double told = p.t2_old[x];
@@ -920,7 +926,14 @@ void k_cc_tail(Context& cx, const CCTail& a)
     TailArgs p;
     p.t2 = a.t2; p.t1 = a.t1; p.r2 = a.r2; p.r1 = a.r1; p.voovv = a.voovv; p.D2 = a.D2; p.D1 = a.D1; p.pp = a.pp; p.t2_old = a.t2_old;
     p.o = a.o; p.v = a.v; p.ht = a.ht; p.he = a.he; p.amp_s = a.amp_s; p.hist_e = a.hist_e; p.stride = a.stride; p.ny = a.ny; p.slot = a.slot;
+    p.r2y = a.r2y;
     const int nblk = (int)grid_for((int64_t)a.o * a.o * a.v * a.v, RED_BLOCKS);   // (only blocks that have elements write partials)
+    if (a.r2y) {
+        if (a.ny == 0) LAUNCH((cc_tail_kernel<0, true>), dim3(nblk), partials(cx), p);
+        else if (a.ny <= 4) LAUNCH((cc_tail_kernel<4, true>), dim3(nblk), partials(cx), p);
+        else if (a.ny <= 8) LAUNCH((cc_tail_kernel<8, true>), dim3(nblk), partials(cx), p);
+        else LAUNCH((cc_tail_kernel<16, true>), dim3(nblk), partials(cx), p);
+    } else
     if (a.ny == 0) LAUNCH(cc_tail_kernel<0>, dim3(nblk), partials(cx), p);
     else if (a.ny <= 4) LAUNCH(cc_tail_kernel<4>, dim3(nblk), partials(cx), p);
     else if (a.ny <= 8) LAUNCH(cc_tail_kernel<8>, dim3(nblk), partials(cx), p);

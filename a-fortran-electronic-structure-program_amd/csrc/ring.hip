@@ -28,8 +28,8 @@ namespace afesp {
 
 struct RingTg {
     int64_t ov = 0, Kc = 0, each = 0;   // rows = columns = summation length o v, padded K, doubles per buffer
-    double* slab = nullptr;             // eleven buffers of `each` doubles
-    double *cp, *t2p, *t2x, *asp, *nIo, *Ivo, *F1, *F2, *F3, *R, *Y;
+    double* slab = nullptr;             // ten buffers of `each` doubles
+    double *cp, *t2p, *t2x, *asp, *nIo, *Ivo, *F1, *F2, *F3, *Y;
     uint32_t* rc32 = nullptr;           // byte offset of row / column x of an operand: 8 Kc x   (ov + 256 entries)
     int64_t *cm1 = nullptr, *cn1 = nullptr, *cm2 = nullptr, *cn2 = nullptr;   // C offsets of L1 / L2 (ov + 128 entries each)
     int64_t* tab_block = nullptr;
@@ -81,9 +81,9 @@ static RingTg* ring_get(Context& cx, CCState& s)
     r->Kc = (r->ov + TG_BK - 1) / TG_BK * TG_BK;
     r->each = r->Kc * r->ov + 2 * TG_BK;   // (+ slack: a K step of the last row may be fetched whole)
     r->each = (r->each + 15) / 16 * 16;
-    r->slab = cx.alloc(11 * r->each);      // zeroed: the K padding of every operand stays zero for ever
-    double** bufs[11] = {&r->cp, &r->t2p, &r->t2x, &r->asp, &r->nIo, &r->Ivo, &r->F1, &r->F2, &r->F3, &r->R, &r->Y};
-    for (int q = 0; q < 11; ++q) *bufs[q] = r->slab + q * r->each;
+    r->slab = cx.alloc(10 * r->each);      // zeroed: the K padding of every operand stays zero for ever
+    double** bufs[10] = {&r->cp, &r->t2p, &r->t2x, &r->asp, &r->nIo, &r->Ivo, &r->F1, &r->F2, &r->F3, &r->Y};
+    for (int q = 0; q < 10; ++q) *bufs[q] = r->slab + q * r->each;
     const int64_t n32 = r->ov + 256, n64 = r->ov + 128;
     int64_t* tab = cx.alloc_i64(4 * n64 + (n32 + 1) / 2 + 8);
     r->cm1 = tab; r->cn1 = tab + n64; r->cm2 = tab + 2 * n64; r->cn2 = tab + 3 * n64;
@@ -110,7 +110,8 @@ static RingTg* ring_get(Context& cx, CCState& s)
     fill(g[0], r->t2p, r->cp, r->F2, r->F3, r->Ivo, r->cn1, 0, 2 * nk1);
     fill(g[1], r->cp, r->cp, r->F1, r->F1, r->nIo, r->cn1, mt * nt, nk1);
     g[2].tile_start = 2 * mt * nt;
-    fill(g[3], r->t2p, r->Ivo, r->nIo, r->asp, r->R, r->cn2, 0, 2 * nk1);
+    // (the two terms with rows (j,b), columns (i,a) open the residual itself: s.r2 lives as long as the state)
+    fill(g[3], r->t2p, r->Ivo, r->nIo, r->asp, s.r2.d, r->cn2, 0, 2 * nk1);
     fill(g[4], r->nIo, r->nIo, r->t2x, r->t2x, r->Y, r->cn2, mt * nt, nk1);
     g[5].tile_start = 2 * mt * nt;
     r->groups = (TgGroup*)cx.alloc((int64_t)(6 * sizeof(TgGroup) / (sizeof(double)) + 1));
@@ -134,7 +135,6 @@ void ring_free(Context& cx, CCState& s)
 bool ring_live(const CCState& s) { return s.ring && ((RingTg*)s.ring)->live; }
 bool ring_res_live(const CCState& s) { return s.ring && ((RingTg*)s.ring)->res_live; }
 void ring_res_clear(CCState& s) { if (s.ring) ((RingTg*)s.ring)->res_live = false; }
-const double* ring_R(const CCState& s) { return ((RingTg*)s.ring)->R; }
 const double* ring_Y(const CCState& s) { return ((RingTg*)s.ring)->Y; }
 
 // a view [K = (m,e) | row pair (p,x)] of one of the slab's buffers, indexed with the labels of the tensor it is copied from
@@ -176,7 +176,7 @@ void ring_tg_intermediates(Context& cx, CCState& s)
     r->live = true;
 }
 
-// the three ring terms of the T2 residual into R(i,j,a,b) and Y (i and j exchanged)
+// the three ring terms of the T2 residual: two into r2(i,j,a,b) itself (stored, not added: call it first), one into Y (i and j exchanged)
 void ring_tg_residual(Context& cx, CCState& s)
 {
     RingTg* r = (RingTg*)s.ring;

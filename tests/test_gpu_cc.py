@@ -70,6 +70,35 @@ def test_molecule_full_path_matches_reference(eng, name):
 
 
 @pytest.mark.parametrize("name", ["n2-cc-pvdz", "f2-cc-pvdz"])
+@pytest.mark.parametrize("ring,tail", [("1", "1"), ("1000000", "1"), ("1", "0")])
+def test_large_system_path_walks_the_reference_iteration_table(eng, name, ring, tail, monkeypatch):
+    """The path config 5 takes (one stream of whole-tensor products; the o^3 v^3 ring products as two launches of the LDS-DMA GEMM,
+    csrc/ring.hip; update + energy + DIIS push in one pass) on the bundled molecules: every CCSD iteration energy and rms of the
+    reference's own els.out (src/ccsd.f90:362-363, 12 decimals), with the ring products on the gather kernel and with the
+    three-kernel tail as well."""
+    monkeypatch.setenv("AFESP_SMALL_MAX", "0")
+    monkeypatch.setenv("AFESP_RING_TG_MIN", ring)
+    monkeypatch.setenv("AFESP_LARGE_TAIL", tail)
+    si, ints, res, gold = molecules.load(name)
+    n, o = ints.nbasis, ints.nel // 2
+    v = n - o
+    eng.do_mp2_spatial(n, o, res.canon_coeff, res.canon_levels, ints.eri, want_eri_mo=False)
+    eng.ccsd_init(o, v, res.canon_levels, None, si.ccsd_diis_n_errmat)
+    nit, en, rm = eng.do_ccsd_spatial(si.ccsd_maxiter, si.ccsd_e_tol, si.ccsd_t_tol)
+    assert nit == gold["cc_iters"][-1][0]
+    for (git, ge, gde, grms) in gold["cc_iters"]:
+        assert abs(en[git] - ge) < 1e-10 and abs(rm[git] - grms) < 1e-10, (git, en[git], ge)
+    assert abs(en[nit] - molecules.SURVEY_GOLD[name]["ccsd_corr"]) < 1e-8
+    # the step-by-step entry points (afesp_ccsd_iterate + afesp_ccsd_diis) walk the same table
+    eng.ccsd_init(o, v, res.canon_levels, None, si.ccsd_diis_n_errmat)
+    eng.ccsd_energy(si.ccsd_e_tol, si.ccsd_t_tol)
+    for (git, ge, gde, grms) in gold["cc_iters"][1:6]:
+        e, r, _ = eng.ccsd_iterate(si.ccsd_e_tol, si.ccsd_t_tol)
+        eng.ccsd_diis()
+        assert abs(e - ge) < 1e-10, (git, e, ge)
+
+
+@pytest.mark.parametrize("name", ["n2-cc-pvdz", "f2-cc-pvdz"])
 def test_completely_renormalised_triples_match_bundled_outputs(eng, name):
     """CR-CCSD[T]/(T) (src/ccsd.f90:2338-2551): the numbers of the reference's bundled CRCCSD(T)_spatial runs."""
     si, ints, res, gold = molecules.load(name)
