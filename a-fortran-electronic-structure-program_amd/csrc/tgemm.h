@@ -51,13 +51,16 @@ constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 16;
 // draw from their own counters; launches of ONE state must be ordered on one stream (the counters are reset in stream order).
 struct TgLaunchState {
     unsigned* tickets = nullptr;
-    int cap = 0;
+    int cap = 0, cap_mixed = 0;
 };
 void tgemm_state_free(TgLaunchState& st);
+// bm = 0: 128-row tiles throughout (tgemm_kernel).  bm = 128 / 96: m-tiles of that many rows, and a tile with at most 96 rows left runs
+// as a 96-row tile -- three of a wave's four accumulator rows, three quarters of the MFMAs (tgemm_mixed_kernel): M = 220 is 128 + 96
+// rows instead of two 128-row tiles; the callers count their tiles with the same bm (and pass it to tgemm_group_m).
 hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngroups, int total_tiles, int max_ntiles, hipStream_t stream,
-                        TgLaunchState& st);
+                        TgLaunchState& st, int bm = 0);
 void preload_tgemm();
 unsigned tgemm_inverse(int d);
-int tgemm_group_m(int M, int max_ntiles);
+int tgemm_group_m(int M, int max_ntiles, int bm = TG_BM);
 
 }  // namespace afesp

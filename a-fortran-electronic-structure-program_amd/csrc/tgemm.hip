@@ -71,6 +71,10 @@ struct TgArgs {
     // So the halves of the grid take turns: in slices of 2^prio_shift x 10 ns of the device-wide clock (s_memrealtime) one half
     // runs at priority 1, then the other -- no communication, and the two workgroups of a CU stay level.  0: off.
     int prio_shift;
+    // MIXED instantiation only: rows per m-tile, 128 or 96.  A tile with at most 96 rows left (every tile when bm = 96, the last one of
+    // bm = 128 when M mod 128 <= 96) runs as a 96-row tile: a wave then owns 48 x 64 = 3 x 4 accumulators, its workgroup's A image has
+    // 96 rows (wave w stages rows 24 w .., fragments of wave row wm start at row 48 wm) and a quarter of the MFMAs is not issued.
+    int bm;
 };
 
 #ifdef TG_STAMPS
@@ -91,7 +95,8 @@ __device__ __forceinline__ int tg_xcd_remap(int b, int nwg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-__global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
+template <bool MIXED>
+__device__ __forceinline__ void tgemm_body(const TgArgs& a)
 {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[TG_LDS];
     const TgProblem& p = a.p;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         const int gsz = min(a.mtiles - first, a.gm), rem = tile - grp * width;
         const unsigned ig = gsz == a.gm ? a.inv_gm : a.inv_gl;
         const int col = ig ? (int)__umulhi((unsigned)rem, ig) : rem;
-        m0 = (first + rem - col * gsz) * TG_BM;
+        m0 = (first + rem - col * gsz) * (MIXED ? a.bm : TG_BM);
         n0 = col * TG_BN;
     };
 
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     const char *fa1 = nullptr, *fa2 = nullptr, *fb1 = nullptr, *fb2 = nullptr;
     unsigned voffA[4], voffB[4];
     int pnk = 0, pnk1 = 0, pmrem = 0, pnrem = 0;
+    int pni = 4, fni = 4, cni = 4;   // (MIXED) fragment rows per wave of the tile entered / fetched / computed: 4, or 3 for a 96-row tile
     int64_t pc0 = 0, fc0 = 0;
     const char *pa1 = nullptr, *pa2 = nullptr, *pb1 = nullptr, *pb2 = nullptr;
     bool pending = false;
@@ -177,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         pb2 = (const char*)(p.B + g->b2);
         pmrem = p.M - m0;
         pnrem = N - n0;
+        if (MIXED) pni = (a.bm == 96 || pmrem <= 96) ? 3 : 4;
         const char* src = wave == 0   ? (const char*)(p.offCm + m0)
                           : wave == 1 ? (const char*)((const int64_t*)(uintptr_t)g->offCn + n0)
                           : wave == 2 ? (const char*)(p.rowA + m0)
@@ -197,14 +204,19 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     // ... and committed after the next barrier (its tables are in LDS): row / column byte offsets of this thread's transfers
     auto commit_tile = [&](int j) {
         const unsigned* sr = reinterpret_cast<const unsigned*>(lds + TG_SIDE + (j % TG_NSLOT) * TG_SLOT + 2048);
-        const int lm = min(TG_BM, pmrem) - 1, ln = min(TG_BN, pnrem) - 1;   // rows / columns beyond M / N fetch the last valid one
+        const int lm = min(MIXED ? 32 * pni : TG_BM, pmrem) - 1, ln = min(TG_BN, pnrem) - 1;   // rows / columns beyond M / N fetch the last valid one
+        // (96-row tile: wave w stages A rows 24 w + 8 q .., so the swizzle parity of a transfer follows w + q; its fourth transfer repeats
+        // the next wave's first one -- same bytes to the same place -- and wave 3's lands behind the image)
+        const int arow = MIXED ? 8 * pni * wave + (lane >> 3) : drow;
+        const int apar = (MIXED && pni == 3) ? (wave & 1) : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int r = drow + 8 * q;
+            const int r = drow + 8 * q, ra = arow + 8 * q;
             const int c = 32 * (r >> 5) + 2 * (r & 15) + ((r >> 4) & 1);   // tile column of B image row r (header: Columns)
-            voffA[q] = sr[min(r, lm)] + ((q & 1) ? dch1 : dch0);
+            voffA[q] = sr[min(ra, lm)] + (((q + apar) & 1) ? dch1 : dch0);
             voffB[q] = sr[256 + min(c, ln)] + ((q & 1) ? dch1 : dch0);
         }
+        fni = pni;
         fnk = pnk; fnk1 = pnk1; fa1 = pa1; fa2 = pa2; fb1 = pb1; fb2 = pb2; fmrem = pmrem; fnrem = pnrem; fc0 = pc0;
         pending = false;
     };
@@ -215,17 +227,18 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     // v_readlane with which hipcc reloads a SPILLED scalar register right in front of the statement -- must not be read by a
     // vector-memory instruction in the next five states, and hipcc pads no hazard of an asm statement)
     const char *dma_ap = nullptr, *dma_bp = nullptr;
-    unsigned dma_dst = 0;
+    unsigned dma_dst = 0, dma_dsta = 0;
     auto dma_setup = [&](int stage) {
         const int k = tg_uni(fkt), k1 = tg_uni(fnk1);
         dma_ap = (const char*)tg_uni64((int64_t)((k < k1) ? fa1 + (int64_t)k * 128 : fa2 + (int64_t)(k - k1) * 128));
         dma_bp = (const char*)tg_uni64((int64_t)((k < k1) ? fb1 + (int64_t)k * 128 : fb2 + (int64_t)(k - k1) * 128));
         dma_dst = (unsigned)tg_uni((int)(lds0 + (unsigned)(stage * TG_STAGE + wave * 4096)));
+        dma_dsta = MIXED ? (unsigned)tg_uni((int)(lds0 + (unsigned)(stage * TG_STAGE + wave * 1024 * fni))) : dma_dst;
     };
 #define TG_DMA(Q)                                                                                                        \
     asm volatile("s_nop %c[nop]\n\ts_add_u32 m0, %[d], %[off]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v], %[p]"         \
                  :                                                                                                       \
-                 : [v] "v"((Q) < 4 ? voffA[(Q) & 3] : voffB[(Q) & 3]), [p] "s"((Q) < 4 ? dma_ap : dma_bp), [d] "s"(dma_dst), \
+                 : [v] "v"((Q) < 4 ? voffA[(Q) & 3] : voffB[(Q) & 3]), [p] "s"((Q) < 4 ? dma_ap : dma_bp), [d] "s"((Q) < 4 ? dma_dsta : dma_dst), \
                    [off] "i"(((Q) < 4 ? 0 : TG_BIMG) + ((Q) & 3) * 1024), [nop] "i"(4)                    \
                  : "memory", "scc")
     // The cursor moves on one step.  When the step is the last one of its tile the next tile is entered BEFORE the step's own
@@ -259,22 +272,25 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
     v2d fa0[4], fb0[4], fa1_[4], fb1_[4];
     // acc[i][j][r] = C(m0 + 64 wm + 16 i + (l >> 4) + 4 r, n0 + 64 wn + col(j, l & 15)); offsets from the tile's slot
-    auto store_tile = [&](int slot, int mrem, int nrem, int64_t c0) {
+    auto store_tile = [&](int slot, int mrem, int nrem, int64_t c0, int ni) {
         double* const Cg = p.C + c0;
         const int64_t* sc = reinterpret_cast<const int64_t*>(lds + TG_SIDE + slot * TG_SLOT);
-        if (mrem >= TG_BM && nrem >= TG_BN && p.c_pairs) {
+        const int wrow = MIXED ? wm * 16 * ni : wm * 64;   // first tile row of this wave
+        if (mrem >= (MIXED ? 32 * ni : TG_BM) && nrem >= TG_BN && p.c_pairs) {
             int64_t cn[2];
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) cn[jj] = sc[128 + wn * 64 + 32 * jj + 2 * fm];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                if (MIXED && i >= ni) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int64_t cm = sc[wm * 64 + 16 * i + 4 * r + ff];
+                    const int64_t cm = sc[wrow + 16 * i + 4 * r + ff];
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj)   // (scalar base + 32-bit offset instead of 64-bit addresses: same time, measured)
                         *reinterpret_cast<v2d*>(Cg + cm + cn[jj]) = (v2d){acc[i][2 * jj][r], acc[i][2 * jj + 1][r]};
                 }
+            }
         } else if (p.c_pairs) {
             // a tile on the edge of C: still 16 bytes per lane where both columns of the pair exist -- single doubles leave every
             // 32-byte sector half written until the other parity's instruction comes, and the L2 fetches such sectors from HBM first
@@ -290,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ml = wm * 64 + 16 * i + 4 * r + ff;
-                    if (ml >= mrem) continue;
+                    const int ml = wrow + 16 * i + 4 * r + ff;
+                    if (ml >= mrem || (MIXED && i >= ni)) continue;
                     const int64_t cm = sc[ml];
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
@@ -311,8 +327,8 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ml = wm * 64 + 16 * i + 4 * r + ff;
-                    if (ml >= mrem) continue;
+                    const int ml = wrow + 16 * i + 4 * r + ff;
+                    if (ml >= mrem || (MIXED && i >= ni)) continue;
                     const int64_t cm = sc[ml];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -349,6 +365,10 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
     commit_tile(0);
     int kt = 0, cj = 0, cur = 0, nk_cur = fnk, nk1_cur = fnk1, mrem_cur = fmrem, nrem_cur = fnrem;
     int64_t c0_cur = fc0;
+    if (MIXED) {
+        cni = fni;
+        if (cni == 3) { rdA0 -= (unsigned)(wm * 2048); rdA1 -= (unsigned)(wm * 2048); rdA1t -= (unsigned)(wm * 2048); }
+    }
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
         fetch_begin(st);
@@ -386,8 +406,24 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
             }
         }
         TG_SB;
+        const bool ni4 = !MIXED || cni == 4;   // (a 96-row tile has no fourth row of accumulators: ONE branch per half step)
+        if (!MIXED) {
 #pragma unroll
-        for (int x = 8; x < 32; ++x) TG_MF(fa0, fb0, x);
+            for (int x = 8; x < 32; ++x) TG_MF(fa0, fb0, x);
+        } else {
+            // (the fourth accumulator row last, under the one branch)
+#pragma unroll
+            for (int x = 8; x < 12; ++x) TG_MF(fa0, fb0, x);
+#pragma unroll
+            for (int x = 16; x < 28; ++x) TG_MF(fa0, fb0, x);
+            TG_SB;
+            if (ni4) {
+#pragma unroll
+                for (int x = 12; x < 16; ++x) TG_MF(fa0, fb0, x);
+#pragma unroll
+                for (int x = 28; x < 32; ++x) TG_MF(fa0, fb0, x);
+            }
+        }
         TG_SB;
 #ifdef TG_STAMPS
         const unsigned long long st_b0 = __builtin_amdgcn_s_memtime();
@@ -415,6 +451,14 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         const int freed = cur;
         cur ^= 1;
         rdA0 ^= TG_STAGE; rdA1 ^= TG_STAGE; rdB0 ^= TG_STAGE; rdB1 ^= TG_STAGE; rdA1t ^= TG_STAGE; rdB1t ^= TG_STAGE;
+        if (MIXED) {
+            // the fragments requested next are the NEXT step's: behind a tile's last step they lie in an image of the next tile's height
+            // (that tile was committed a step ago at the latest, the one after it is not before the next step: fni is the next tile's)
+            if (kt + 1 == nk_cur && fni != cni) {
+                const unsigned d = (unsigned)(wm * 2048 * (fni - cni));
+                rdA0 += d; rdA1 += d; rdA1t += d;
+            }
+        }
 #define TG_B(Q) TG_FRAG(fa0, fb0, rdA0, rdB0, Q); TG_SB; TG_MF(fa1_, fb1_, Q); TG_SB;
         TG_B(0) TG_B(1) TG_B(2) TG_B(3) TG_B(4) TG_B(5) TG_B(6) TG_B(7)
 #undef TG_B
@@ -429,18 +473,40 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
         fetch_begin(freed);
         TG_SB;
 #define TG_C(Q) TG_DMA(Q); TG_SB; TG_MF(fa1_, fb1_, 8 + (Q)); TG_SB;
-        TG_C(0) TG_C(1) TG_C(2) TG_C(3) TG_C(4) TG_C(5) TG_C(6) TG_C(7)
-#undef TG_C
-        if (!ktl) {
+        if (!MIXED) {
+            TG_C(0) TG_C(1) TG_C(2) TG_C(3) TG_C(4) TG_C(5) TG_C(6) TG_C(7)
+            if (!ktl) {
 #pragma unroll
-            for (int x = 16; x < 32; ++x) TG_MF(fa1_, fb1_, x);
+                for (int x = 16; x < 32; ++x) TG_MF(fa1_, fb1_, x);
+            }
+        } else {
+            // (the transfers ride in the gaps of the MFMAs every tile issues: two per gap)
+            TG_DMA(0); TG_SB; TG_DMA(1); TG_SB; TG_MF(fa1_, fb1_, 8); TG_SB;
+            TG_DMA(2); TG_SB; TG_DMA(3); TG_SB; TG_MF(fa1_, fb1_, 9); TG_SB;
+            TG_DMA(4); TG_SB; TG_DMA(5); TG_SB; TG_MF(fa1_, fb1_, 10); TG_SB;
+            TG_DMA(6); TG_SB; TG_DMA(7); TG_SB; TG_MF(fa1_, fb1_, 11); TG_SB;
+            if (ni4) {
+#pragma unroll
+                for (int x = 12; x < 16; ++x) TG_MF(fa1_, fb1_, x);
+            }
+            TG_SB;
+            if (!ktl) {
+#pragma unroll
+                for (int x = 16; x < 28; ++x) TG_MF(fa1_, fb1_, x);
+                TG_SB;
+                if (ni4) {
+#pragma unroll
+                    for (int x = 28; x < 32; ++x) TG_MF(fa1_, fb1_, x);
+                }
+            }
         }
+#undef TG_C
         TG_SB;
         if (++kt == nk_cur) {
 #ifdef TG_STAMPS
             const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
 #endif
-            if (!(a.dbg & 1)) store_tile(cj % TG_NSLOT, mrem_cur, nrem_cur, c0_cur);
+            if (!(a.dbg & 1)) store_tile(cj % TG_NSLOT, mrem_cur, nrem_cur, c0_cur, cni);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -459,6 +525,7 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
             mrem_cur = fmrem;
             nrem_cur = fnrem;
             c0_cur = fc0;
+            if (MIXED) cni = fni;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no transfer may land in LDS that belongs to the next workgroup
@@ -477,13 +544,17 @@ __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a)
 #undef TG_DMA
 }
 
+__global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a) { tgemm_body<false>(a); }
+// ... with 96-row tiles where the rows end (TgArgs::bm): the AO->MO transforms (220 rows = 128 + 96 instead of two 128-row tiles)
+__global__ __launch_bounds__(256, 2) void tgemm_mixed_kernel(TgArgs a) { tgemm_body<true>(a); }
+
 // floor(x / d) == umulhi(x, tgemm_inverse(d)) for x * d < 2^32 (tile ids inside a group and patch widths are far below);
 // 0 stands for d = 1 (no 32-bit factor reproduces x itself)
 unsigned tgemm_inverse(int d) { return d <= 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)d + 1); }
 // a patch of gm m-tiles x all n-tiles of a group = the ~64 tiles one XCD works on in a round
-int tgemm_group_m(int M, int max_ntiles)
+int tgemm_group_m(int M, int max_ntiles, int bm)
 {
-    const int mtiles = (M + TG_BM - 1) / TG_BM;
+    const int mtiles = (M + bm - 1) / bm;
     if (mtiles <= 4) return mtiles;   // few rows: the m-tiles of a column tile side by side (they share its B lines)
     static const int patch = getenv("AFESP_TG_PATCH") ? atoi(getenv("AFESP_TG_PATCH")) : 64;   // tuning knob: tiles per patch
     return std::min(mtiles, std::max(1, (patch + max_ntiles / 2) / std::max(1, max_ntiles)));
@@ -493,6 +564,7 @@ void preload_tgemm()
 {
     hipFuncAttributes at;
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(tgemm_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(tgemm_mixed_kernel));
     (void)hipGetLastError();
 }
 
@@ -503,26 +575,29 @@ void tgemm_state_free(TgLaunchState& st)
 }
 
 hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngroups, int total_tiles, int max_ntiles, hipStream_t stream,
-                        TgLaunchState& st)
+                        TgLaunchState& st, int bm)
 {
     if (p.M <= 0 || ngroups <= 0 || total_tiles <= 0) return hipSuccess;
-    int& cap = st.cap;
+    if (bm != 0 && bm != 96 && bm != TG_BM) return hipErrorInvalidValue;
+    const bool mixed = bm != 0;
+    int& cap = mixed ? st.cap_mixed : st.cap;
     if (cap == 0) {
         int dev = 0, cus = 256, occ = 2;
         if (hipGetDevice(&dev) == hipSuccess) {
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, tgemm_kernel, 256, 0) != hipSuccess || occ <= 0) occ = 2;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mixed ? tgemm_mixed_kernel : tgemm_kernel, 256, 0) != hipSuccess || occ <= 0) occ = 2;
         }
         cap = cus * occ;
     }
     TgArgs a;
     a.p = p;
     a.groups = dev_groups;
-    a.mtiles = (p.M + TG_BM - 1) / TG_BM;
+    a.bm = mixed ? bm : TG_BM;
+    a.mtiles = (p.M + a.bm - 1) / a.bm;
     a.total_tiles = total_tiles;
     static const int dbg_env = getenv("AFESP_TG_DBG") ? atoi(getenv("AFESP_TG_DBG")) : 0;
     a.dbg = dbg_env;
-    a.gm = tgemm_group_m(p.M, max_ntiles);
+    a.gm = tgemm_group_m(p.M, max_ntiles, a.bm);
     a.inv_gm = tgemm_inverse(a.gm);
     a.inv_gl = tgemm_inverse(std::max(1, a.mtiles % a.gm));
     static const int grid_env = getenv("AFESP_TG_GRID") ? atoi(getenv("AFESP_TG_GRID")) : 0;   // diagnostic: fewer workgroups, longer tile streams
@@ -541,7 +616,8 @@ hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngrou
         if (me != hipSuccess) return me;
         a.tickets = st.tickets;
     }
-    hipLaunchKernelGGL(tgemm_kernel, dim3(grid), dim3(256), 0, stream, a);
+    if (mixed) hipLaunchKernelGGL(tgemm_mixed_kernel, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(tgemm_kernel, dim3(grid), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

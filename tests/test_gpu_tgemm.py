@@ -49,3 +49,17 @@ def test_shapes_streams_and_tickets(check_bin, shape):
     pairs = {"TG_PAIRS": 1} if shape[2] % 2 == 0 and shape[3] % 2 == 0 else {}
     for grid in (8, 16, 64):
         _run(check_bin, shape, AFESP_TG_DYNAMIC=2, AFESP_TG_GRID=grid, **pairs)
+
+
+@pytest.mark.parametrize("bm", [128, 96])
+@pytest.mark.parametrize("shape", [(220, 48, 200, 70), (92, 32, 300, 130), (300, 48, 200, 70), (210, 64, 150, 150), (190, 48, 96, 20), (900, 48, 150, 150),
+                                   (224, 32, 256, 128), (97, 32, 130, 40), (40, 16, 10, 10)])
+def test_tiles_of_96_rows_where_the_rows_end(check_bin, shape, bm):
+    """The instantiation with 96-row tiles (TgArgs::bm; the AO->MO transforms' 220 rows = 128 + 96): m-tiles of 128 rows whose last one
+    runs 96 rows high when at most 96 are left, and m-tiles of 96 rows throughout -- tile streams that change height from tile to
+    tile, one tile per workgroup, tiles drawn from the ticket counters, K tails and pair stores."""
+    _run(check_bin, shape, TG_BM=bm)
+    _run(check_bin, shape, TG_BM=bm, AFESP_TG_GRID=3)
+    _run(check_bin, shape, TG_BM=bm, AFESP_TG_GRID=2, TG_KV=shape[1] - 5)
+    if shape[2] % 2 == 0 and shape[3] % 2 == 0:
+        _run(check_bin, shape, TG_BM=bm, TG_PAIRS=1, AFESP_TG_DYNAMIC=2, AFESP_TG_GRID=8)

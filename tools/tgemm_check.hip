@@ -9,12 +9,15 @@
 #include <vector>
 using namespace afesp;
 static TgLaunchState g_tg;   // (one launcher state for this stand-alone program)
+// TG_BM=128 / 96: the instantiation with 96-row tiles where the rows end (tgemm.h); unset: 128-row tiles throughout
+static const int g_bm = getenv("TG_BM") ? atoi(getenv("TG_BM")) : 0;
+static const int g_bme = g_bm ? g_bm : 128;
 
 static int run_big(int argc, char** argv)
 {
     const int M = argc > 2 ? atoi(argv[2]) : 40000, Kc = argc > 3 ? atoi(argv[3]) : 224, N = argc > 4 ? atoi(argv[4]) : 1000;
     const int ng = argc > 5 ? atoi(argv[5]) : 12;
-    const int nk1 = Kc / 16, mt = (M + 127) / 128, nt = (N + 127) / 128;
+    const int nk1 = Kc / 16, mt = (M + g_bme - 1) / g_bme, nt = (N + 127) / 128;
     const size_t na = (size_t)2 * M * Kc, nb = (size_t)2 * ng * N * Kc, nc = (size_t)M * N * ng;
     double *dA, *dB, *dC; uint32_t* d32; int64_t* d64; TgGroup* dg;
     hipMalloc(&dA, na * 8); hipMalloc(&dB, nb * 8); hipMalloc(&dC, nc * 8);
@@ -30,7 +33,7 @@ static int run_big(int argc, char** argv)
     for (int n = 0; n < ng * N; ++n) { t32[(size_t)M + n] = (uint32_t)((size_t)8 * Kc * n); t64[(size_t)M + n] = (n & 1) + (int64_t)2 * M * (n >> 1); }
     hipMemcpy(d32, t32.data(), t32.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d64, t64.data(), t64.size() * 8, hipMemcpyHostToDevice);
     std::vector<TgGroup> g(ng + 1);
-    const int gm = tgemm_group_m(M, nt);
+    const int gm = tgemm_group_m(M, nt, g_bme);
     int tile = 0;
     for (int q = 0; q < ng; ++q) {
         g[q].a1 = 0; g[q].a2 = (int64_t)M * Kc; g[q].b1 = 0; g[q].b2 = (int64_t)ng * N * Kc; g[q].c0 = 0;
@@ -47,7 +50,7 @@ static int run_big(int argc, char** argv)
     for (int q = 0; q < ng; ++q) flop += 2.0 * M * N * 16.0 * g[q].nk;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0, 0);
-        hipError_t e = tgemm_launch(p, dg, ng, tile, nt, 0, g_tg);
+        hipError_t e = tgemm_launch(p, dg, ng, tile, nt, 0, g_tg, g_bm);
         hipEventRecord(e1, 0);
         hipError_t e2 = hipDeviceSynchronize();
         float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
@@ -105,7 +108,7 @@ int main(int argc, char** argv)
     const bool pairs = getenv("TG_PAIRS") != nullptr;
     if (pairs) for (int m = 0; m < M; ++m) offCm[m] = 2 * m;
     for (int n = 0; n < ncol; ++n) { colB[n] = (uint32_t)(8 * Kc * ((n * 7) % ncol)); offCn[n] = pairs ? (n & 1) + (int64_t)2 * M * (n >> 1) : (int64_t)M * n; }   // 7 coprime to ncol assumed
-    const int mt = (M + 127) / 128;
+    const int mt = (M + g_bme - 1) / g_bme;
     uint32_t* d32; int64_t* d64; double *dA, *dB, *dC; TgGroup* dg;
     hipMalloc(&d32, (M + ncol + 256) * 4); hipMalloc(&d64, (M + ncol + 128) * 8);
     hipMalloc(&dA, A.size() * 8); hipMalloc(&dB, B.size() * 8); hipMalloc(&dC, C.size() * 8); hipMalloc(&dg, 3 * sizeof(TgGroup));
@@ -116,7 +119,7 @@ int main(int argc, char** argv)
     TgGroup g[3] = {};
     int mx = 0, tile = 0;
     for (int q = 0; q < 2; ++q) mx = std::max(mx, (Ns[q] + 127) / 128);
-    const int gm = tgemm_group_m(M, mx);
+    const int gm = tgemm_group_m(M, mx, g_bme);
     for (int q = 0; q < 2; ++q) {
         g[q].a1 = 0; g[q].a2 = (int64_t)M * Kc; g[q].b1 = 0; g[q].b2 = (int64_t)ncol * Kc; g[q].c0 = 0;
         g[q].colB = d32 + M + (q ? Ns[0] : 0); g[q].offCn = d64 + M + (q ? Ns[0] : 0);
@@ -128,7 +131,7 @@ int main(int argc, char** argv)
     hipMemcpy(dg, g, sizeof(g), hipMemcpyHostToDevice);
     // (offCn[n] = M n: columns are adjacent only when M == 1; pairs are exercised with TG_PAIRS=1, which lays C out column-pair-major)
     TgProblem p{dA, dB, dC, d32, d64, M, pairs, (Kv - (Kc - 16) + 3) / 4};
-    hipError_t e = tgemm_launch(p, dg, 2, tile, mx, 0, g_tg);
+    hipError_t e = tgemm_launch(p, dg, 2, tile, mx, 0, g_tg, g_bm);
     hipError_t e2 = hipDeviceSynchronize();
     printf("launch %s sync %s tiles %d gm %d\n", hipGetErrorString(e), hipGetErrorString(e2), tile, gm);
     hipMemcpy(C.data(), dC, C.size() * 8, hipMemcpyDeviceToHost);
