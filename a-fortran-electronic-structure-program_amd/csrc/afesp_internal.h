@@ -200,7 +200,14 @@ void k_r2_full(Context& cx, double* out, const double* r2, const double* pp, int
 void k_denominators(Context& cx, double* D1, double* D2, const double* e, int o, int v);
 // symmetric / antisymmetric operands of the pp-ladder (pairs x <= y indexed y(y+1)/2 + x, pairs x < y indexed y(y-1)/2 + x)
 void k_vvvv_sympack_packed(Context& cx, double* vs, double* va, const double* packed, int o, int v, int64_t ks, int64_t ka);
-void k_c_sympack(Context& cx, double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na);
+// half: 1/2 (x(ijef) +- x(ijfe)), 1/4 on e == f (the weights of k_vvvv_sympack_packed: the integral side of a pair-form product)
+void k_c_sympack(Context& cx, double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na, bool half = false);
+// I_oooo(k,l,i,j) += Xs(kl,ij) +- Xa(kl,ij) (+ where k < l and i < j order alike); xs / xa: (kl) x (ij) pairs, leading dimensions ns / na
+void k_oooo_pair_expand_add(Context& cx, double* I, const double* xs, const double* xa, int o, int64_t ns, int64_t na);
+// Is(ij,mn) = 1/2 (I(ijmn) + I(ijnm)) (1/4 on m == n) over i <= j, m <= n;  Ia(ij,mn) = 1/2 (I(ijmn) - I(ijnm)) over i < j, m < n
+void k_oooo_sympack(Context& cx, double* is, double* ia, const double* I, int o, int64_t ns, int64_t na);
+// dst[k0 + r + ld * col] = src[r + ns * col], r < ns, col < ncol: c+-(mn, .) behind V+-(ef, .) in every row of the ladder's operand
+void k_rows_append(Context& cx, double* dst, int64_t ld, int64_t k0, const double* src, int64_t ns, int64_t ncol);
 void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na,
                  int64_t p0 = 0, int64_t p1 = -1);   // rows [p0, p1) of PP only (a rank's share); default: all
 void k_vvx_sympack(Context& cx, double* ws, double* wa, const double* x, int v, int64_t ncol, int64_t ks, int64_t ka);

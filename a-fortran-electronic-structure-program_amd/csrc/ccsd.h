@@ -43,6 +43,13 @@ struct CCState : DiisRing {
     bool pp_sym = false;
     double *pp_vs = nullptr, *pp_va = nullptr, *pp_cs = nullptr, *pp_ca = nullptr, *pp_ps = nullptr, *pp_pa = nullptr;
     int64_t pp_ks = 0, pp_ka = 0, pp_ns = 0, pp_na = 0, pp_kn = 0;   // even leading dimensions of those operands
+    // rows of V+- / W+- are [ V(ef, .) | c+-(mn, .) ]: the hole-hole ladder (ccsd.f90:1673) rides in the pp-ladder's products as ns / na
+    // more summation steps (ccsd_pp_ladder); pp_lds / pp_lda = ks + ns / ka + na are the row strides
+    int64_t pp_lds = 0, pp_lda = 0;
+    double *pp_ts = nullptr, *pp_ta = nullptr;      // t2+-(jk,ef) of the I_ooov_p product (c+- stay packed from I_oooo to the ladder)
+    double *oo_vs = nullptr, *oo_va = nullptr;      // 1/2 (<ij|ef> +- <ij|fe>) over pairs (frozen): I_oooo's c <ij|ef> term in pair form
+    double *oo_xs = nullptr, *oo_xa = nullptr;      // its two results, (kl) x (ij) pairs
+    bool cs_packed = false;                         // pp_cs / pp_ca hold c+- of the current amplitudes (ccsd_intermediates)
     int64_t pp_nm = 0;                                     // rows the row tables cover: max(v(v+1)/2, o v)
     double *ov_ws = nullptr, *ov_wa = nullptr;             // the same split of <ef|ia> (v_vvov) for I_ooov_p, built at init
     Tensor I_vo, I_vv, I_oo_p, I_oo, c, asym, x_voov, I_oooo, I_ovov, I_voov, I_ooov_p;

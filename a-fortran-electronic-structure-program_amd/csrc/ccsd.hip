@@ -81,24 +81,33 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
             auto even = [](int64_t x) { return (x + 1) & ~(int64_t)1; };
             const int64_t npa = V * (V - 1) / 2, ks = even(np), ka = even(npa), ns = even(O * (O + 1) / 2), na = even(O * (O - 1) / 2);
             s.pp_ks = ks; s.pp_ka = ka; s.pp_ns = ns; s.pp_na = na;
-            // (the products of t2 with <ef|ia> for I_ooov_p use the same tables and the same c+- / P+- buffers: rows m = (i,a))
+            // A row of V+- (and of W+-, which shares the row tables) is [ V(ef, .) : ks | c+-(mn, .) : ns ], and c+- has ns more rows
+            // I+-(., mn): the hole-hole ladder (ccsd.f90:1673) as ns / na more summation steps of the same two products (ccsd_pp_ladder)
+            const int64_t lds = ks + ns, lda = ka + na, kx = lds;
+            s.pp_lds = lds; s.pp_lda = lda;
+            // (the products of t2 with <ef|ia> for I_ooov_p use the same tables and the same P+- buffers: rows m = (i,a))
             const int64_t nm = std::max(np, O * V);
             s.pp_nm = nm;
-            s.pp_vs = cx.alloc(ks * np); s.pp_cs = cx.alloc(ns * ks); s.pp_ps = cx.alloc(ns * nm);
-            s.ov_ws = cx.alloc(ks * O * V);
+            s.pp_vs = cx.alloc(lds * np); s.pp_cs = cx.alloc(ns * kx); s.pp_ps = cx.alloc(ns * nm);
+            s.ov_ws = cx.alloc(lds * O * V);
+            s.pp_ts = cx.alloc(ns * ks);
+            s.oo_vs = cx.alloc(ns * ks); s.oo_xs = cx.alloc(ns * ns);
             if (npa > 0 && na > 0) {
-                s.pp_va = cx.alloc(ka * npa); s.pp_ca = cx.alloc(na * ka); s.pp_pa = cx.alloc(na * nm);
-                s.ov_wa = cx.alloc(ka * O * V);
+                s.pp_va = cx.alloc(lda * npa); s.pp_ca = cx.alloc(na * kx); s.pp_pa = cx.alloc(na * nm);
+                s.ov_wa = cx.alloc(lda * O * V);
+                s.pp_ta = cx.alloc(na * ka);
+                s.oo_va = cx.alloc(na * ka); s.oo_xa = cx.alloc(na * na);
             }
-            k_vvvv_sympack_packed(cx, s.pp_vs, s.pp_va, eri_mo_dev, o, v, ks, ka);
-            k_vvx_sympack(cx, s.ov_ws, s.ov_wa, s.v_vvov.d, v, O * V, ks, ka);
-            // [ x (k or n) | ks*m | ka*m | ns*k | na*k | ns*m | na*m ]: entries beyond the antisymmetric extents unused
-            s.pp_kn = std::max(ks, ns);
+            k_vvvv_sympack_packed(cx, s.pp_vs, s.pp_va, eri_mo_dev, o, v, lds, lda);
+            k_vvx_sympack(cx, s.ov_ws, s.ov_wa, s.v_vvov.d, v, O * V, lds, lda);
+            k_c_sympack(cx, s.oo_vs, s.oo_va, s.v_oovv.d, s.o, s.v, ns, na, true);   // 1/2 (<ij|ef> +- <ij|fe>), 1/4 on e == f
+            // [ x (k or n) | lds*m | lda*m | ns*k | na*k | ns*m | na*m ]: entries beyond the antisymmetric extents unused
+            s.pp_kn = kx;
             for (int64_t k = 0; k < s.pp_kn; ++k) tab.push_back(k);
-            for (int64_t m = 0; m < nm; ++m) tab.push_back(ks * m);
-            for (int64_t m = 0; m < nm; ++m) tab.push_back(ka * m);
-            for (int64_t k = 0; k < ks; ++k) tab.push_back(ns * k);
-            for (int64_t k = 0; k < ks; ++k) tab.push_back(na * k);
+            for (int64_t m = 0; m < nm; ++m) tab.push_back(lds * m);
+            for (int64_t m = 0; m < nm; ++m) tab.push_back(lda * m);
+            for (int64_t k = 0; k < kx; ++k) tab.push_back(ns * k);
+            for (int64_t k = 0; k < kx; ++k) tab.push_back(na * k);
             for (int64_t m = 0; m < nm; ++m) tab.push_back(ns * m);
             for (int64_t m = 0; m < nm; ++m) tab.push_back(na * m);
         }
@@ -147,7 +156,7 @@ void ccsd_free(Context& cx, CCState& s)
                       s.w_oovo.d, s.D1.d, s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.I_vo.d, s.I_vv.d, s.I_oo_p.d, s.I_oo.d, s.c.d,
                       s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_ooov_p.d, s.z_ooov.d, s.amp_s, s.hist_t,
                       s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d, s.pp, (double*)s.pp_tab, s.pp_vs, s.pp_va, s.pp_cs,
-                      s.pp_ca, s.pp_ps, s.pp_pa, s.bmat, s.ov_ws, s.ov_wa};
+                      s.pp_ca, s.pp_ps, s.pp_pa, s.bmat, s.ov_ws, s.ov_wa, s.pp_ts, s.pp_ta, s.oo_vs, s.oo_va, s.oo_xs, s.oo_xa};
     for (double* b : bufs) cx.release(b);
     // Contraction plans are keyed by shape and stay valid for the life of the context (the AO->MO plans carry tables of
     // n^2 npair entries: rebuilding them costs a quarter of a second at n = 220), so a new system of the same extents finds
@@ -180,6 +189,7 @@ void diis_save(Context& cx, DiisRing& s)
 void ccsd_diis_save(Context& cx, CCState& s) { diis_save(cx, s); }
 
 static bool lanes_pay(const CCState& s);
+static void ccsd_oooo_pair_form(Context& cx, CCState& s);
 
 // Lanes pay when a launch cannot fill the device anyway: o^2 v^2 up to 2^20 elements (H2O/cc-pVTZ: 70 225).
 bool ccsd_uses_lanes(const CCState& s) { return lanes_pay(s); }
@@ -294,7 +304,8 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     lane(1);
     // I_oooo(k,l,i,j)                                                    ccsd.f90:1139-1156
     k_copy(cx, s.I_oooo.d, s.v_oooo.d, s.I_oooo.size());
-    C(1.0, s.c, "klef", s.v_oovv, "ijef", 1.0, s.I_oooo, "klij");
+    if (s.pp_sym && !par && !fused) ccsd_oooo_pair_form(cx, s);   // c(kl,ef) <ij|ef> over pair indices: an eighth of the multiply-adds
+    else C(1.0, s.c, "klef", s.v_oovv, "ijef", 1.0, s.I_oooo, "klij");
     C(1.0, s.t1, "ke", s.v_oovo, "ilej", 1.0, s.I_oooo, "klij");
     C(1.0, s.t1, "le", s.v_oovo, "jkei", 1.0, s.I_oooo, "klij");
     lane(2);
@@ -431,6 +442,36 @@ static void pp_b_range(const CCState& s, int64_t* b0, int64_t* b1)
     *b1 = s.sh_rank + 1 == s.sh_world ? V : std::min(V, cut(s.sh_rank + 1));
 }
 
+// I_oooo(k,l,i,j) += sum_ef c(kl,ef) <ij|ef> (ccsd.f90:1139-1156) over pair indices: X(klij) = Xs + Xa for k <= l, i <= j (and
+// X(lkij) = X(klji) = Xs - Xa), Xs = sum_{e<=f} c+(kl,ef) vs(ij,ef), Xa = sum_{e<f} c-(kl,ef) va(ij,ef) with vs / va = 1/2 (<ij|ef> +- <ij|fe>)
+// built once.  Both operands are pair-packed (128 MB in all at o = 20, v = 200 against 256 MB) and the multiply-adds an eighth of the
+// plain product's: 0.36 -> 0.08 ms.  c+- stay packed for the pp-ladder (s.cs_packed).
+static void ccsd_oooo_pair_form(Context& cx, CCState& s)
+{
+    const int64_t ks = s.pp_ks, ka = s.pp_ka, ns = s.pp_ns, na = s.pp_na, nm = s.pp_nm, kx = s.pp_lds;
+    const int64_t* t = s.pp_tab;
+    const int64_t* u = t + s.pp_kn;
+    k_c_sympack(cx, s.pp_cs, s.pp_ca, s.c.d, s.o, s.v, ns, na);
+    s.cs_packed = true;
+    GettProblem gp;
+    gp.alpha = 1.0; gp.beta = 0.0;
+    gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
+    gp.a_kcontig = false; gp.b_kcontig = false;
+    gp.wide = true;
+    gp.offAm = gp.offBn = gp.offCm = t;
+    gp.A = s.pp_cs; gp.B = s.oo_vs; gp.C = s.oo_xs;
+    gp.offAk = gp.offBk = u + 2 * nm; gp.offCn = u + 2 * nm + 2 * kx;
+    gp.M = gp.N = (int)ns; gp.K = (int)ks;
+    AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+    if (s.pp_pa) {
+        gp.A = s.pp_ca; gp.B = s.oo_va; gp.C = s.oo_xa;
+        gp.offAk = gp.offBk = u + 2 * nm + kx; gp.offCn = u + 3 * nm + 2 * kx;
+        gp.M = gp.N = (int)na; gp.K = (int)ka;
+        AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
+    }
+    k_oooo_pair_expand_add(cx, s.I_oooo.d, s.oo_xs, s.pp_pa ? s.oo_xa : nullptr, s.o, ns, na);
+}
+
 void ccsd_pp_ladder(Context& cx, CCState& s)
 {
     const int64_t O = s.o, V = s.v, np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
@@ -452,27 +493,39 @@ void ccsd_pp_ladder(Context& cx, CCState& s)
         else if (p1 > p0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
         return;
     }
-    const int64_t npa = V * (V - 1) / 2, ks = s.pp_ks, ka = s.pp_ka, ns = s.pp_ns, na = s.pp_na, nm = s.pp_nm;
+    const int64_t npa = V * (V - 1) / 2, ks = s.pp_ks, ka = s.pp_ka, ns = s.pp_ns, na = s.pp_na, nm = s.pp_nm, kx = s.pp_lds;
     const int64_t* t = s.pp_tab;
-    const int64_t* u = t + s.pp_kn;   // [ ks*m | ka*m | ns*k | na*k | ns*m | na*m ], nm rows each
-    k_c_sympack(cx, s.pp_cs, s.pp_ca, s.c.d, s.o, s.v, ns, na);
+    const int64_t* u = t + s.pp_kn;   // [ lds*m | lda*m | ns*k | na*k | ns*m | na*m ]: nm, nm, kx, kx, nm, nm entries
+    if (!s.cs_packed) k_c_sympack(cx, s.pp_cs, s.pp_ca, s.c.d, s.o, s.v, ns, na);   // (a large system's I_oooo has packed them already)
+    s.cs_packed = false;
+    // The hole-hole ladder 1/2 I_oooo(ijmn) c(mnab) (ccsd.f90:1673) has the symmetry of the pp-ladder and the same pair decomposition
+    // over (m,n): hh(ij,ab) = sum_{m<=n} Is(ij,mn) c+(mn,ab) + sum_{m<n} Ia(ij,mn) c-(mn,ab) with Is / Ia = 1/2 (I(ijmn) +- I(ijnm)).  So it
+    // rides in the two products below as ns / na more summation steps: c+-(mn, .) behind V+-(ef, .) in every row, Is / Ia behind
+    // c+-(., ef) -- 2 x 210 x 20100 x 210 multiply-adds in a launch that is running anyway instead of a product over o^2 x o^2 x v^2
+    // (0.29 ms at o = 20, v = 200) and a pass over the residual.
+    const bool fold = !cx.rec && !s.sharded && p0 == 0 && p1 == np;
+    if (fold) {
+        k_rows_append(cx, s.pp_vs, s.pp_lds, ks, s.pp_cs, ns, np);
+        if (s.pp_pa) k_rows_append(cx, s.pp_va, s.pp_lda, ka, s.pp_ca, na, npa);
+        k_oooo_sympack(cx, s.pp_cs + ns * ks, s.pp_pa ? s.pp_ca + na * ka : nullptr, s.I_oooo.d, s.o, ns, na);
+    }
     gp.wide = true;
     gp.offAk = t; gp.offBn = gp.offCn = t;
     gp.A = s.pp_vs; gp.B = s.pp_cs; gp.C = s.pp_ps;
-    gp.offAm = u + p0; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * ks + p0;
-    gp.M = (int)(p1 - p0); gp.N = (int)ns; gp.K = (int)ks;
+    gp.offAm = u + p0; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * kx + p0;
+    gp.M = (int)(p1 - p0); gp.N = (int)ns; gp.K = (int)(fold ? ks + ns : ks);
     const char* fs = getenv("AFESP_PP_SPLIT");   // tuning knob: K slices of the two pair products (0 = the launcher's own choice)
     const int force_split = fs ? atoi(fs) : 0;
     // tuning knob AFESP_PP_TILES="tm,tn,split,tm,tn,split": tile codes and K slices of the symmetric / the antisymmetric product
     int pt[6] = {0, 0, force_split, 0, 0, force_split};
     if (const char* e = getenv("AFESP_PP_TILES")) sscanf(e, "%d,%d,%d,%d,%d,%d", &pt[0], &pt[1], &pt[2], &pt[3], &pt[4], &pt[5]);
-    if (cx.rec) cx.rec->product(gp, ks * np, ns * ks, ns * np);
+    if (cx.rec) cx.rec->product(gp, s.pp_lds * np, ns * ks, ns * np);
     else if (p1 > p0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, pt[2], pt[0], pt[1]));
     if (s.pp_pa) {
         gp.A = s.pp_va; gp.B = s.pp_ca; gp.C = s.pp_pa;
-        gp.offAm = u + nm + q0; gp.offBk = u + 2 * nm + ks; gp.offCm = u + 3 * nm + 2 * ks + q0;
-        gp.M = (int)(q1 - q0); gp.N = (int)na; gp.K = (int)ka;
-        if (cx.rec) cx.rec->product(gp, ka * npa, na * ka, na * npa);
+        gp.offAm = u + nm + q0; gp.offBk = u + 2 * nm + kx; gp.offCm = u + 3 * nm + 2 * kx + q0;
+        gp.M = (int)(q1 - q0); gp.N = (int)na; gp.K = (int)(fold ? ka + na : ka);
+        if (cx.rec) cx.rec->product(gp, s.pp_lda * npa, na * ka, na * npa);
         else if (q1 > q0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, pt[5], pt[3], pt[4]));
     }
     (void)npa;
@@ -492,7 +545,8 @@ void ccsd_ooov_pair_form(Context& cx, CCState& s, double* out, int64_t a0, int64
                   nm = s.pp_nm, M = O * (a1 - a0), m0 = O * a0;
     const int64_t* t = s.pp_tab;
     const int64_t* u = t + s.pp_kn;
-    k_c_sympack(cx, s.pp_cs, s.pp_ca, s.t2.d, s.o, s.v, ns, na);
+    k_c_sympack(cx, s.pp_ts, s.pp_ta, s.t2.d, s.o, s.v, ns, na);   // (buffers of its own: c+- stay packed from I_oooo to the ladder)
+    const int64_t kx = s.pp_lds;   // rows of the "ns*k" / "na*k" tables
     GettProblem gp;
     gp.alpha = 1.0; gp.beta = 0.0;
     gp.nbatch = 1; gp.batchA = gp.batchB = gp.batchC = nullptr;
@@ -507,16 +561,16 @@ void ccsd_ooov_pair_form(Context& cx, CCState& s, double* out, int64_t a0, int64
         while (sp > 1 && ksteps / sp < 32) --sp;
         return (int)std::max<int64_t>(1, std::min<int64_t>(sp, 32));
     };
-    gp.A = s.ov_ws; gp.B = s.pp_cs; gp.C = s.pp_ps;
-    gp.offAm = u + m0; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * ks + m0;
+    gp.A = s.ov_ws; gp.B = s.pp_ts; gp.C = s.pp_ps;
+    gp.offAm = u + m0; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * kx + m0;
     gp.M = (int)M; gp.N = (int)ns; gp.K = (int)ks;
-    if (cx.rec) cx.rec->product(gp, ks * O * V, ns * ks, ns * O * V);
+    if (cx.rec) cx.rec->product(gp, s.pp_lds * O * V, ns * ks, ns * O * V);
     else AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, slices(ns, ks)));
     if (s.ov_wa) {
-        gp.A = s.ov_wa; gp.B = s.pp_ca; gp.C = s.pp_pa;
-        gp.offAm = u + nm + m0; gp.offBk = u + 2 * nm + ks; gp.offCm = u + 3 * nm + 2 * ks + m0;
+        gp.A = s.ov_wa; gp.B = s.pp_ta; gp.C = s.pp_pa;
+        gp.offAm = u + nm + m0; gp.offBk = u + 2 * nm + kx; gp.offCm = u + 3 * nm + 2 * kx + m0;
         gp.M = (int)M; gp.N = (int)na; gp.K = (int)ka;
-        if (cx.rec) cx.rec->product(gp, ka * O * V, na * ka, na * O * V);
+        if (cx.rec) cx.rec->product(gp, s.pp_lda * O * V, na * ka, na * O * V);
         else AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, slices(na, ka)));
     }
     (void)np; (void)npa;
@@ -587,7 +641,8 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     lane(4);
     ccsd_pp_ladder(cx, s);                                                 // :1669  particle-particle ladder
     lane(1);
-    if (!sh) C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");     // :1673  hole-hole ladder
+    // :1673  hole-hole ladder (the pair form of the pp-ladder carries it along: ccsd_pp_ladder)
+    if (!sh && !(s.pp_sym && !cx.rec)) C(0.5, s.I_oooo, "ijmn", s.c, "mnab", 1.0, s.r2, "ijab");
     lane(2);
     if (ring) {
     } else if (!sh) {

@@ -539,7 +539,7 @@ __global__ void vvvv_sympack_packed_kernel(double* vs, double* va, const double*
     }
 }
 // cs(ij,ef) = c(ijef) + c(ijfe) over i <= j, e <= f;  ca(ij,ef) = c(ijef) - c(ijfe) over i < j, e < f; leading dimensions ns / na
-__global__ void c_sympack_kernel(double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na)
+__global__ void c_sympack_kernel(double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na, int half)
 {
     const int64_t O = o, V = v, n = O * O * V * V;
     GRID_STRIDE(x, n)
@@ -551,8 +551,44 @@ __global__ void c_sympack_kernel(double* cs, double* ca, const double* c, int o,
         const int e = (int)(r % V), f = (int)(r / V);
         if (i > j || e > f) continue;
         const double p = c[x], q = c[i + O * (j + O * (f + V * e))];
-        cs[(int64_t)j * (j + 1) / 2 + i + ns * ((int64_t)f * (f + 1) / 2 + e)] = p + q;
-        if (ca && i < j && e < f) ca[(int64_t)j * (j - 1) / 2 + i + na * ((int64_t)f * (f - 1) / 2 + e)] = p - q;
+        const double ws = half ? (e == f ? 0.25 : 0.5) : 1.0, wa = half ? 0.5 : 1.0;
+        cs[(int64_t)j * (j + 1) / 2 + i + ns * ((int64_t)f * (f + 1) / 2 + e)] = ws * (p + q);
+        if (ca && i < j && e < f) ca[(int64_t)j * (j - 1) / 2 + i + na * ((int64_t)f * (f - 1) / 2 + e)] = wa * (p - q);
+    }
+}
+__global__ void oooo_pair_expand_add_kernel(double* I, const double* xs, const double* xa, int o, int64_t ns, int64_t na)
+{
+    const int64_t O = o, n = O * O * O * O;
+    GRID_STRIDE(x, n)
+    {
+        const int k = (int)(x % O), l = (int)((x / O) % O), i = (int)((x / (O * O)) % O), j = (int)(x / (O * O * O));
+        const int kl_lo = k < l ? k : l, kl_hi = k < l ? l : k, ij_lo = i < j ? i : j, ij_hi = i < j ? j : i;
+        double val = xs[(int64_t)kl_hi * (kl_hi + 1) / 2 + kl_lo + ns * ((int64_t)ij_hi * (ij_hi + 1) / 2 + ij_lo)];
+        if (xa && k != l && i != j) {
+            const double w = xa[(int64_t)kl_hi * (kl_hi - 1) / 2 + kl_lo + na * ((int64_t)ij_hi * (ij_hi - 1) / 2 + ij_lo)];
+            val += ((k < l) == (i < j)) ? w : -w;
+        }
+        I[x] += val;
+    }
+}
+__global__ void oooo_sympack_kernel(double* is, double* ia, const double* I, int o, int64_t ns, int64_t na)
+{
+    const int64_t O = o, n = O * O * O * O;
+    GRID_STRIDE(x, n)
+    {
+        const int i = (int)(x % O), j = (int)((x / O) % O), m = (int)((x / (O * O)) % O), nn = (int)(x / (O * O * O));
+        if (i > j || m > nn) continue;
+        const double p = I[x], q = I[i + O * (j + O * (nn + O * m))];
+        is[(int64_t)j * (j + 1) / 2 + i + ns * ((int64_t)nn * (nn + 1) / 2 + m)] = (m == nn ? 0.25 : 0.5) * (p + q);
+        if (ia && i < j && m < nn) ia[(int64_t)j * (j - 1) / 2 + i + na * ((int64_t)nn * (nn - 1) / 2 + m)] = 0.5 * (p - q);
+    }
+}
+__global__ void rows_append_kernel(double* dst, int64_t ld, int64_t k0, const double* src, int64_t ns, int64_t n)
+{
+    GRID_STRIDE(x, n)
+    {
+        const int64_t r = x % ns, col = x / ns;
+        dst[k0 + r + ld * col] = src[x];
     }
 }
 // PP(i,j,p) = Ps(ij,p) +/- Pa(ij,p): + for i < j, - for i > j (p over a <= b; Pa vanishes on i == j and on a == b)
@@ -627,16 +663,32 @@ void k_vvvv_sympack_packed(Context& cx, double* vs, double* va, const double* pa
 {
     LAUNCH(vvvv_sympack_packed_kernel, dim3(grid_for((int64_t)v * v * ((int64_t)v * (v + 1) / 2), 65536)), vs, va, packed, o, v, ks, ka);
 }
-void k_c_sympack(Context& cx, double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na)
+void k_oooo_pair_expand_add(Context& cx, double* I, const double* xs, const double* xa, int o, int64_t ns, int64_t na)
+{
+    if (cx.rec) throw Error(2, "k_oooo_pair_expand_add: not part of a recorded sequence");
+    LAUNCH(oooo_pair_expand_add_kernel, dim3(grid_for((int64_t)o * o * o * o)), I, xs, xa, o, ns, na);
+}
+void k_oooo_sympack(Context& cx, double* is, double* ia, const double* I, int o, int64_t ns, int64_t na)
+{
+    if (cx.rec) throw Error(2, "k_oooo_sympack: not part of a recorded sequence");
+    LAUNCH(oooo_sympack_kernel, dim3(grid_for((int64_t)o * o * o * o)), is, ia, I, o, ns, na);
+}
+void k_rows_append(Context& cx, double* dst, int64_t ld, int64_t k0, const double* src, int64_t ns, int64_t ncol)
+{
+    if (cx.rec) throw Error(2, "k_rows_append: not part of a recorded sequence");
+    if (ns * ncol > 0) LAUNCH(rows_append_kernel, dim3(grid_for(ns * ncol)), dst, ld, k0, src, ns, ns * ncol);
+}
+void k_c_sympack(Context& cx, double* cs, double* ca, const double* c, int o, int v, int64_t ns, int64_t na, bool half)
 {
     if (cx.rec) {
+        if (half) throw Error(2, "k_c_sympack: the weighted form is not part of a recorded sequence");
         const int64_t np = (int64_t)v * (v + 1) / 2, npa = (int64_t)v * (v - 1) / 2, ks = (np + 1) & ~(int64_t)1, ka = (npa + 1) & ~(int64_t)1;
         std::vector<FusedRange> wr = {frange(cs, ns * ks)};
         if (ca) wr.push_back(frange(ca, na * ka));
         cx.rec->opaque({frange(c, (int64_t)o * o * v * v)}, wr, [=](Context& c_) { k_c_sympack(c_, cs, ca, c, o, v, ns, na); });
         return;
     }
-    LAUNCH(c_sympack_kernel, dim3(grid_for((int64_t)o * o * v * v)), cs, ca, c, o, v, ns, na);
+    LAUNCH(c_sympack_kernel, dim3(grid_for((int64_t)o * o * v * v)), cs, ca, c, o, v, ns, na, half ? 1 : 0);
 }
 void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na, int64_t p0, int64_t p1)
 {
