@@ -74,6 +74,7 @@ void triples_plan_free(CCState& s);
 
 // ring.hip: the six o^3 v^3 ring products of a large system's iteration as two launches of the LDS-DMA GEMM
 bool ring_tg_applies(const CCState& s);
+bool ring_tg_pack(Context& cx, CCState& s);            // asym_t2, c and the amplitudes' [K | row] copies in one pass (false: run k_asym_c)
 void ring_tg_intermediates(Context& cx, CCState& s);   // I_ovov' / I_voov' from the small terms left in I_ovov / I_voov
 void ring_tg_residual(Context& cx, CCState& s);        // the three ring terms: two OPEN r2 (i,j,a,b), one into ring_Y (j,i,a,b)
 void ring_tg_materialize(Context& cx, CCState& s, const Tensor& I_ovov_out, const Tensor& I_voov_out);   // the reference's layout (tests)

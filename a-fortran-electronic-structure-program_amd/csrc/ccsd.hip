@@ -257,7 +257,9 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     slice_bounds(s, &v0, &v1);
     auto sl = [&](const Tensor& t, int axis) { return slice_axis(t, axis, v0, v1); };
     // asym_t2, c_oovv                                                    ccsd.f90:1063-1079
-    k_asym_c(cx, s.asym.d, s.c.d, s.t1.d, s.t2.d, s.o, s.v);
+    // (large systems: together with the copies of the amplitudes that the ring products read, ring.hip)
+    if (!(lanes_pay(s) || cx.rec) && ring_tg_applies(s) && ring_tg_pack(cx, s)) {}
+    else k_asym_c(cx, s.asym.d, s.c.d, s.t1.d, s.t2.d, s.o, s.v);
     // Small systems are bound by the latency of ~100 dependent launches: the independent chains below then run on four
     // lanes (streams) side by side.  Each intermediate is built entirely on one lane; I_vo feeds I_oo (same lane), x_voov feeds
     // I_voov (same lane) and the last term of I_ooov_p (explicit event).
@@ -266,7 +268,7 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     // large systems: the three o^3 v^3 products of I_ovov / I_voov in one launch of the LDS-DMA GEMM (ring.hip) -- the small terms are
     // formed here as always, the products are skipped
     const bool ring = !par && !fused && ring_tg_applies(s);
-    if (!ring) ring_invalidate(s);
+    if (!ring) ring_invalidate(s);   // (after the pack above: `ring` is the condition it ran under)
     auto lane = [&](int i) { if (par) cx.use_lane(i); };
     if (par) cx.fork(6);
     lane(0);

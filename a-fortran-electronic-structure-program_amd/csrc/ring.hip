@@ -37,6 +37,7 @@ struct RingTg {
     int tiles = 0, mx = 0;
     bool pairs2 = false;
     bool frozen_built = false;
+    bool packed = false;                // the amplitudes' four copies are those of the current t1 / t2 (ring_tg_pack)
     bool live = false;                  // I_ovov' / I_voov' hold the current intermediates (the reference-layout tensors only their small terms)
     bool res_live = false;              // R / Y hold ring terms of the current residual
 };
@@ -69,6 +70,73 @@ bool ring_tg_applies(const CCState& s)
     const int64_t min_ov = m ? (int64_t)atoll(m) : (int64_t)2048;
     const int64_t ov = (int64_t)s.o * s.v, Kc = (ov + TG_BK - 1) / TG_BK * TG_BK;
     return !s.sharded && ov >= min_ov && ov >= 2 * TG_BK && 8 * Kc * ov < ((int64_t)1 << 32) - 4096;
+}
+
+// asym_t2 = 2 t2 - t2(jiab), c = t2 + t1 t1 (ccsd.f90:1063-1079) AND the four [K | row] copies the two launches read, from ONE pass
+// over t2: a workgroup stages the o^2 x P x Q block t2(:,:,p0..,q0..) in LDS (reads: runs of o^2 doubles) and writes it out in the
+// three orders -- the reference's (asym, c), [(m,p) | (j,q)] (t2', asym': runs of o P doubles) and [(m,q) | (j,p)] (t2x, c': o Q).
+// 8 (1 + 6) o^2 v^2 bytes instead of 8 (3 + 8) for k_asym_c and four permuting copies.
+struct RingPackArgs {
+    const double *t1, *t2;
+    double *asym, *c, *cp, *t2p, *t2x, *asp;
+    int o, v, P, Q;
+    int64_t Kc;
+    unsigned inv_o, inv_oo;   // tgemm_inverse(o), tgemm_inverse(o * o)
+};
+__device__ __forceinline__ unsigned ring_div(unsigned x, unsigned inv) { return inv ? __umulhi(x, inv) : x; }
+
+__global__ __launch_bounds__(256) void ring_pack_kernel(RingPackArgs a)
+{
+    extern __shared__ double tile[];   // t2(m, j, p0 + pp, q0 + qq) at (m + o j) + o^2 (pp + P qq)
+    const int o = a.o, v = a.v, oo = o * o, P = a.P, Q = a.Q;
+    const int tiles_p = (v + P - 1) / P;
+    const int p0 = ((int)blockIdx.x % tiles_p) * P, q0 = ((int)blockIdx.x / tiles_p) * Q;
+    const int np = min(P, v - p0), nq = min(Q, v - q0), n = oo * np * nq;
+    const unsigned inv_np = np == 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)np + 1);
+    const int64_t O = o, V = v;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const int r = (int)ring_div((unsigned)idx, a.inv_oo), mj = idx - r * oo;
+        const int qq = (int)ring_div((unsigned)r, inv_np), pp = r - qq * np;
+        tile[mj + oo * (pp + P * qq)] = a.t2[mj + O * O * ((p0 + pp) + V * (q0 + qq))];
+    }
+    __syncthreads();
+    // the reference's layout: asym(m,j,p,q), c(m,j,p,q)
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const int r = (int)ring_div((unsigned)idx, a.inv_oo), mj = idx - r * oo;
+        const int qq = (int)ring_div((unsigned)r, inv_np), pp = r - qq * np;
+        const int j = (int)ring_div((unsigned)mj, a.inv_o), m = mj - j * o;
+        const int blk = oo * (pp + P * qq);
+        const double t = tile[mj + blk], tt = tile[j + o * m + blk];
+        const int64_t x = mj + O * O * ((p0 + pp) + V * (q0 + qq));
+        a.asym[x] = 2.0 * t - tt;
+        a.c[x] = t + a.t1[m + o * (p0 + pp)] * a.t1[j + o * (q0 + qq)];
+    }
+    // [(m,p) | (j,q)]: t2'(jq; mp) = t2(m,j,p,q), asym'(jq; mp) = asym(m,j,p,q)
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        int r = (int)ring_div((unsigned)idx, a.inv_o);
+        const int m = idx - r * o;
+        int r2 = (int)ring_div((unsigned)r, inv_np);
+        const int pp = r - r2 * np;
+        const int qq = (int)ring_div((unsigned)r2, a.inv_o), j = r2 - qq * o;
+        const int blk = oo * (pp + P * qq);
+        const double t = tile[m + o * j + blk], tt = tile[j + o * m + blk];
+        const int64_t out = m + O * (p0 + pp) + a.Kc * (j + O * (q0 + qq));
+        a.t2p[out] = t;
+        a.asp[out] = 2.0 * t - tt;
+    }
+    // [(m,q) | (j,p)]: t2x(jp; mq) = t2(m,j,p,q), c'(jp; mq) = c(m,j,p,q)
+    const unsigned inv_nq = nq == 1 ? 0u : (unsigned)(((uint64_t)1 << 32) / (unsigned)nq + 1);
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        int r = (int)ring_div((unsigned)idx, a.inv_o);
+        const int m = idx - r * o;
+        int r2 = (int)ring_div((unsigned)r, inv_nq);
+        const int qq = r - r2 * nq;
+        const int pp = (int)ring_div((unsigned)r2, a.inv_o), j = r2 - pp * o;
+        const double t = tile[m + o * j + oo * (pp + P * qq)];
+        const int64_t out = m + O * (q0 + qq) + a.Kc * (j + O * (p0 + pp));
+        a.t2x[out] = t;
+        a.cp[out] = t + a.t1[m + o * (p0 + pp)] * a.t1[j + o * (q0 + qq)];
+    }
 }
 
 static RingTg* ring_get(Context& cx, CCState& s)
@@ -151,6 +219,28 @@ static Tensor kview(const RingTg* r, double* buf, const CCState& s, int pos_m, i
     return t;
 }
 
+// asym_t2, c and the amplitudes' four copies in one pass (instead of k_asym_c + four permuting copies); false: not available for these
+// extents (the o^2 block of one (p,q) does not fit the LDS) -- the caller runs k_asym_c
+bool ring_tg_pack(Context& cx, CCState& s)
+{
+    static const bool off = getenv("AFESP_RING_PACK") && getenv("AFESP_RING_PACK")[0] == '0';
+    const int64_t oo = (int64_t)s.o * s.o;
+    if (off || oo * 8 > 65536 || oo >= 65536 / 4) return false;
+    RingTg* r = ring_get(cx, s);
+    RingPackArgs a;
+    a.t1 = s.t1.d; a.t2 = s.t2.d; a.asym = s.asym.d; a.c = s.c.d;
+    a.cp = r->cp; a.t2p = r->t2p; a.t2x = r->t2x; a.asp = r->asp;
+    a.o = s.o; a.v = s.v; a.Kc = r->Kc;
+    a.P = a.Q = oo * 16 * 8 <= 65536 ? 4 : oo * 4 * 8 <= 65536 ? 2 : 1;
+    a.inv_o = tgemm_inverse(s.o);
+    a.inv_oo = tgemm_inverse((int)oo);
+    const int tiles = ((s.v + a.P - 1) / a.P) * ((s.v + a.Q - 1) / a.Q);
+    hipLaunchKernelGGL(ring_pack_kernel, dim3((unsigned)tiles), dim3(256), (size_t)(oo * a.P * a.Q * 8), cx.stream, a);
+    AFESP_HIP(hipGetLastError());
+    r->packed = true;
+    return true;
+}
+
 // I_ovov' and I_voov' from the small terms that ccsd_intermediates has left in I_ovov / I_voov (reference layout)
 void ring_tg_intermediates(Context& cx, CCState& s)
 {
@@ -163,10 +253,13 @@ void ring_tg_intermediates(Context& cx, CCState& s)
         r->frozen_built = true;
     }
     // the amplitudes' copies: c'(ja;me) = c(m,j,a,e), t2'(ja;me) = t2(m,j,e,a), t2x(ja;me) = t2(m,j,a,e), asym'(ia;me) = asym(m,i,e,a)
-    permute_add(cx, 1.0, s.c, "mjae", 0.0, kview(r, r->cp, s, 0, 1, 2, 3), "mjae");
-    permute_add(cx, 1.0, s.t2, "mjea", 0.0, kview(r, r->t2p, s, 0, 1, 3, 2), "mjea");
-    permute_add(cx, 1.0, s.t2, "mjae", 0.0, kview(r, r->t2x, s, 0, 1, 2, 3), "mjae");
-    permute_add(cx, 1.0, s.asym, "miea", 0.0, kview(r, r->asp, s, 0, 1, 3, 2), "miea");
+    if (!r->packed) {   // (ring_tg_pack has not made them with asym_t2 and c)
+        permute_add(cx, 1.0, s.c, "mjae", 0.0, kview(r, r->cp, s, 0, 1, 2, 3), "mjae");
+        permute_add(cx, 1.0, s.t2, "mjea", 0.0, kview(r, r->t2p, s, 0, 1, 3, 2), "mjea");
+        permute_add(cx, 1.0, s.t2, "mjae", 0.0, kview(r, r->t2x, s, 0, 1, 2, 3), "mjae");
+        permute_add(cx, 1.0, s.asym, "miea", 0.0, kview(r, r->asp, s, 0, 1, 3, 2), "miea");
+    }
+    r->packed = false;
     const int ktail4 = (int)((r->ov - (r->Kc - TG_BK) + 3) / 4);
     TgProblem p{r->slab, r->slab, r->slab, r->rc32, r->cm1, (int)r->ov, true, ktail4};
     AFESP_HIP(tgemm_launch(p, r->groups, 2, r->tiles, r->mx, cx.stream, cx.tg));
@@ -197,7 +290,7 @@ void ring_tg_materialize(Context& cx, CCState& s, const Tensor& I_ovov_out, cons
 
 void ring_invalidate(CCState& s)
 {
-    if (s.ring) { ((RingTg*)s.ring)->live = false; ((RingTg*)s.ring)->res_live = false; }
+    if (s.ring) { ((RingTg*)s.ring)->live = false; ((RingTg*)s.ring)->res_live = false; ((RingTg*)s.ring)->packed = false; }
 }
 
 }  // namespace afesp
