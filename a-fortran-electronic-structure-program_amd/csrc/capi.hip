@@ -1091,6 +1091,7 @@ int afesp_ccsd_so_init(afesp_ctx* ctx, int64_t nbasis, int64_t nel, const double
         cx.drop_scratch("ao2mo_");   // the AO->MO temporaries
         ctx->so_programs_reset();
         so_init(cx, ctx->so, (int)nbasis, (int)nel, src, canon_levels, diis_n_errmat, (flags & AFESP_SO_FOO_AS_PUBLISHED) != 0);
+        ctx->so.amp_epoch = ++cx.amp_clock;
         if (tmp) cx.release(tmp);
     });
 }
@@ -1111,6 +1112,7 @@ int afesp_ccsd_so_iterate(afesp_ctx* ctx, double e_tol, double t_tol, double* en
 {
     return guarded(ctx, [&] {
         if (!ctx->so.ready) throw Error(1, "afesp_ccsd_so_iterate: call afesp_ccsd_so_init first");
+        ctx->so.amp_epoch = ++ctx->cx.amp_clock;   // (the amplitudes may change: derived copies go stale)
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         // (the levelled sequence of fused.h where the system is small enough for its products to be launch-bound: the big ones
         // keep their own kernels inside it)
@@ -1131,6 +1133,7 @@ int afesp_ccsd_so_diis(afesp_ctx* ctx)
 {
     return guarded(ctx, [&] {
         if (!ctx->so.ready) throw Error(1, "afesp_ccsd_so_diis: call afesp_ccsd_so_init first");
+        ctx->so.amp_epoch = ++ctx->cx.amp_clock;
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         diis_update(ctx->cx, ctx->so);
     });
@@ -1152,6 +1155,7 @@ int afesp_ccsd_so_set_amplitudes(afesp_ctx* ctx, const double* t1, const double*
 {
     return guarded(ctx, [&] {
         if (!ctx->so.ready) throw Error(1, "afesp_ccsd_so_set_amplitudes: no spin-orbital CCSD state");
+        ctx->so.amp_epoch = ++ctx->cx.amp_clock;
         AFESP_HIP(hipSetDevice(ctx->cx.device));
         SOState& s = ctx->so;
         if (t1) AFESP_HIP(hipMemcpyAsync(s.t1.d, t1, sizeof(double) * s.t1.size(), hipMemcpyHostToDevice, ctx->cx.stream));

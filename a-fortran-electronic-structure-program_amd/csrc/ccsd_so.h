@@ -19,6 +19,7 @@ struct SOState : DiisRing {
     Tensor t1_w;                     // t1 as the last so_intermediates saw it
     double energy = 0.0, energy_old = 0.0, rms = 0.0;
     void* tplan = nullptr;           // cached (T) launch plan (triples_so.hip)
+    int64_t amp_epoch = 0;           // bumped by every entry point that may change t1 / t2: the (T) operand copies are rebuilt only then
     // 1/2 tau_ijef W_abef (ccsd.f90:1021-1024) without W_abef (so_ladder): the bare part over antisymmetric pairs -- va(ef, ab) =
     // <ab||ef> for e < f, a < b built once, ta(ij, ef) = tau for i < j, e < f and the product pa(ij, ab) per iteration
     double *va = nullptr, *ta = nullptr, *pa = nullptr;

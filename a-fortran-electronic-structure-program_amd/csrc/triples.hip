@@ -1094,6 +1094,13 @@ void so_triples_plan_free(SOState& s)
     s.tplan = nullptr;
 }
 
+// canon_levels_spinorb (ccsd.f90:451-454): spin orbital x carries the energy of spatial orbital x / 2
+__global__ void so_levels_kernel(double* e_so, const double* e, int n2)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < n2) e_so[x] = e[x / 2];
+}
+
 double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
 {
     if (!s.ready) throw Error(1, "ccsd_so_triples: no converged spin-orbital CCSD state in this context");
@@ -1106,8 +1113,14 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
     k_fill(cx, cx.scal, 1, 0.0);
     if (t_end <= t_begin) return 0.0;
     TriplesPlan* p = plan_for(cx, s.tplan, o, v, t_begin, t_end);
-    cx.t_ops_owner = nullptr;   // (this path fills the same cached buffers: the spin-free copies are gone)
     Tensor vt = view(cx.scratch("t_vt", Kc * v2 * O), {Kc, V, V, O}), tt = view(cx.scratch("t_tt", Kc * V * O * O), {Kc, V, O, O});
+    Tensor vs = view(cx.scratch("t_vs", v2 * O * O), {V, V, O, O});    // vs(x,y,p,q) = <pq||xy>
+    double* e_so = cx.scratch("t_eso", O + V);
+    // The operand copies depend on the amplitudes only: a call on unchanged amplitudes -- the next shard of the same (T), a timed
+    // repetition -- finds them in the cached buffers (as the spin-free path does) instead of five permuting passes, two memsets and a
+    // round trip of the orbital energies through the host with two stream synchronisations (round 4: every call).
+    const bool ops_valid = cx.t_ops_owner == (const void*)&s && cx.t_ops_amp == s.amp_epoch && cx.t_ops_scratch == cx.scratch_epoch;
+    if (!ops_valid) {
     auto sub = [&](const Tensor& full, int64_t row0, int64_t nrows) {
         Tensor t = full;
         t.d = full.d + row0;
@@ -1122,18 +1135,15 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
     permute_add(cx, 1.0, s.t2, "mpcb", 0.0, sub(vt, V, O), "mbcp");
     permute_add(cx, 1.0, s.t2, "qraf", 0.0, sub(tt, 0, V), "farq");
     permute_add(cx, -1.0, s.ovoo, "maqr", 0.0, sub(tt, V, O), "marq");
-    Tensor vs = view(cx.scratch("t_vs", v2 * O * O), {V, V, O, O});    // vs(x,y,p,q) = <pq||xy>
     permute_add(cx, 1.0, s.oovv, "pqxy", 0.0, vs, "xypq");
-    double* e_so = cx.scratch("t_eso", O + V);
-    {
-        std::vector<double> es((size_t)(O + V));
-        std::vector<double> eh((size_t)s.n);
-        AFESP_HIP(hipMemcpyAsync(eh.data(), s.e, sizeof(double) * s.n, hipMemcpyDeviceToHost, cx.stream));
-        cx.sync();
-        for (int64_t x = 0; x < O + V; ++x) es[(size_t)x] = eh[(size_t)(x / 2)];   // canon_levels_spinorb, ccsd.f90:451-454
-        AFESP_HIP(hipMemcpyAsync(e_so, es.data(), sizeof(double) * (O + V), hipMemcpyHostToDevice, cx.stream));
-        cx.sync();
+    hipLaunchKernelGGL(so_levels_kernel, dim3((unsigned)((O + V + 255) / 256)), dim3(256), 0, cx.stream, e_so, s.e, (int)(O + V));
+    AFESP_HIP(hipGetLastError());
     }
+    cx.t_ops_owner = (const void*)&s;
+    cx.t_ops_amp = s.amp_epoch;
+    cx.t_ops_scratch = cx.scratch_epoch;
+    cx.t_ops_ts = false;
+    cx.t_ops_cr = -1;
     TriplesIn in{e_so, s.t1.d, vs.d, nullptr, s.t2.d, o, v};
     double* Xpool = cx.scratch("t_xpool", 3 * p->nb * vp3);
     double* partial = cx.scratch("t_partial", std::max<int64_t>((int64_t)p->norb * p->nb, 512));
@@ -1161,8 +1171,8 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
         hipLaunchKernelGGL(triples_so_orbit_kernel, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,
                            p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
         AFESP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(triples_sum_kernel, dim3(1), dim3(256), 0, cx.stream, cx.scal, partial, p->norb * ch.nt);
-        AFESP_HIP(hipGetLastError());
+        // (two stages, 128 blocks first: one block walking the 67 200 partials of the H2O/cc-pVTZ shape took 0.10 ms of a 2.8 ms evaluation)
+        sum_partials(cx, cx.scal, partial, 1, p->norb * ch.nt, cx.scratch("t_sum_tmp", 6 * 128));
     }
     double* h = host_scalars(cx, 1);
     return h[0];

@@ -268,7 +268,12 @@ def spinorb_h2o_tz(rank, world, local, dist, cdev, torch, backend, jobdir):
     # 2 o v^4 to build it, 2 o^2 v^4 to contract it, src/ccsd.f90:849-858, :1021-1024)
     flop_exec = 2.0 * npo * npv * npv + 2.0 * os_**3 * vs_**3 + 4.0 * (os_ * vs_) ** 3 + 4.0 * os_**4 * vs_**2 + 4.0 * os_**2 * vs_**3
     flop_ref = 2.0 * os_**2 * vs_**4 + 2.0 * os_ * vs_**4 + 4.0 * (os_ * vs_) ** 3 + 4.0 * os_**4 * vs_**2 + 4.0 * os_**2 * vs_**3
+    # (T): every triple i < j < k of the whole list (this rank's share: 1 / world of them) is three products of v^2 x v x (v + o)
+    flop_t = (os_ * (os_ - 1) * (os_ - 2) // 6) * 3 * 2.0 * vs_**3 * (vs_ + os_)
     return {"nocc_spin": nel, "nvirt_spin": 2 * n - nel, "ccsd_iter_s": t_it, "t_s": t_t, "e_t": float(et[0]),
+            "t_flop_executed": flop_t, "t_fraction_of_mfma_peak": flop_t / t_t / 1e12 / MFMA_F64_PEAK_TFLOPS / max(world, 1),
+            "t_dominant_kernel": "tgemm_kernel (one launch per chunk of triples: Y(b,c;a) blocks over kappa = f (+) m) + triples_so_orbit_kernel; "
+                                 "operand copies cached per converged state -- kernel sequence in profiles/r05_so_t_timeline.txt",
             "flop_per_iter_executed": flop_exec, "flop_per_iter_reference_formulation": flop_ref,
             "fraction_of_mfma_peak": flop_exec / t_it / 1e12 / MFMA_F64_PEAK_TFLOPS,
             "tflops_reference_equivalent": flop_ref / t_it / 1e12,
