@@ -653,8 +653,13 @@ int afesp_ccsd_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, const double* e
         } else if (!src || ctx->eri_mo_n != n) {
             throw Error(1, "afesp_ccsd_init: no MO integrals resident for this basis size (call afesp_ao2mo_mp2 first)");
         }
-        ctx->cc_programs_reset();
-        cx.drop_scratch("ao2mo_");   // the AO->MO temporaries
+        // (a state of the same extents is initialised again where it lies: its compiled programs stay)
+        if (!ccsd_can_reinit(ctx->cc, (int)nocc, (int)nvirt, diis_n_errmat)) {
+            ctx->cc_programs_reset();
+            cx.drop_scratch("ao2mo_");   // the AO->MO temporaries
+        } else {
+            ctx->graph_cc.reset();
+        }
         ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, src, canon_levels, diis_n_errmat);
         if (tmp) {
             // a large system forms <ef|ab> on request only (ccsd_need_vvvv): its state keeps the device copy of the integrals
@@ -1280,7 +1285,8 @@ int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double sca
         double* packed = cx.alloc(ne);
         hipLaunchKernelGGL(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, packed, ne, scale, seed);
         AFESP_HIP(hipGetLastError());
-        ctx->cc_programs_reset();
+        if (!ccsd_can_reinit(ctx->cc, (int)nocc, (int)nvirt, diis_n_errmat)) ctx->cc_programs_reset();
+        else ctx->graph_cc.reset();
         ccsd_init(cx, ctx->cc, (int)nocc, (int)nvirt, packed, e.data(), diis_n_errmat);
         if (ctx->cc.v_vvvv.d) { cx.release(packed); ctx->cc.eri_src = nullptr; }
         else ctx->cc.eri_own = packed;   // kept for ccsd_need_vvvv

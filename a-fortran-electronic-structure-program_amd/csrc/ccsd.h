@@ -82,11 +82,14 @@ bool ring_live(const CCState& s);        // the intermediates of the current ite
 bool ring_res_live(const CCState& s);    // ... and a ring term of the current residual in ring_Y
 void ring_res_clear(CCState& s);
 void ring_invalidate(CCState& s);
+void ring_reinit(CCState& s);            // the state is initialised again where it lies: the integrals' copies follow
 const double* ring_Y(const CCState& s);
 void ring_free(Context& cx, CCState& s);
 
 // eri_mo_dev: packed chemist MO integrals ON DEVICE (length neri(o+v)); e_host: orbital energies (host)
 void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, const double* e_host, int diis_nerr);
+// whether ccsd_init would initialise the state again where it lies (same extents: addresses, plans and compiled programs stay valid)
+bool ccsd_can_reinit(const CCState& s, int o, int v, int diis_nerr);
 void ccsd_need_vvvv(Context& cx, CCState& s);          // forms <ef|ab> (v^4) if the state does not hold it yet
 void ccsd_refresh_sharding(Context& cx, CCState& s);   // call before an iteration: picks up the context's communicator
 bool ccsd_uses_lanes(const CCState& s);   // small systems: the iteration's chains run on parallel lanes (ccsd.hip)

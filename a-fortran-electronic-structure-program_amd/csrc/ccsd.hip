@@ -19,21 +19,47 @@ namespace afesp {
 
 static inline int64_t tri64(int64_t i, int64_t j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
+// A state of the same extents can be initialised again where it lies: every buffer, table and plan keeps its address, so the programs
+// compiled for it (fused.h: recording and compiling them is 0.7-0.8 ms, a third of a small molecule's whole solve) stay valid -- the
+// next point of a scan over geometries (utils/els_wrapper.py re-enters with the same shape) starts at the steady iteration time.
+// AFESP_CC_REINIT=0: always from scratch.
+bool ccsd_can_reinit(const CCState& s, int o, int v, int diis_nerr)
+{
+    const char* e = getenv("AFESP_CC_REINIT");
+    if (e && e[0] == '0') return false;
+    return s.ready && s.o == o && s.v == v && s.nerr == diis_nerr && s.pp_sym == pp_sym_pays(o, v);
+}
+
 void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, const double* e_host, int diis_nerr)
 {
     if (o <= 0 || v <= 0) throw Error(1, "ccsd_init: need at least one occupied and one virtual orbital");
-    ccsd_free(cx, s);
+    const bool again = ccsd_can_reinit(s, o, v, diis_nerr);
+    if (again) {
+        cx.quiesce();
+        s.ready = false;
+        if (s.eri_own) { cx.release(s.eri_own); s.eri_own = nullptr; }
+        ring_reinit(s);
+        s.cs_packed = s.partials_live = false;
+        s.tail_pending = false;
+        s.nact = 0; s.it = 0;
+    } else {
+        ccsd_free(cx, s);
+    }
     s.o = o; s.v = v;
     const int64_t O = o, V = v, n = o + v, ov = O * V, o2v2 = O * O * V * V;
-    s.e = cx.alloc(n);
+    // (a state initialised again keeps what it has: `T` / `A` allocate only for a new one)
+    auto T = [&](Tensor& t, std::initializer_list<int64_t> dims) { if (!again) t = cx.tensor(dims); };
+    auto A = [&](double*& ptr, int64_t nd) { if (!again) ptr = cx.alloc(nd); };
+    A(s.e, n);
     AFESP_HIP(hipMemcpyAsync(s.e, e_host, sizeof(double) * n, hipMemcpyHostToDevice, cx.stream));
     cx.sync();
-    s.v_oovv = cx.tensor({O, O, V, V}); s.v_ovov = cx.tensor({O, V, O, V}); s.v_vvov = cx.tensor({V, V, O, V});
-    s.v_oovo = cx.tensor({O, O, V, O}); s.v_oooo = cx.tensor({O, O, O, O});
+    T(s.v_oovv, {O, O, V, V}); T(s.v_ovov, {O, V, O, V}); T(s.v_vvov, {V, V, O, V});
+    T(s.v_oovo, {O, O, V, O}); T(s.v_oooo, {O, O, O, O});
     s.pp_sym = pp_sym_pays(O, V);
     s.eri_src = eri_mo_dev;
-    if (!s.pp_sym) s.v_vvvv = cx.tensor({V, V, V, V});   // the plain ladder reads <ef|ab>; the pair form is built from the packed array
-    s.w_oovv = cx.tensor({O, O, V, V}); s.w_oovo = cx.tensor({O, O, V, O});   // (w_vvov: on first use, ccsd_need_w_vvov)
+    if (!s.pp_sym) T(s.v_vvvv, {V, V, V, V});   // the plain ladder reads <ef|ab>; the pair form is built from the packed array
+    else if (again && s.v_vvvv.d) { cx.release(s.v_vvvv.d); s.v_vvvv = Tensor(); }   // (formed on request for the last system)
+    T(s.w_oovv, {O, O, V, V}); T(s.w_oovo, {O, O, V, O});   // (w_vvov: on first use, ccsd_need_w_vvov)
     // ccsd.f90:496-512: <pq|rs> = (pr|qs), virtual offsets removed
     k_slice_phys(cx, s.v_oovv.d, eri_mo_dev, o, o, v, v, 0, 0, o, o);
     k_slice_phys(cx, s.v_ovov.d, eri_mo_dev, o, v, o, v, 0, o, 0, o);
@@ -47,22 +73,31 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
     const int64_t fid = ++cx.amp_clock;
     for (Tensor* t : {&s.v_oovv, &s.v_ovov, &s.v_vvov, &s.v_oovo, &s.v_oooo, &s.w_oovv, &s.w_oovo}) t->frozen = fid;
     s.frozen_id = fid;
-    s.D1 = cx.tensor({O, V}); s.D2 = cx.tensor({O, O, V, V});
+    if (again && s.w_vvov.d) {   // (the companion made on first use: it follows the new integrals)
+        k_antisym_pair(cx, s.w_vvov.d, s.v_vvov.d, s.v, s.v, s.o, s.v, 0);
+        s.w_vvov.frozen = fid;
+    }
+    T(s.D1, {O, V}); T(s.D2, {O, O, V, V});
     k_denominators(cx, s.D1.d, s.D2.d, s.e, o, v);
     s.nvec = ov + o2v2;
-    s.amp = cx.alloc(s.nvec);
-    s.t1 = view(s.amp, {O, V}); s.t2 = view(s.amp + ov, {O, O, V, V});
-    double* res = cx.alloc(s.nvec);
-    s.r1 = view(res, {O, V}); s.r2 = view(res + ov, {O, O, V, V});
-    s.t2_old = cx.tensor({O, O, V, V});
-    s.I_vo = cx.tensor({V, O}); s.I_vv = cx.tensor({V, V}); s.I_oo_p = cx.tensor({O, O}); s.I_oo = cx.tensor({O, O});
-    s.c = cx.tensor({O, O, V, V}); s.asym = cx.tensor({O, O, V, V}); s.x_voov = cx.tensor({V, O, O, V});
-    s.I_oooo = cx.tensor({O, O, O, O}); s.I_ovov = cx.tensor({O, V, O, V}); s.I_voov = cx.tensor({V, O, O, V});
-    s.I_ooov_p = cx.tensor({O, O, O, V}); s.z_ooov = cx.tensor({O, O, O, V});
+    if (!again) {
+        s.amp = cx.alloc(s.nvec);
+        s.t1 = view(s.amp, {O, V}); s.t2 = view(s.amp + ov, {O, O, V, V});
+        double* res = cx.alloc(s.nvec);
+        s.r1 = view(res, {O, V}); s.r2 = view(res + ov, {O, O, V, V});
+    } else {
+        AFESP_HIP(hipMemsetAsync(s.t1.d, 0, sizeof(double) * ov, cx.stream));          // t1 = 0 (ccsd.f90:520)
+        AFESP_HIP(hipMemsetAsync(s.t2_old.d, 0, sizeof(double) * o2v2, cx.stream));
+    }
+    T(s.t2_old, {O, O, V, V});
+    T(s.I_vo, {V, O}); T(s.I_vv, {V, V}); T(s.I_oo_p, {O, O}); T(s.I_oo, {O, O});
+    T(s.c, {O, O, V, V}); T(s.asym, {O, O, V, V}); T(s.x_voov, {V, O, O, V});
+    T(s.I_oooo, {O, O, O, O}); T(s.I_ovov, {O, V, O, V}); T(s.I_voov, {V, O, O, V});
+    T(s.I_ooov_p, {O, O, O, V}); T(s.z_ooov, {O, O, O, V});
     // pp-ladder (ccsd.f90:1669) over the symmetry-unique column pairs a <= b
     {
         const int64_t np = V * (V + 1) / 2, K2 = V * V, N2 = O * O;
-        s.pp = cx.alloc(N2 * np + O * O * V * V + O * V);   // [PP | r2_sh | r1_sh]: the one exchange buffer of a split iteration
+        A(s.pp, N2 * np + O * O * V * V + O * V);   // [PP | r2_sh | r1_sh]: the one exchange buffer of a split iteration
         s.r2_sh = s.pp + N2 * np;
         s.r1_sh = s.r2_sh + O * O * V * V;
         std::vector<int64_t> tab;
@@ -88,15 +123,15 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
             // (the products of t2 with <ef|ia> for I_ooov_p use the same tables and the same P+- buffers: rows m = (i,a))
             const int64_t nm = std::max(np, O * V);
             s.pp_nm = nm;
-            s.pp_vs = cx.alloc(lds * np); s.pp_cs = cx.alloc(ns * kx); s.pp_ps = cx.alloc(ns * nm);
-            s.ov_ws = cx.alloc(lds * O * V);
-            s.pp_ts = cx.alloc(ns * ks);
-            s.oo_vs = cx.alloc(ns * ks); s.oo_xs = cx.alloc(ns * ns);
+            A(s.pp_vs, lds * np); A(s.pp_cs, ns * kx); A(s.pp_ps, ns * nm);
+            A(s.ov_ws, lds * O * V);
+            A(s.pp_ts, ns * ks);
+            A(s.oo_vs, ns * ks); A(s.oo_xs, ns * ns);
             if (npa > 0 && na > 0) {
-                s.pp_va = cx.alloc(lda * npa); s.pp_ca = cx.alloc(na * kx); s.pp_pa = cx.alloc(na * nm);
-                s.ov_wa = cx.alloc(lda * O * V);
-                s.pp_ta = cx.alloc(na * ka);
-                s.oo_va = cx.alloc(na * ka); s.oo_xa = cx.alloc(na * na);
+                A(s.pp_va, lda * npa); A(s.pp_ca, na * kx); A(s.pp_pa, na * nm);
+                A(s.ov_wa, lda * O * V);
+                A(s.pp_ta, na * ka);
+                A(s.oo_va, na * ka); A(s.oo_xa, na * na);
             }
             k_vvvv_sympack_packed(cx, s.pp_vs, s.pp_va, eri_mo_dev, o, v, lds, lda);
             k_vvx_sympack(cx, s.ov_ws, s.ov_wa, s.v_vvov.d, v, O * V, lds, lda);
@@ -111,14 +146,16 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
             for (int64_t m = 0; m < nm; ++m) tab.push_back(ns * m);
             for (int64_t m = 0; m < nm; ++m) tab.push_back(na * m);
         }
-        s.pp_tab = cx.alloc_i64((int64_t)tab.size());
-        AFESP_HIP(hipMemcpyAsync(s.pp_tab, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
-        cx.sync();
+        if (!again) {   // (the tables depend on the extents only)
+            s.pp_tab = cx.alloc_i64((int64_t)tab.size());
+            AFESP_HIP(hipMemcpyAsync(s.pp_tab, tab.data(), tab.size() * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
+            cx.sync();
+        }
     }
     // ccsd.f90:520-521: t1 = 0, t2 = v_oovv / D
     k_div(cx, s.t2.d, s.v_oovv.d, s.D2.d, o2v2);
     // ccsd.f90:577-615
-    diis_alloc(cx, s, diis_nerr);
+    if (!again) diis_alloc(cx, s, diis_nerr);
     s.energy = s.energy_old = s.rms = 0.0;
     s.amp_epoch = ++cx.amp_clock;   // (a clock of the context: a re-initialised state never repeats an epoch)
     s.cr_epoch = ++cx.amp_clock;

@@ -288,6 +288,12 @@ void ring_tg_materialize(Context& cx, CCState& s, const Tensor& I_ovov_out, cons
     permute_add(cx, 1.0, kview(r, r->Ivo, s, 2, 1, 3, 0), "bjia", 0.0, I_voov_out, "bjia");
 }
 
+void ring_reinit(CCState& s)
+{
+    ring_invalidate(s);
+    if (s.ring) ((RingTg*)s.ring)->frozen_built = false;
+}
+
 void ring_invalidate(CCState& s)
 {
     if (s.ring) { ((RingTg*)s.ring)->live = false; ((RingTg*)s.ring)->res_live = false; ((RingTg*)s.ring)->packed = false; }

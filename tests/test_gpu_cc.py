@@ -98,6 +98,31 @@ def test_large_system_path_walks_the_reference_iteration_table(eng, name, ring, 
         assert abs(e - ge) < 1e-10, (git, e, ge)
 
 
+def test_same_shape_state_is_initialised_again_where_it_lies():
+    """A scan over geometries (utils/els_wrapper.py) re-enters afesp_ccsd_init with the same extents: the state keeps its buffers and its
+    compiled programs (no second recording), and walks the reference's iteration table again -- also after other amplitudes, a (T)
+    evaluation and a system of another shape in between."""
+    from afesp_amd.capi import Engine
+    with Engine(0) as e:
+        tables = {}
+        for name in ("n2-cc-pvdz", "n2-cc-pvdz", "f2-cc-pvdz", "n2-cc-pvdz", "n2-cc-pvdz"):
+            si, ints, res, gold = molecules.load(name)
+            n, o = ints.nbasis, ints.nel // 2
+            v = n - o
+            e.do_mp2_spatial(n, o, res.canon_coeff, res.canon_levels, ints.eri, want_eri_mo=False)
+            e.ccsd_init(o, v, res.canon_levels, None, si.ccsd_diis_n_errmat)
+            nit, en, rm = e.do_ccsd_spatial(si.ccsd_maxiter, si.ccsd_e_tol, si.ccsd_t_tol)
+            assert nit == gold["cc_iters"][-1][0]
+            for (git, ge, gde, grms) in gold["cc_iters"]:
+                assert abs(en[git] - ge) < 1e-10 and abs(rm[git] - grms) < 1e-10, (name, git)
+            out = e.do_ccsd_t_spatial()
+            g = molecules.SURVEY_GOLD[name]
+            assert abs(en[nit] + out[1] - g["ccsd_pt_corr"]) < 1e-8
+            if name in tables:   # bit for bit the first walk
+                assert np.array_equal(tables[name][0], en[:nit + 1]) and np.array_equal(tables[name][1], out)
+            tables[name] = (en[:nit + 1].copy(), out.copy())
+
+
 @pytest.mark.parametrize("name", ["n2-cc-pvdz", "f2-cc-pvdz"])
 def test_completely_renormalised_triples_match_bundled_outputs(eng, name):
     """CR-CCSD[T]/(T) (src/ccsd.f90:2338-2551): the numbers of the reference's bundled CRCCSD(T)_spatial runs."""
