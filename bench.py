@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "a-fortran-electronic-structure-program_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-WORKLOADS = {"h2o_tz": (5, 53), "cfg5": (20, 200), "n2": (7, 21), "f2": (9, 19), "mid": (10, 100)}
+WORKLOADS = {"h2o_tz": (5, 53), "cfg5": (20, 200), "n2": (7, 21), "f2": (9, 19), "mid": (10, 100), "mid_large": (12, 120)}
 MFMA_F64_PEAK_TFLOPS = 78.6      # v_mfma_f64_16x16x4_f64: 32 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -367,6 +367,7 @@ class Reducer:
         self.eng, self.world, self.dist, self.cdev, self.torch = eng, world, dist, cdev, torch
         self.kind = "none (one rank)"
         self.own = False
+        self.checked = False          # the first sum through the product's own transport has come back on every rank
         if world == 1:
             return
         from afesp_amd import capi
@@ -406,7 +407,29 @@ class Reducer:
         if self.world == 1:
             return np.asarray(values, dtype=np.float64)
         if self.own:
-            return self.eng.allreduce_sum(values)
+            # The first afesp_allreduce_sum of a communicator is the first time its transport really runs (ncclAllReduce on N > 1
+            # GPUs has only ever executed on the driver's node): if it fails on any rank, every rank falls back to
+            # torch.distributed for the rest of the run and the line says so -- the measurement is not lost.
+            out, err = None, None
+            try:
+                out = self.eng.allreduce_sum(values)
+            except Exception as exc:   # noqa: BLE001
+                err = exc
+            if self.checked:
+                if err is not None:
+                    raise err
+                return out
+            self.checked = True
+            flag = self.torch.tensor([0.0 if err is not None else 1.0], dtype=self.torch.float64, device=self.cdev)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+            if float(flag.cpu()[0]) == 1.0:
+                return out
+            try:
+                self.eng.comm_destroy()
+            except Exception:   # noqa: BLE001
+                pass
+            self.own = False
+            self.kind = "torch.distributed.all_reduce (the first afesp_allreduce_sum failed" + (f": {err})" if err is not None else " on another rank)")
         t = self.torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64)).to(self.cdev)
         self.dist.all_reduce(t)
         return t.cpu().numpy()
@@ -692,6 +715,22 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
                 res["cr_t"] = {"cr_intermediates_s": t_cri, "cr_t_s": t_cr, "out": [float(x) for x in cr],
                                "max_abs_diff_of_E[T]_E(T)_to_the_plain_evaluation": float(np.max(np.abs(np.asarray(cr[:2]) - np.asarray(acc["last"][:2]))))}
             res["ao2mo"] = time_ao2mo(eng, o, v, 21 if o * v < 2000 else 5)
+            if world == 1:
+                # A whole calculation, so that the weights of its stages are visible (a step of this benchmark is ONE iteration beside the
+                # full (T); a solve is 20-30 of them): AO->MO + MP2 (as timed above), CCSD from the MP1 amplitudes to the reference's
+                # default thresholds (src/system.f90:46-50) through afesp_ccsd_solve, then the (T) of the benchmark configuration
+                eng.synthetic_init(o, v, scale, seed, 8)
+                t0 = time.perf_counter()
+                nit_w, en_w, _ = eng.do_ccsd_spatial(100, 1e-6, 1e-7)
+                t_solve = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                eng.do_ccsd_t_spatial_plain(0, nt)
+                t_tw = time.perf_counter() - t0
+                res["whole_calculation"] = {"ao2mo_mp2_s": res["ao2mo"]["ms"] * 1e-3, "ccsd_solve_s": t_solve, "ccsd_iterations": int(nit_w),
+                                            "ccsd_converged": bool(nit_w > 0), "ccsd_e_tol": 1e-6, "ccsd_t_tol": 1e-7,
+                                            "ccsd_energy": float(en_w[nit_w]) if nit_w > 0 else None,
+                                            "t_s": t_tw, "total_s": res["ao2mo"]["ms"] * 1e-3 + t_solve + t_tw,
+                                            "note": "the (T) evaluation includes building its operand copies from the converged amplitudes"}
         if args.cpu_baseline and with_cpu and world == 1:   # rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline(o, v, scale, seed, eng)
             res["cpu_baseline"]["vs_gpu_step"] = res["cpu_baseline"]["value"] / sec_per_step
@@ -728,6 +767,41 @@ def spawn_ranks(n):
     return next((c for c in codes if c != 0), 0)
 
 
+def key_paths(d, prefix=""):
+    out = set()
+    for k, v in d.items():
+        out.add(prefix + k)
+        if isinstance(v, dict):
+            out |= key_paths(v, prefix + k + ".")
+    return out
+
+
+def dry_ranks(n, argv):
+    """`--dry-ranks N`: walk the N > 1 control flow on ONE GPU before a multi-GPU node ever sees it -- N ranks of this script over the
+    host-segment transport (shard bounds, block-size agreement, the split self-check, the per-rank fields, every same-run leg) on a
+    mid-size system past the small-system switch (o = 12, v = 120: the split of the iteration is attempted), then the same command on one rank -- and check that the N-rank line carries every key of the one-rank line
+    (`cpu_baseline`, the launch-path comparison, the CR-(T) timing and `whole_calculation` are one-rank measurements by contract).  Prints one JSON report; exit code 1 if
+    a key is missing.  At most 6 ranks: a GPU box admits six processes on its card."""
+    if not 2 <= n <= 6:
+        raise SystemExit("bench.py --dry-ranks: 2 ... 6 ranks (one GPU admits six processes)")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mid_large", "--steps", "2", "--warmup", "1", "--no-live-pmc"]
+    lines = {}
+    for tag, extra in (("one_rank", ["--gpus", "1"]), ("n_ranks", ["--gpus", str(n), "--backend", "gloo"])):
+        r = subprocess.run(base + extra, capture_output=True, text=True, env=dict(os.environ, AFESP_CC_SHARD=os.environ.get("AFESP_CC_SHARD", "1")))
+        js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not js:
+            print(json.dumps({"dry_ranks": n, "failed": tag, "returncode": r.returncode, "stderr_tail": r.stderr[-2000:]}))
+            return 1
+        lines[tag] = json.loads(js[-1])
+    one_rank_only = tuple(pre + k for pre in ("", "h2o_tz_same_run.") for k in ("cpu_baseline", "ccsd_iter_paths", "cr_t", "whole_calculation"))
+    missing = sorted(k for k in key_paths(lines["one_rank"]) - key_paths(lines["n_ranks"])
+                     if not any(k == p or k.startswith(p + ".") for p in one_rank_only))
+    rep = {"dry_ranks": n, "missing_keys": missing, "n_rank_only_keys": sorted(key_paths(lines["n_ranks"]) - key_paths(lines["one_rank"])),
+           "n_ranks_line": lines["n_ranks"]}
+    print(json.dumps(rep))
+    return 1 if missing else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -746,8 +820,13 @@ def main():
                          "this run (four rocprofv3 --pmc passes of this command as child processes, N = 1 only)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo only to rehearse the multi-rank path on a one-GPU box")
+    ap.add_argument("--dry-ranks", type=int, default=0,
+                    help="rehearse the N-rank control flow on one GPU (host transport, mid-size system) and check the emitted line's keys "
+                         "against a one-rank run: see dry_ranks()")
     args = ap.parse_args()
 
+    if args.dry_ranks:
+        sys.exit(dry_ranks(args.dry_ranks, sys.argv[1:]))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
