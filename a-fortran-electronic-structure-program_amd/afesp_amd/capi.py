@@ -30,7 +30,7 @@ EXPORTS = [
     "afesp_read_eri_text", "afesp_write_fcidump", "afesp_set_eri", "afesp_build_fock", "afesp_ccsd_t_plain",
     "afesp_synthetic_ao", "afesp_ccsd_pp_ladder_flop", "afesp_ccsd_iteration_flop",
     "afesp_device_count", "afesp_comm_unique_id", "afesp_comm_init", "afesp_comm_destroy", "afesp_allreduce_sum",
-    "afesp_ccsd_t_block_size", "afesp_test_inject", "afesp_ccsd_is_split", "afesp_ccsd_set_split", "afesp_ccsd_set_fused", "afesp_ccsd_iteration_launches", "afesp_debug_stamps", "afesp_arena_stats",
+    "afesp_ccsd_t_block_size", "afesp_test_inject", "afesp_ccsd_is_split", "afesp_ccsd_set_split", "afesp_ccsd_set_fused", "afesp_ccsd_iteration_launches", "afesp_debug_stamps", "afesp_launch_counts", "afesp_arena_stats",
 ]
 COMM_RCCL, COMM_HOST = 0, 1
 
@@ -117,6 +117,7 @@ def load_library():
     L.afesp_ccsd_set_fused.argtypes = [C.c_void_p, C.c_int]
     L.afesp_ccsd_iteration_launches.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.afesp_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+    L.afesp_launch_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -283,6 +284,13 @@ class Engine:
         out = np.zeros(4)
         self._chk(self.L.afesp_arena_stats(self.h, out))
         return dict(driver_calls=int(out[0]), reuse_hits=int(out[1]), idle_gb=out[2] / 1e9, live_gb=out[3] / 1e9)
+
+    def launch_counts(self):
+        """launches so far in this context: tall (streamed tall x skinny kernel), gett (gather kernel through the planner), tgemm
+        (LDS-DMA GEMM, 128-row tiles), tgemm_mixed (... with 96-row tiles where the rows end)"""
+        out = (C.c_uint64 * 4)()
+        self._chk(self.L.afesp_launch_counts(self.h, out))
+        return dict(tall=int(out[0]), gett=int(out[1]), tgemm=int(out[2]), tgemm_mixed=int(out[3]))
 
     def ccsd_set_split(self, mode):
         """1: split the CCSD iteration over the ranks, 0: replicas, -1: as AFESP_CC_SHARD says (default replicas)."""

@@ -94,6 +94,7 @@ struct Context {
     std::vector<void*> owned;             // everything freed at destroy
     GettWorkspace ws{nullptr, 0};
     TgLaunchState tg;                     // ticket counters / grid size of this context's tgemm_kernel launches (tgemm.h)
+    unsigned long long n_tall = 0, n_gett = 0;   // launches of the streamed tall x skinny kernel / the gather kernel by contract() (afesp_launch_counts)
     bool in_repack = false;               // set while contract() runs on a re-laid-out operand
     // Lanes: extra streams (each with its own split-K workspace) on which independent chains of small launches run side
     // by side.  `stream` / `ws` above always denote the lane in use; lane 0 is the context's main stream.

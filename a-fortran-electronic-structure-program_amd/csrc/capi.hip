@@ -1541,10 +1541,17 @@ int afesp_ccsd_t_block_size(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr,
 // diagnostic builds of the GEMM kernel (AFESP_GETT_VARIANT bit 64): the per-wave cycle stamps of the last launch
 int afesp_debug_stamps(unsigned long long* out, int n)
 {
-    if (n == -1000) { out[0] = tall_launch_count(); return 0; }                   // launches of the streamed tall x skinny kernel (tests)
     if (n < 0) return triples_read_orbit_stamps(out, -n) == hipSuccess ? 0 : 1;   // the (T) orbit kernel's phase sums
     if (getenv("AFESP_STAMPS_GROUPED")) return gett_read_stamps_grouped(out, n) == hipSuccess ? 0 : 1;
     return gett_read_stamps(out, n) == hipSuccess ? 0 : 1;
+}
+
+// which kernel took the products of this context so far (tests: a shape that should stream did, the LDS-DMA GEMM ran with 96-row tiles)
+int afesp_launch_counts(afesp_ctx* ctx, uint64_t out[4])
+{
+    return guarded(ctx, [&] {
+        out[0] = ctx->cx.n_tall; out[1] = ctx->cx.n_gett; out[2] = ctx->cx.tg.launches; out[3] = ctx->cx.tg.launches_mixed;
+    });
 }
 
 // device arena of the context: {driver allocations so far, requests served from idle blocks, idle bytes, live bytes}

@@ -794,6 +794,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
     static const bool trace = getenv("AFESP_CONTRACT_TRACE") != nullptr;
     // tall x skinny (one extent of C at most 32, K a few hundred: the products of t1 with a four-index array): streamed, tall.h
     const bool tall = !force_split && !force_tm && !force_tn && tall_eligible(g);
+    ++(tall ? cx.n_tall : cx.n_gett);
     auto launch = [&]() { return tall ? tall_launch(g, cx.stream) : gett_launch(g, cx.ws, cx.stream, force_split, force_tm, force_tn); };
     if (!trace) {
         AFESP_HIP(launch());

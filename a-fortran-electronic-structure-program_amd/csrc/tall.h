@@ -17,6 +17,5 @@ namespace afesp {
 bool tall_eligible(const GettProblem& p);                          // shape test; batched problems are not taken
 hipError_t tall_launch(const GettProblem& p, hipStream_t stream);   // precondition: tall_eligible(p)
 void preload_tall();
-unsigned long long tall_launch_count();                              // launches so far in this process (tests: afesp_debug_stamps(out, -1000))
 
 }  // namespace afesp

@@ -225,13 +225,9 @@ static hipError_t tall_launch_ch(int ch, const TallArgs& a, size_t lds, int grid
     return hipErrorInvalidValue;
 }
 
-static unsigned long long g_tall_launches = 0;
-unsigned long long tall_launch_count() { return g_tall_launches; }
-
 hipError_t tall_launch(const GettProblem& p, hipStream_t stream)
 {
     if (!tall_eligible(p)) return hipErrorInvalidValue;
-    ++g_tall_launches;
     const bool tall_n = p.N > p.M;   // C's lanes (n) run along the tall index
     TallArgs a;
     a.X = tall_n ? p.B : p.A;

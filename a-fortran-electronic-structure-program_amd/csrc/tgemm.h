@@ -52,6 +52,7 @@ constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 16;
 struct TgLaunchState {
     unsigned* tickets = nullptr;
     int cap = 0, cap_mixed = 0;
+    unsigned long long launches = 0, launches_mixed = 0;   // tgemm_kernel / tgemm_mixed_kernel launches through this state (afesp_launch_counts)
 };
 void tgemm_state_free(TgLaunchState& st);
 // bm = 0: 128-row tiles throughout (tgemm_kernel).  bm = 128 / 96: m-tiles of that many rows, and a tile with at most 96 rows left runs

@@ -618,6 +618,7 @@ hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngrou
     }
     if (mixed) hipLaunchKernelGGL(tgemm_mixed_kernel, dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(tgemm_kernel, dim3(grid), dim3(256), 0, stream, a);
+    ++(mixed ? st.launches_mixed : st.launches);
     return hipGetLastError();
 }
 

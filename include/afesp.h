@@ -197,6 +197,10 @@ int afesp_arena_stats(afesp_ctx* ctx, double out[4]);
 /* Test hook: what = 1 makes the next laned (small-system) amplitude update throw once, from a lane other than the main one
  * -- the failure mode of a capture that dies half-way (tests/test_gpu_cc.py). */
 int afesp_test_inject(afesp_ctx* ctx, int what);
+/* Test / diagnostic hook, per context: launches so far of {the streamed tall x skinny kernel, the gather kernel through the operator
+ * layer's planner, the LDS-DMA GEMM with 128-row tiles, the LDS-DMA GEMM with 96-row tiles where the rows end} -- tests check with it
+ * that a product took the kernel meant for its shape (tests/test_gpu_operators.py, tests/test_gpu_cc.py). */
+int afesp_launch_counts(afesp_ctx* ctx, uint64_t out[4]);
 /* Diagnostic builds only: n > 0: per (workgroup, wave) cycle sums of the GEMM kernel's last launch (tools/stamp_probe.py);
  * n < 0: the first -n phase sums of the (T) orbit kernel since the last call (tools/orbit_stamps.py).  Zeros in a shipped build. */
 int afesp_debug_stamps(unsigned long long* out, int n);

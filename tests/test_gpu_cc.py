@@ -283,12 +283,13 @@ def test_ao2mo_pair_symmetric_transform(eng, n, o, blocked, monkeypatch):
     assert np.array_equal(third, eri_mo) and e3 == e_mp2
 
 
-@pytest.mark.parametrize("n,o", [(16, 3), (24, 5), (58, 5), (130, 9)])
+@pytest.mark.parametrize("n,o", [(16, 3), (24, 5), (58, 5), (130, 9), (100, 7)])
 def test_ao2mo_on_the_lds_dma_gemm(n, o, monkeypatch):
     """The whole-tensor AO->MO with its four quarter transforms on tgemm_kernel (what even bases from n = 96 on run; forced here
     for the small ones): K tails of 0, 8, 10 and 2 elements, one and two row tiles, the triangular column list of the last
     transform, the first-128-rows shortcut for the pairs with p < 128 (n = 130) -- every packed MO integral against the
-    restatement (n <= 58) and against the gather-GEMM path (all n), also from the (ij|KL) copy of a Fock build."""
+    restatement (n <= 58) and against the gather-GEMM path (all n), also from the (ij|KL) copy of a Fock build.  Rows that end at most
+    96 past a multiple of 128 run their last tile 96 rows high (tgemm_mixed_kernel: every n here but 100, whose rows keep 128-row tiles)."""
     from afesp_amd import inputs
     from afesp_amd.capi import Engine
     rng = np.random.default_rng(7 * n + o)
@@ -302,6 +303,8 @@ def test_ao2mo_on_the_lds_dma_gemm(n, o, monkeypatch):
         with Engine(0) as eng:
             got[mode] = eng.do_mp2_spatial(n, o, c, e, eri)
             if mode == "1":
+                lc = eng.launch_counts()
+                assert (lc["tgemm_mixed"] > 0) if n != 100 else (lc["tgemm"] > 0 and lc["tgemm_mixed"] == 0), lc
                 eng.set_eri(n, eri)
                 eng.build_fock(n, np.eye(n), np.zeros((n, n)))
                 e3, third = eng.do_mp2_spatial(n, o, c, e, None)

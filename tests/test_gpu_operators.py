@@ -100,10 +100,7 @@ def test_tall_skinny_products_of_the_iteration(eng, o, v, beta, monkeypatch):
     ]
     h = _rand(rng, v, va, oi, v)               # <ab|je>-shaped (b, a, j, e): summed index slowest
     cases[2] = ("ie", t1, "baje", h, "ijab", (o, oi, va, v))
-    import ctypes
-    count = (ctypes.c_ulonglong * 1)()
-    eng.L.afesp_debug_stamps(count, -1000)
-    before = count[0]
+    before = eng.launch_counts()["tall"]     # (per context: include/afesp.h, afesp_launch_counts)
     for la, A, lb, B, lc, shape in cases:
         C0 = _rand(rng, *shape)
         ref = beta * C0 + 1.5 * np.einsum(f"{la},{lb}->{lc}", A, B)
@@ -111,16 +108,14 @@ def test_tall_skinny_products_of_the_iteration(eng, o, v, beta, monkeypatch):
         assert np.max(np.abs(got - ref)) < 1e-11, (la, lb, lc)
         gather = eng.contract(1.5, A, la, B, lb, beta, C0.copy(order="F"), lc, force_tm=1, force_tn=1)
         assert np.max(np.abs(got - gather)) < 1e-11, (la, lb, lc)
-    eng.L.afesp_debug_stamps(count, -1000)
     # (o = 1: C(i,j,a,b) then runs along j first, across the fastest index of <ab|je> -- that one stays with the gather kernel)
-    taken = count[0] - before
+    taken = eng.launch_counts()["tall"] - before
     assert taken == (3 if o > 1 else 2), "the streamed kernel did not take these products"
     # a product that reads its tall operand across its fastest index stays with the gather kernel
     m = _rand(rng, o, v, oi * va, v)           # <mb|ie>-shaped (m, b, i, e)
     got = eng.contract(1.0, t1, "je", m, "mbie", 0.0, np.zeros((oi * va, o, o, v), order="F"), "ijmb")
     assert np.max(np.abs(got - np.einsum("je,mbie->ijmb", t1, m))) < 1e-11
-    eng.L.afesp_debug_stamps(count, -1000)
-    assert count[0] - before == taken
+    assert eng.launch_counts()["tall"] - before == taken
 
 
 @pytest.mark.parametrize("order", ["".join(p) for p in itertools.permutations("1234")])
