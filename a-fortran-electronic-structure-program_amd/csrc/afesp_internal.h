@@ -141,6 +141,7 @@ struct Context {
     size_t plan_slab_left = 0;
     int64_t* plan_alloc(size_t n);        // n int64, 16-byte aligned, not zeroed
     void plan_clear();                    // drops every plan and its tables
+    int64_t plan_epoch = 0;               // bumped by plan_clear: compiled programs that point into the tables go stale (fused.h)
     std::map<std::string, std::pair<void*, size_t>> cache;   // named scratch buffers kept across calls (not zeroed)
     std::string last_error;
     // optional HIP-event timing of the (T) launches (bench.py roofline): enabled by afesp_profile

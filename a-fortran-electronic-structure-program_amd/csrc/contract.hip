@@ -205,6 +205,7 @@ void Context::plan_clear()
     plan_slab_left = 0;
     plans.clear();
     plan_bytes = 0;
+    ++plan_epoch;
 }
 
 Tensor Context::tensor(std::initializer_list<int64_t> dims)

@@ -13,6 +13,10 @@
 //                          copies that have become ready
 //   stage 3 (products) ...
 //
+// Operands must be FINITE everywhere the tables can reach, also beyond a K slice's end: the last block of a slice is masked on the A
+// fragment only (`valid ? a : 0`), B is multiplied as loaded from its clamped address -- an Inf / NaN there would turn the masked
+// zero into a NaN.  Every tensor of the solver states is (they are zero-initialised and only ever hold finite results); a caller of
+// Recorder::product with hand-built tables has to keep that.
 // Products that accumulate into one result in the same stage share its slabs: one pass sums them all.  The compiled program
 // (descriptor tables in device memory) is replayed every iteration; nothing is decided on the host between launches.
 #pragma once
@@ -80,6 +84,7 @@ void fused_run(Context& cx, const FusedProgram* p);   // launches only: may be c
 void fused_free(Context& cx, FusedProgram* p);
 int fused_launches(const FusedProgram* p);           // kernels per replay
 int64_t fused_epoch(const FusedProgram* p);          // Context::scratch_epoch it was compiled under, -2: refers to no scratch buffer
+int64_t fused_plan_epoch(const FusedProgram* p);     // Context::plan_epoch it was compiled under (its items point into the plans' tables)
 void preload_fused();
 
 // A program slot of a solver state: record `body` on first use (it runs the ordinary solver code with cx.rec set), replay afterwards.
@@ -98,6 +103,9 @@ inline bool fused_exec(Context& cx, FusedSlot& slot, Body body)
 {
     if (slot.disabled || !fused_enabled(cx)) return false;
     if (slot.prog && fused_epoch(slot.prog) != -2 && fused_epoch(slot.prog) != cx.scratch_epoch) fused_slot_reset(cx, slot);
+    // (Context::plan_clear has dropped the offset tables the program's items point into -- another solver state of the context was
+    // re-initialised after many different systems: compile again)
+    if (slot.prog && fused_plan_epoch(slot.prog) != cx.plan_epoch) fused_slot_reset(cx, slot);
     if (!slot.prog) {
         const bool dbg = getenv("AFESP_FUSED_DEBUG") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
@@ -115,7 +123,13 @@ inline bool fused_exec(Context& cx, FusedSlot& slot, Body body)
         }
         cx.rec = nullptr;
         const auto t1 = std::chrono::steady_clock::now();
-        slot.prog = fused_compile(cx, rec);
+        try {
+            slot.prog = fused_compile(cx, rec);
+        } catch (...) {
+            slot.disabled = true;      // (not compiled again every iteration: the direct path from now on)
+            slot.why = "fused_compile threw";
+            throw;
+        }
         if (dbg)
             fprintf(stderr, "afesp fused: recorded in %.2f ms, compiled in %.2f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());

@@ -332,6 +332,7 @@ struct FusedProgram {
     double* slabs = nullptr;
     uint32_t* ktab = nullptr;
     int64_t epoch = 0;
+    int64_t plan_epoch = 0;      // Context::plan_epoch it was compiled under: its items point into the plans' offset tables
     int launches = 0;
 };
 
@@ -494,8 +495,15 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
         r.fail("partial-sum slabs too large");
         return nullptr;
     }
-    FusedProgram* P = new FusedProgram();
+    // (anything below may throw -- an allocation, a copy, the wait: the program and its blocks then go back, and fused_exec marks the slot)
+    struct Holder {
+        Context& cx;
+        FusedProgram* p;
+        ~Holder() { if (p) fused_free(cx, p); }
+    } hold{cx, new FusedProgram()};
+    FusedProgram* P = hold.p;
     P->epoch = r.uses_scratch ? cx.scratch_epoch : -2;
+    P->plan_epoch = cx.plan_epoch;
     // the K-offset tables of the products in the form the kernel reads (32-bit byte offsets, interleaved, padded)
     std::vector<int64_t> ktab_at(ops.size(), 0);
     int64_t ktab_total = 0;
@@ -650,6 +658,7 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
             }
         }
     }
+    hold.p = nullptr;
     return P;
 }
 
@@ -703,6 +712,7 @@ void fused_free(Context& cx, FusedProgram* P)
 
 int fused_launches(const FusedProgram* P) { return P ? P->launches : 0; }
 int64_t fused_epoch(const FusedProgram* P) { return P ? P->epoch : -1; }
+int64_t fused_plan_epoch(const FusedProgram* P) { return P ? P->plan_epoch : -1; }
 
 void fused_slot_reset(Context& cx, FusedSlot& slot)
 {

@@ -9,6 +9,9 @@
 // tall index for the whole of K: its operand elements go from memory straight into MFMA fragment registers (lane (t, k) of
 // v_mfma_f64_16x16x4_f64 loads X(t0 + t, k0 + k): no LDS, no barrier in the stream, two chunks of up to 16 loads in flight per
 // wave), the skinny operand sits in LDS for the lifetime of the workgroup.
+// Operands must be finite wherever the offset tables reach: padded k of the last chunk are masked through the zeroed image of the
+// skinny operand, the tall operand is read from a clamped (valid) address and multiplied as loaded -- an Inf / NaN there would make
+// the masked product a NaN.
 #pragma once
 #include "gett.h"
 
