@@ -59,15 +59,17 @@ __global__ __launch_bounds__(256) void ring_tables_kernel(uint32_t* rc32, int64_
     }
 }
 
-// AFESP_RING_TG=0: the gather kernel's six launches at every size.  From o v = 2048 on (AFESP_RING_TG_MIN; read per call: tests
-// send small systems down this path): below that a launch has too few 128 x 128 tiles for the device.  Row offsets inside an
-// operand are 32-bit byte offsets: 8 Kc o v < 4 GiB.
+// AFESP_RING_TG=0: the gather kernel's six launches at every size.  From o v = 3584 on (28 row tiles; AFESP_RING_TG_MIN; read per
+// call: tests send small systems down this path): a launch needs about four 128 x 128 tiles per workgroup slot to beat the gather
+// kernel, whose tile shapes adapt to the extents (iteration, gather kernel / this path: o = 16, v = 160 8.23 / 8.16 ms, o = 18, v = 180
+// 14.6 / 15.0, o = 20, v = 200 23.9 / 22.6; profiles/r05_mid_sweep.txt).  Row offsets inside an operand are 32-bit byte offsets:
+// 8 Kc o v < 4 GiB.
 bool ring_tg_applies(const CCState& s)
 {
     const char* e = getenv("AFESP_RING_TG");
     if (e && e[0] == '0') return false;
     const char* m = getenv("AFESP_RING_TG_MIN");
-    const int64_t min_ov = m ? (int64_t)atoll(m) : (int64_t)2048;
+    const int64_t min_ov = m ? (int64_t)atoll(m) : (int64_t)3584;
     const int64_t ov = (int64_t)s.o * s.v, Kc = (ov + TG_BK - 1) / TG_BK * TG_BK;
     return !s.sharded && ov >= min_ov && ov >= 2 * TG_BK && 8 * Kc * ov < ((int64_t)1 << 32) - 4096;
 }
