@@ -1333,8 +1333,13 @@ int afesp_ccsd_iteration_flop(afesp_ctx* ctx, double* flop)
         const double pp = sym ? 2.0 * (os * ps * ps + oa * pa * pa) : 2.0 * O * O * V * V * ps;
         const double ooov = sym ? 2.0 * O * V * (os * ps + oa * pa) : 2.0 * O * O * O * V * V * V;
         const double o3v3 = O * O * O * V * V * V;
+        // large-system path (round 5): c <ij|ef> -> I_oooo and the hole-hole ladder over pair indices (the latter inside the pp-ladder's
+        // products), and the bare t(i,e) <ab|ej> term as a copy of x_voov instead of a third o^2 v^3 product
+        const bool large = !ccsd_uses_lanes(ctx->cc);
+        const double oooo = (sym && large) ? 4.0 * (os * os * ps + oa * oa * pa) : 2.0 * O * O * O * O * V * V;
+        const double o2v3 = large ? 16.0 : 18.0;
         if (flop)
-            *flop = pp + ooov + 12.0 * o3v3 + 2.0 * O * O * O * O * V * V + 2.0 * O * O * O * O * V + 18.0 * O * O * V * V * V +
+            *flop = pp + ooov + 12.0 * o3v3 + oooo + 2.0 * O * O * O * O * V + o2v3 * O * O * V * V * V +
                     2.0 * O * V * V * V + 14.0 * O * O * O * V * V;
     });
 }
