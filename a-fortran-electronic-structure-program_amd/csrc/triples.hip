@@ -1059,6 +1059,9 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         AFESP_HIP(hipGetLastError());
     }
     double* h = pub ? host_scalars_wait(cx, 6, pub_seq) : host_scalars(cx, 6);
+    // (the published sums can be seen before the runtime has marked the stamps in front of them complete: hipEventElapsedTime then says
+    // "device not ready" -- seen with six ranks sharing one GPU in a rehearsal, round 5)
+    if (!evs.empty()) AFESP_HIP(hipEventSynchronize(evs.back()));
     for (size_t q = 0; q + 2 < evs.size(); q += 3) {
         float a = 0.f, b = 0.f;
         AFESP_HIP(hipEventElapsedTime(&a, evs[q], evs[q + 1]));

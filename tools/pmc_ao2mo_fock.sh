@@ -28,7 +28,7 @@ for tag in ("ao", "fk"):
             for r in csv.DictReader(open(f)):
                 agg[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
             for k, v in agg.items():
-                if not any(s in k for s in ("pair_square", "pack_pairs", "gett_kernel", "tgemm_kernel", "fock_")):
+                if not any(s in k for s in ("pair_square", "pack_pairs", "gett_kernel", "tgemm_kernel", "tgemm_mixed_kernel", "fock_")):
                     continue
                 e = out["kernels"].setdefault(tag + ": " + k, {"dispatches": len(v)})
                 e["fetch_GB" if c == "FETCH_SIZE" else "write_GB"] = sum(v) / len(v) * 1024 * (2 if c == "FETCH_SIZE" else 1) / 1e9
@@ -37,6 +37,12 @@ for tag in ("ao", "fk"):
                 if k in dur:
                     e["ms_under_pmc"] = sum(dur[k]) / len(dur[k])
                     e["ms_per_call_under_pmc"] = sum(dur[k]) / 2
+tot = {"fetch_GB_per_call": 0.0, "write_GB_per_call": 0.0, "ms_per_call_under_pmc": 0.0}
+for k, e in out["kernels"].items():
+    if k.startswith("ao: "):
+        for q in tot: tot[q] += e.get(q, 0.0)
+tot["hbm_GB_per_call"] = tot["fetch_GB_per_call"] + tot["write_GB_per_call"]
+out["ao2mo_total_per_call"] = tot
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 PY
 echo done
