@@ -480,6 +480,7 @@ static void ao2mo_tg_xform(Context& cx, Ao2moTg& t, const double* in, double* ou
     t.groups_used += (int64_t)hv.size();
     AFESP_HIP(hipMemcpyAsync(dev, hv.data(), hv.size() * sizeof(TgGroup), hipMemcpyHostToDevice, cx.stream));
     TgProblem p{t.ct, in, out, t.rowA + row0, t.offCm + row0, (int)M, true, (int)((n - (t.Kc - TG_BK) + 3) / 4)};
+    p.tag = 2;
     // (rows that end at most 96 past a multiple of 128 -- n = 220: 92 -- take a 96-row last tile: three quarters of its MFMAs, tgemm.h)
     static const bool mixed_off = getenv("AFESP_AO2MO_MIXED") && getenv("AFESP_AO2MO_MIXED")[0] == '0';
     const int bm = (!mixed_off && M % TG_BM != 0 && M % TG_BM <= 96) ? TG_BM : 0;

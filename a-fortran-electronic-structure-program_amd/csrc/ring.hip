@@ -264,6 +264,7 @@ void ring_tg_intermediates(Context& cx, CCState& s)
     r->packed = false;
     const int ktail4 = (int)((r->ov - (r->Kc - TG_BK) + 3) / 4);
     TgProblem p{r->slab, r->slab, r->slab, r->rc32, r->cm1, (int)r->ov, true, ktail4};
+    p.tag = 1;
     AFESP_HIP(tgemm_launch(p, r->groups, 2, r->tiles, r->mx, cx.stream, cx.tg));
     // + the small terms: -I_ovov'[(i,b) | (j,a)] -= I_ovov(j,b,i,a),  I_voov'[(i,b) | (j,a)] += I_voov(b,j,i,a)
     permute_add(cx, -1.0, s.I_ovov, "jbia", 1.0, kview(r, r->nIo, s, 2, 0, 3, 1), "jbia");
@@ -278,6 +279,7 @@ void ring_tg_residual(Context& cx, CCState& s)
     if (!r || !r->live) throw Error(2, "ring_tg_residual: the intermediates of this iteration were not formed on this path");
     const int ktail4 = (int)((r->ov - (r->Kc - TG_BK) + 3) / 4);
     TgProblem p{r->slab, r->slab, r->slab, r->rc32, r->cm2, (int)r->ov, r->pairs2, ktail4};
+    p.tag = 1;
     AFESP_HIP(tgemm_launch(p, r->groups + 3, 2, r->tiles, r->mx, cx.stream, cx.tg));
     r->res_live = true;
 }

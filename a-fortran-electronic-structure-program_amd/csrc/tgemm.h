@@ -39,6 +39,10 @@ struct TgProblem {
     bool c_pairs = false;
     // groups of four valid k in the last K step of each of a group's two runs (1..4; the rest of that step is zero padding)
     int ktail4 = 4;
+    // which entry point of the (one) kernel body launches it: 0 tgemm_kernel (the (T) products), 1 tgemm_ring_kernel (the CCSD
+    // iteration's ring products), 2 tgemm_xform_kernel (AO->MO quarter transforms on 128-row tiles) -- names of their own so that a
+    // kernel trace's per-kernel averages mean something (a (T) launch is 21 ms, a ring launch 5.6, a transform 1-5)
+    int tag = 0;
 };
 
 constexpr int TG_BM = 128, TG_BN = 128, TG_BK = 16;

@@ -545,6 +545,9 @@ __device__ __forceinline__ void tgemm_body(const TgArgs& a)
 }
 
 __global__ __launch_bounds__(256, 2) void tgemm_kernel(TgArgs a) { tgemm_body<false>(a); }
+// the same body under the names of its other users (TgProblem::tag)
+__global__ __launch_bounds__(256, 2) void tgemm_ring_kernel(TgArgs a) { tgemm_body<false>(a); }
+__global__ __launch_bounds__(256, 2) void tgemm_xform_kernel(TgArgs a) { tgemm_body<false>(a); }
 // ... with 96-row tiles where the rows end (TgArgs::bm): the AO->MO transforms (220 rows = 128 + 96 instead of two 128-row tiles)
 __global__ __launch_bounds__(256, 2) void tgemm_mixed_kernel(TgArgs a) { tgemm_body<true>(a); }
 
@@ -565,6 +568,8 @@ void preload_tgemm()
     hipFuncAttributes at;
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(tgemm_kernel));
     (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(tgemm_mixed_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(tgemm_ring_kernel));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(tgemm_xform_kernel));
     (void)hipGetLastError();
 }
 
@@ -619,6 +624,8 @@ hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngrou
         a.tickets = st.tickets;
     }
     if (mixed) hipLaunchKernelGGL(tgemm_mixed_kernel, dim3(grid), dim3(256), 0, stream, a);
+    else if (p.tag == 1) hipLaunchKernelGGL(tgemm_ring_kernel, dim3(grid), dim3(256), 0, stream, a);
+    else if (p.tag == 2) hipLaunchKernelGGL(tgemm_xform_kernel, dim3(grid), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(tgemm_kernel, dim3(grid), dim3(256), 0, stream, a);
     ++(mixed ? st.launches_mixed : st.launches);
     return hipGetLastError();

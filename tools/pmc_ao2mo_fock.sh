@@ -28,7 +28,7 @@ for tag in ("ao", "fk"):
             for r in csv.DictReader(open(f)):
                 agg[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
             for k, v in agg.items():
-                if not any(s in k for s in ("pair_square", "pack_pairs", "gett_kernel", "tgemm_kernel", "tgemm_mixed_kernel", "fock_")):
+                if not any(s in k for s in ("pair_square", "pack_pairs", "gett_kernel", "tgemm_kernel", "tgemm_xform_kernel", "tgemm_mixed_kernel", "fock_")):
                     continue
                 e = out["kernels"].setdefault(tag + ": " + k, {"dispatches": len(v)})
                 e["fetch_GB" if c == "FETCH_SIZE" else "write_GB"] = sum(v) / len(v) * 1024 * (2 if c == "FETCH_SIZE" else 1) / 1e9
