@@ -783,6 +783,12 @@ int afesp_ccsd_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2
         if (!ctx->cc.ready) throw Error(1, "afesp_ccsd_set_amplitudes: no CCSD state");
         Context& cx = ctx->cx;
         AFESP_HIP(hipSetDevice(cx.device));
+        // (a large system holds I_ovov / I_voov and copies of the OLD amplitudes in the layout of its ring launches (ring.hip): an
+        // afesp_ccsd_update_amplitudes that follows without new intermediates reads the reference-layout tensors and the new amplitudes)
+        if (ring_live(ctx->cc)) {
+            ring_tg_materialize(cx, ctx->cc, ctx->cc.I_ovov, ctx->cc.I_voov);
+            ring_invalidate(ctx->cc);
+        }
         if (t1) AFESP_HIP(hipMemcpyAsync(ctx->cc.t1.d, t1, sizeof(double) * ctx->cc.t1.size(), hipMemcpyHostToDevice, cx.stream));
         if (t2) AFESP_HIP(hipMemcpyAsync(ctx->cc.t2.d, t2, sizeof(double) * ctx->cc.t2.size(), hipMemcpyHostToDevice, cx.stream));
         cx.sync();

@@ -121,6 +121,37 @@ def test_same_shape_state_is_initialised_again_where_it_lies():
             if name in tables:   # bit for bit the first walk
                 assert np.array_equal(tables[name][0], en[:nit + 1]) and np.array_equal(tables[name][1], out)
             tables[name] = (en[:nit + 1].copy(), out.copy())
+            # what a state may have grown on request before it is initialised again: the CR moments, the <ef|ab> slice
+            e.build_cr_intermediates()
+            cr = e.do_ccsd_t_spatial_cr()
+            assert abs(en[nit] + cr[5] / cr[3] - gold["cr_ccsd_pt_corr"]) < 1e-8
+            vvvv = e.tensor("v_vvvv")
+            assert np.max(np.abs(vvvv - vvvv.transpose(1, 0, 3, 2))) == 0.0
+
+
+@pytest.mark.parametrize("pp_sym", ["0", "1"])
+def test_reinitialised_state_follows_new_integrals(pp_sym, monkeypatch):
+    """Initialised again where it lies with OTHER integrals of the same extents (the next geometry of a scan), on both forms of the
+    pp-ladder and down the large-system path too: iteration energies and (T) against the oracle on the second system, after the first
+    one has left its amplitudes, DIIS history, on-request tensors and integral copies behind."""
+    from afesp_amd.capi import Engine
+    o, v = 5, 13
+    for large in ("0", "1"):
+        if large == "1":
+            monkeypatch.setenv("AFESP_SMALL_MAX", "0")
+            monkeypatch.setenv("AFESP_RING_TG_MIN", "1")
+        monkeypatch.setenv("AFESP_PP_SYM", pp_sym)
+        with Engine(0) as e:
+            for seed in (3, 4, 5):
+                n, lev, eri = molecules.synthetic_system(o, v, scale=0.05, seed=seed)
+                cc = orc.OracleCC(o, v, eri, lev, 4)
+                e.ccsd_init(o, v, lev, eri, 4)
+                nit, en, rm = e.do_ccsd_spatial(40, 1e-9, 1e-9)
+                onit, oen, _ = cc.solve(40, 1e-9, 1e-9)
+                assert nit == onit and np.max(np.abs(en[:nit + 1] - oen[:onit + 1])) < 1e-10, (seed, large)
+                assert np.max(np.abs(e.do_ccsd_t_spatial() - cc.triples(lev))) < 1e-10
+                e.tensor("v_vvvv")
+                e.tensor("I_vovv_p")
 
 
 @pytest.mark.parametrize("name", ["n2-cc-pvdz", "f2-cc-pvdz"])
