@@ -789,6 +789,7 @@ int afesp_ccsd_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2
             ring_tg_materialize(cx, ctx->cc, ctx->cc.I_ovov, ctx->cc.I_voov);
             ring_invalidate(ctx->cc);
         }
+        ctx->cc.amps_touched = true;
         if (t1) AFESP_HIP(hipMemcpyAsync(ctx->cc.t1.d, t1, sizeof(double) * ctx->cc.t1.size(), hipMemcpyHostToDevice, cx.stream));
         if (t2) AFESP_HIP(hipMemcpyAsync(ctx->cc.t2.d, t2, sizeof(double) * ctx->cc.t2.size(), hipMemcpyHostToDevice, cx.stream));
         cx.sync();

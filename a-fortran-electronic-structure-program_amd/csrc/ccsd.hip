@@ -289,6 +289,7 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     auto C = [&](double al, const Tensor& A, const char* la, const Tensor& B, const char* lb, double be, const Tensor& Cc,
                  const char* lc) { contract(cx, al, A, la, B, lb, be, Cc, lc); };
     ccsd_refresh_sharding(cx, s);
+    s.amps_touched = false;
     // this rank's slice [v0, v1) of the last (virtual) index of I_ovov / I_voov: the whole range unless the iteration is split
     int64_t v0, v1;
     slice_bounds(s, &v0, &v1);
@@ -670,7 +671,9 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     // o v^3 integrals (0.32 -> 0.08 ms at o = 20, v = 200)
     // (ring.hip: two of the three ring terms open the residual -- the LDS-DMA GEMM stores, it does not accumulate -- and everything else adds to them)
     if (ring) ring_tg_residual(cx, s);                                              // :1680-1695 ring terms, all three
-    if (open_with_vvov) permute_add(cx, 1.0, s.x_voov, "bija", ring ? 1.0 : 0.0, s.r2, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
+    // (amplitudes replaced from outside since the intermediates were formed: x_voov carries the OLD t1, the reference's update the new one)
+    if (open_with_vvov && !s.amps_touched) permute_add(cx, 1.0, s.x_voov, "bija", ring ? 1.0 : 0.0, s.r2, "ijab");   // :1700, bare part: t(i,e) <ab|ej>
+    else if (open_with_vvov) C(1.0, s.t1, "ie", s.v_vvov, "baje", ring ? 1.0 : 0.0, s.r2, "ijab");
     // (split iteration: every term of the T2 residual is evaluated for this rank's slice of b -- or of a, where that is the index the
     // sliced intermediate carries -- into the zeroed partial residual: the replicated residual has no terms of its own)
     if (!sh) {

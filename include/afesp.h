@@ -70,7 +70,9 @@ int afesp_ccsd_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2
  * r2 is the T2 residual before P(ia/jb) up to terms held as their images under (i <-> j, a <-> b): r2(ijab) + r2(jiba) is what
  * equals the same sum of the reference's tmp_t2, src/ccsd.f90:1720-1728) */
 int afesp_ccsd_get_tensor(afesp_ctx* ctx, const char* name, double* out, int64_t capacity);
-/* intermediates / amplitude equations separately (src/ccsd.f90:350,357), for term-by-term parity tests */
+/* intermediates / amplitude equations separately (src/ccsd.f90:350,357), for term-by-term parity tests.  The two calls are ONE update
+ * of one set of amplitudes, as in the reference's loop: terms are regrouped between them (the t1-dressed parts of I_vovv_p, the bare
+ * t(i,e) <ab|ej> term), so amplitudes replaced in between give a residual that is neither the old nor the new one. */
 int afesp_ccsd_update_intermediates(afesp_ctx* ctx);
 int afesp_ccsd_update_amplitudes(afesp_ctx* ctx);
 

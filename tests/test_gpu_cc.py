@@ -129,6 +129,34 @@ def test_same_shape_state_is_initialised_again_where_it_lies():
             assert np.max(np.abs(vvvv - vvvv.transpose(1, 0, 3, 2))) == 0.0
 
 
+def test_amplitudes_set_again_between_intermediates_and_update(eng, monkeypatch):
+    """A large system keeps I_ovov / I_voov and copies of the amplitudes in the layout of its ring launches (csrc/ring.hip).
+    afesp_ccsd_set_amplitudes between afesp_ccsd_update_intermediates and afesp_ccsd_update_amplitudes -- here with the same values: the
+    two calls are one update of ONE set of amplitudes (include/afesp.h) -- turns them back into the reference's layout, and the update
+    then runs on the gather kernel: same intermediates, same residuals."""
+    monkeypatch.setenv("AFESP_SMALL_MAX", "0")
+    monkeypatch.setenv("AFESP_RING_TG_MIN", "1")
+    o, v = 4, 9
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05)
+    cc = orc.OracleCC(o, v, eri, e, 8)
+    eng.ccsd_init(o, v, e, eri, 8)
+    rng = np.random.default_rng(9)
+    t1 = 0.05 * rng.standard_normal((o, v))
+    t2 = 0.05 * rng.standard_normal((o, o, v, v))
+    t2 = 0.5 * (t2 + t2.transpose(1, 0, 3, 2))
+    cc.t1[...] = t1; cc.t2[...] = t2
+    eng.set_amplitudes(t1, t2)
+    cc.L.orc_cc_intermediates(cc.h)
+    eng.update_intermediates()
+    eng.set_amplitudes(t1, t2)
+    for name in ("I_ovov", "I_voov"):
+        assert np.max(np.abs(eng.tensor(name) - cc.field(name))) < 1e-12, name
+    cc.L.orc_cc_amplitudes(cc.h)
+    eng.update_amplitudes()
+    assert np.max(np.abs(eng.tensor("r1") - cc.field("r1"))) < 1e-12
+    assert np.max(np.abs(_p(eng.tensor("r2")) - _p(cc.field("r2")))) < 1e-12
+
+
 @pytest.mark.parametrize("pp_sym", ["0", "1"])
 def test_reinitialised_state_follows_new_integrals(pp_sym, monkeypatch):
     """Initialised again where it lies with OTHER integrals of the same extents (the next geometry of a scan), on both forms of the
