@@ -29,8 +29,9 @@ static int run_big(int argc, char** argv)
     std::vector<uint32_t> t32((size_t)M + (size_t)ng * N);
     std::vector<int64_t> t64((size_t)M + (size_t)ng * N);
     // C: pairs of columns interleaved (tgemm.h c_pairs): C(m, n) at 2 m + (n & 1) + 2 M (n >> 1)
-    for (int m = 0; m < M; ++m) { t32[m] = (uint32_t)((size_t)8 * Kc * m); t64[m] = 2 * m; }
-    for (int n = 0; n < ng * N; ++n) { t32[(size_t)M + n] = (uint32_t)((size_t)8 * Kc * n); t64[(size_t)M + n] = (n & 1) + (int64_t)2 * M * (n >> 1); }
+    const bool csmall = getenv("TG_CSMALL") != nullptr;   // diagnostic: every tile's stores land in the same 128 KiB (no HBM write traffic)
+    for (int m = 0; m < M; ++m) { t32[m] = (uint32_t)((size_t)8 * Kc * m); t64[m] = csmall ? 2 * (m % 128) : 2 * m; }
+    for (int n = 0; n < ng * N; ++n) { t32[(size_t)M + n] = (uint32_t)((size_t)8 * Kc * n); t64[(size_t)M + n] = csmall ? (n & 1) + (int64_t)2 * 128 * ((n >> 1) % 64) : (n & 1) + (int64_t)2 * M * (n >> 1); }
     hipMemcpy(d32, t32.data(), t32.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d64, t64.data(), t64.size() * 8, hipMemcpyHostToDevice);
     std::vector<TgGroup> g(ng + 1);
     const int gm = tgemm_group_m(M, nt, g_bme);
