@@ -214,6 +214,9 @@ void k_pp_expand(Context& cx, double* pp, const double* ps, const double* pa, in
                  int64_t p0 = 0, int64_t p1 = -1);   // rows [p0, p1) of PP only (a rank's share); default: all
 void k_vvx_sympack(Context& cx, double* ws, double* wa, const double* x, int v, int64_t ncol, int64_t ks, int64_t ka);
 void k_pair_expand_add(Context& cx, double* out, const double* ps, const double* pa, int o, int64_t ncol, int64_t ns, int64_t na);
+// r1x(i,a) = sum_m [2 X(m,i,m,a) - X(i,m,m,a)] of X(j,k,i',a) = Ts(jk; i'a) +- Ta(jk; i'a) (the pair-form product of t2 with <ef|ia>, columns
+// (i',a) = i' + o a): the term asym(m,i,e,f) <ef|ma> of the T1 equation (src/ccsd.f90:1569-1631) as a trace of that product
+void k_ooov_r1_trace(Context& cx, double* r1x, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na);
 // out[0] = sum (2 v(ijab) - v(ijba)) (t2 + t1 t1), out[1] = sum (t2 - t2_old)^2 ; then t2_old = t2
 void k_cc_energy(Context& cx, double* out2, const double* v_oovv, const double* t1, const double* t2, double* t2_old,
                  int o, int v);

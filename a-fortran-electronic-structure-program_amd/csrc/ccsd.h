@@ -50,6 +50,8 @@ struct CCState : DiisRing {
     double *oo_vs = nullptr, *oo_va = nullptr;      // 1/2 (<ij|ef> +- <ij|fe>) over pairs (frozen): I_oooo's c <ij|ef> term in pair form
     double *oo_xs = nullptr, *oo_xa = nullptr;      // its two results, (kl) x (ij) pairs
     bool cs_packed = false;                         // pp_cs / pp_ca hold c+- of the current amplitudes (ccsd_intermediates)
+    double* r1x = nullptr;                          // asym(m,i,e,f) <ef|ma> as a trace of the pair-form t2 <ef|ia> product (ccsd_ooov_pair_form)
+    bool r1x_valid = false;
     bool amps_touched = true;                       // t1 / t2 were replaced from outside since the last ccsd_intermediates (afesp_ccsd_set_amplitudes)
     int64_t pp_nm = 0;                                     // rows the row tables cover: max(v(v+1)/2, o v)
     double *ov_ws = nullptr, *ov_wa = nullptr;             // the same split of <ef|ia> (v_vvov) for I_ooov_p, built at init

@@ -127,6 +127,7 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
             A(s.ov_ws, lds * O * V);
             A(s.pp_ts, ns * ks);
             A(s.oo_vs, ns * ks); A(s.oo_xs, ns * ns);
+            A(s.r1x, O * V);
             if (npa > 0 && na > 0) {
                 A(s.pp_va, lda * npa); A(s.pp_ca, na * kx); A(s.pp_pa, na * nm);
                 A(s.ov_wa, lda * O * V);
@@ -193,7 +194,7 @@ void ccsd_free(Context& cx, CCState& s)
                       s.w_oovo.d, s.D1.d, s.D2.d, s.amp, s.r1.d, s.t2_old.d, s.I_vo.d, s.I_vv.d, s.I_oo_p.d, s.I_oo.d, s.c.d,
                       s.asym.d, s.x_voov.d, s.I_oooo.d, s.I_ovov.d, s.I_voov.d, s.I_ooov_p.d, s.z_ooov.d, s.amp_s, s.hist_t,
                       s.hist_e, s.coef, s.I_vovv_pp.d, s.I_ooov_pp.d, s.pp, (double*)s.pp_tab, s.pp_vs, s.pp_va, s.pp_cs,
-                      s.pp_ca, s.pp_ps, s.pp_pa, s.bmat, s.ov_ws, s.ov_wa, s.pp_ts, s.pp_ta, s.oo_vs, s.oo_va, s.oo_xs, s.oo_xa};
+                      s.pp_ca, s.pp_ps, s.pp_pa, s.bmat, s.ov_ws, s.ov_wa, s.pp_ts, s.pp_ta, s.oo_vs, s.oo_va, s.oo_xs, s.oo_xa, s.r1x};
     for (double* b : bufs) cx.release(b);
     // Contraction plans are keyed by shape and stay valid for the life of the context (the AO->MO plans carry tables of
     // n^2 npair entries: rebuilding them costs a quarter of a second at n = 220), so a new system of the same extents finds
@@ -290,6 +291,7 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
                  const char* lc) { contract(cx, al, A, la, B, lb, be, Cc, lc); };
     ccsd_refresh_sharding(cx, s);
     s.amps_touched = false;
+    s.r1x_valid = false;
     // this rank's slice [v0, v1) of the last (virtual) index of I_ovov / I_voov: the whole range unless the iteration is split
     int64_t v0, v1;
     slice_bounds(s, &v0, &v1);
@@ -615,6 +617,13 @@ void ccsd_ooov_pair_form(Context& cx, CCState& s, double* out, int64_t a0, int64
     }
     (void)np; (void)npa;
     k_pair_expand_add(cx, out + O * O * m0, s.pp_ps + ns * m0, s.ov_wa ? s.pp_pa + na * m0 : nullptr, s.o, M, ns, na);
+    // The T1 equation's asym(m,i,e,f) <ef|ma> (src/ccsd.f90:1569-1631) is a trace of the product just formed: with X(j,k,i',a) =
+    // sum_ef t2(jkef) <ef|i'a> it is sum_m [2 X(m,i,m,a) - X(i,m,m,a)] -- o^2 v sums of o terms out of the two results, instead of a
+    // pass over the o v^3 integrals (0.34 ms at o = 20, v = 200) and a re-laid-out copy of asym_t2 (0.07).  Whole products only.
+    if (out == s.I_ooov_p.d && M == O * V && !cx.rec) {
+        k_ooov_r1_trace(cx, s.r1x, s.pp_ps, s.ov_wa ? s.pp_pa : nullptr, s.o, s.v, ns, na);
+        s.r1x_valid = true;
+    }
 }
 
 void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
@@ -660,7 +669,8 @@ void ccsd_amplitudes(Context& cx, CCState& s, bool defer_update)
     }
     C(-1.0, s.v_ovov, "maie", s.t1, "me", par ? 0.0 : 1.0, r1b, "ia");
     C(-1.0, s.v_oovo, "mien", s.asym, "mnea", 1.0, r1b, "ia");
-    if (!sh) C(1.0, s.asym, "mief", s.v_vvov, "efma", 1.0, r1b, "ia");
+    if (!sh && s.r1x_valid && !par && !cx.rec) k_axpby(cx, r1b.d, 1.0, s.r1x, 1.0, r1b.size());   // (formed with the t2 <ef|ia> product: ccsd_ooov_pair_form)
+    else if (!sh) C(1.0, s.asym, "mief", s.v_vvov, "efma", 1.0, r1b, "ia");
     lane(1);
     // ---- T2, Eq. 44                                                    ccsd.f90:1637-1716
     // (large-system path: the streamed product over <ab|ej> opens the residual instead of accumulating into it -- an accumulating

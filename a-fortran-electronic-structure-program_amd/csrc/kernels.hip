@@ -645,6 +645,31 @@ __global__ void pair_expand_add_kernel(double* out, const double* ps, const doub
         out[x] += val;
     }
 }
+__global__ void ooov_r1_trace_kernel(double* r1x, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na)
+{
+    const int64_t n = (int64_t)o * v;
+    GRID_STRIDE(x, n)
+    {
+        const int i = (int)(x % o), a = (int)(x / o);
+        double s = 0.0;
+        for (int m = 0; m < o; ++m) {
+            const int lo = m < i ? m : i, hi = m < i ? i : m;
+            const int64_t col = m + (int64_t)o * a;
+            // 2 X(m,i,m,a) - X(i,m,m,a) = Ts + 3 sgn Ta, sgn = +1 for m < i, -1 for m > i (X(j,k,.) = Ts + Ta for j < k, Ts - Ta for j > k)
+            s += ps[(int64_t)hi * (hi + 1) / 2 + lo + ns * col];
+            if (pa && m != i) {
+                const double w = pa[(int64_t)hi * (hi - 1) / 2 + lo + na * col];
+                s += m < i ? 3.0 * w : -3.0 * w;
+            }
+        }
+        r1x[x] = s;
+    }
+}
+void k_ooov_r1_trace(Context& cx, double* r1x, const double* ps, const double* pa, int o, int v, int64_t ns, int64_t na)
+{
+    if (cx.rec) throw Error(2, "k_ooov_r1_trace: not part of a recorded sequence");
+    LAUNCH(ooov_r1_trace_kernel, dim3(grid_for((int64_t)o * v)), r1x, ps, pa, o, v, ns, na);
+}
 void k_vvx_sympack(Context& cx, double* ws, double* wa, const double* x, int v, int64_t ncol, int64_t ks, int64_t ka)
 {
     LAUNCH(vvx_sympack_kernel, dim3(grid_for((int64_t)v * v * ncol, 65536)), ws, wa, x, v, ncol, ks, ka);

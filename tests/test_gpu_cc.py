@@ -221,6 +221,9 @@ def test_one_iteration_term_by_term(eng, o, v, fused, monkeypatch):
         # "ring": the large-system path as config 5 runs it -- the six o^3 v^3 ring products as two launches of the LDS-DMA GEMM
         # (csrc/ring.hip; from o v = 2048 by itself); "large": the same path with those products on the gather kernel
         monkeypatch.setenv("AFESP_RING_TG_MIN", "1" if fused == "ring" else "1000000")
+        if fused == "ring":
+            # ... and the pair forms at every size: there the T1 equation's asym(m,i,e,f) <ef|ma> is a trace of the t2 <ef|ia> product
+            monkeypatch.setenv("AFESP_PP_SYM", "1")
         fused = 0
     if o * v > 100:
         from afesp_amd import inputs
