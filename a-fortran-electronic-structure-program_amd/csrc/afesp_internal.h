@@ -96,6 +96,7 @@ struct Context {
     TgLaunchState tg;                     // ticket counters / grid size of this context's tgemm_kernel launches (tgemm.h)
     unsigned long long n_tall = 0, n_gett = 0;   // launches of the streamed tall x skinny kernel / the gather kernel by contract() (afesp_launch_counts)
     bool in_repack = false;               // set while contract() runs on a re-laid-out operand
+    GettProblem* capture = nullptr;       // set by contract_pair: the next product is handed back instead of being launched
     // Lanes: extra streams (each with its own split-K workspace) on which independent chains of small launches run side
     // by side.  `stream` / `ws` above always denote the lane in use; lane 0 is the context's main stream.
     struct Lane {
@@ -179,6 +180,21 @@ Tensor view(double* d, std::initializer_list<int64_t> dims);
 void contract(Context& cx, double alpha, const Tensor& A, const char* la, const Tensor& B, const char* lb, double beta,
               const Tensor& C, const char* lc, int nbatch = 1, const int64_t* bA = nullptr, const int64_t* bB = nullptr,
               const int64_t* bC = nullptr, int force_split = 0, int force_tm = 0, int force_tn = 0);
+
+// Two products that stream ONE tall array against ONE skinny matrix, enumerated alike in both label strings (t(j,e) <eb|ia> and
+// <be|ia> t(j,e)): one launch in which the array crosses HBM once where the pair qualifies (tall.h, tall_dual_kernel), otherwise
+// the two calls of contract() one after the other.
+struct ContractCall {
+    double alpha;
+    const Tensor* A;
+    const char* la;
+    const Tensor* B;
+    const char* lb;
+    double beta;
+    const Tensor* C;
+    const char* lc;
+};
+void contract_pair(Context& cx, const ContractCall& c1, const ContractCall& c2);
 
 // out[lo] = beta * out[lo] + alpha * in[li]  (li is a permutation of lo)
 void permute_add(Context& cx, double alpha, const Tensor& in, const char* li, double beta, const Tensor& out,

@@ -358,7 +358,9 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     if (ivv_diag && s.sharded) {
         if (v1 > v0) C(1.0, s.t1, "je", sl(s.v_vvov, 3), "ebia", 0.0, sl(s.I_ovov, 3), "jbia");
     } else if (ivv_diag) {
-        C(1.0, s.t1, "je", s.v_vvov, "ebia", 0.0, s.I_ovov, "jbia");
+        // y and x_voov (below) in one launch: both stream <eb|ia> against t1, one along each of its two leading indices -- the o v^3
+        // integrals cross HBM once for the two (tall.h, tall_dual_kernel; contract_pair falls back to the two products)
+        contract_pair(cx, {1.0, &s.t1, "je", &s.v_vvov, "ebia", 0.0, &s.I_ovov, "jbia"}, {1.0, &s.v_vvov, "beia", &s.t1, "je", 0.0, &s.x_voov, "bjia"});
     } else if (v1 > v0) {
         k_copy(cx, s.I_ovov.d + a_off, s.v_ovov.d + a_off, a_cnt);
         if (!ring) C(-0.5, s.v_oovv, "mibe", sl(s.c, 2), "mjae", 1.0, sl(s.I_ovov, 3), "jbia");   // (o^3 v^3)
@@ -369,7 +371,7 @@ void ccsd_intermediates(Context& cx, CCState& s, bool save_for_diis)
     // x_voov(b,j,i,a) = <be|ia> t(j,e)                                   ccsd.f90:1275-1290
     // (split iteration: only this rank's slice of a is ever read -- by I_voov and by the x_voov term of I_ooov_p below)
     if (s.sharded) { if (v1 > v0) C(1.0, sl(s.v_vvov, 3), "beia", s.t1, "je", 0.0, sl(s.x_voov, 3), "bjia"); }
-    else C(1.0, s.v_vvov, "beia", s.t1, "je", 0.0, s.x_voov, "bjia");
+    else if (!ivv_diag) C(1.0, s.v_vvov, "beia", s.t1, "je", 0.0, s.x_voov, "bjia");
     if (ivv_diag && v1 > v0) {
         k_ivv_diag(cx, s.I_vv.d, s.I_ovov.d, s.x_voov.d, s.o, s.v, (int)v0, (int)v1);
         k_axpby(cx, s.I_ovov.d + a_off, 1.0, s.v_ovov.d + a_off, 1.0, a_cnt);

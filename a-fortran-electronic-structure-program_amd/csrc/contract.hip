@@ -782,6 +782,11 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
     g.a_kcontig = p.a_kc; g.b_kcontig = p.b_kc;
     g.a_munit = p.a_mu; g.b_nunit = p.b_nu;
     g.wide = p.wide && ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.B % 16 == 0);
+    if (cx.capture && !cx.rec) {   // contract_pair: the planned product goes back to it
+        *cx.capture = g;
+        cx.capture = nullptr;
+        return;
+    }
     if (cx.rec) {   // launch-fused path: the product joins the recording instead of being launched
         auto span = [](const Tensor& t) {
             int64_t s = 1;
@@ -816,6 +821,46 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
     const double fl = 2.0 * g.M * (double)g.N * g.K * nbatch, by = 8.0 * (A0.size() + B0.size() + C.size());
     fprintf(stderr, "contract %-6s,%-6s>%-6s M %7d N %7d K %7d akc %d bkc %d wide %d %9.1f us %6.2f TF %7.1f GB/s%s\n", la0, lb0, lc, g.M, g.N,
             g.K, (int)g.a_kcontig, (int)g.b_kcontig, (int)g.wide, ms * 1e3, fl / ms * 1e-9, by / ms * 1e-6, cx.in_repack ? "  (repacked)" : tall ? "  (tall)" : "");
+}
+
+void contract_pair(Context& cx, const ContractCall& c1, const ContractCall& c2)
+{
+    static const bool trace = getenv("AFESP_CONTRACT_TRACE") != nullptr;
+    auto plain = [&](const ContractCall& c) { contract(cx, c.alpha, *c.A, c.la, *c.B, c.lb, c.beta, *c.C, c.lc); };
+    if (cx.rec || trace) {
+        plain(c1);
+        plain(c2);
+        return;
+    }
+    GettProblem g[2];
+    const ContractCall* cc[2] = {&c1, &c2};
+    for (int i = 0; i < 2; ++i) {
+        g[i].M = 0;
+        cx.capture = &g[i];
+        try {
+            plain(*cc[i]);
+        } catch (...) {
+            cx.capture = nullptr;
+            throw;
+        }
+        if (cx.capture) {   // (nothing was planned: an empty product)
+            cx.capture = nullptr;
+            g[i].M = 0;
+        }
+    }
+    auto one = [&](const GettProblem& p) {
+        if (p.M <= 0 || p.N <= 0) return;
+        const bool tall = tall_eligible(p);
+        ++(tall ? cx.n_tall : cx.n_gett);
+        AFESP_HIP(tall ? tall_launch(p, cx.stream) : gett_launch(p, cx.ws, cx.stream, 0, 0, 0));
+    };
+    if (g[0].M > 0 && g[1].M > 0 && tall_dual_eligible(g[0], g[1])) {
+        ++cx.n_tall;
+        AFESP_HIP(tall_launch_dual(g[0], g[1], cx.stream));
+    } else {
+        one(g[0]);
+        one(g[1]);
+    }
 }
 
 // ------------------------------------------------------------------ permute_add

@@ -19,6 +19,11 @@ namespace afesp {
 
 bool tall_eligible(const GettProblem& p);                          // shape test; batched problems are not taken
 hipError_t tall_launch(const GettProblem& p, hipStream_t stream);   // precondition: tall_eligible(p)
+// Two products that stream the same tall array against the same skinny matrix, one along each of the array's two leading indices, in ONE
+// launch: the array crosses HBM once (tall.hip, tall_dual_kernel).  The caller vouches that both problems enumerate the skinny matrix
+// alike (offYk / offYs of both describe the same image); everything else is checked.
+bool tall_dual_eligible(const GettProblem& p1, const GettProblem& p2);
+hipError_t tall_launch_dual(const GettProblem& p1, const GettProblem& p2, hipStream_t stream);   // precondition: tall_dual_eligible
 void preload_tall();
 
 }  // namespace afesp

@@ -31,27 +31,14 @@ struct TallArgs {
 
 constexpr int TALL_EP = 16;   // tiles of a wave whose row offsets sit in LDS at a time
 
+// One wave's stream: tiles w, w + nwaves, ... of problem `a` (its K-offset table ktab and the image Yl of the skinny operand in LDS,
+// rX = this wave's 2 * TALL_EP * 16 table entries)
 template <bool TALL_N, int NS, int CH>
-__global__ __launch_bounds__(512) void tall_kernel(TallArgs a)
+__device__ __forceinline__ void tall_stream(const TallArgs& a, const double* Yl, const int64_t* ktab, int64_t* rX, int w, int nwaves, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) double tall_lds[];
-    constexpr int SP = NS == 1 ? 16 : 48;   // row stride of the Y image: 32 dwords mod 64, a ds_read_b64 of (4 k) x (16 s) is conflict-free
-    const int KR = a.nch * CH * 4;          // rows of the image: K padded to whole chunks
-    double* Yl = tall_lds;
-    int64_t* ktab = reinterpret_cast<int64_t*>(tall_lds + (size_t)KR * SP);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // per wave: the X row offsets and the C row offsets of its next TALL_EP tiles (read back by other lanes of the same wave only)
-    int64_t* rX = ktab + KR + (size_t)wave * (2 * TALL_EP * 16);
+    constexpr int SP = NS == 1 ? 16 : 48;
     int64_t* rC = rX + TALL_EP * 16;
-    for (int idx = threadIdx.x; idx < KR * 16 * NS; idx += blockDim.x) {
-        const int k = idx / (16 * NS), s = idx % (16 * NS);
-        Yl[k * SP + s] = (k < a.K && s < a.S) ? a.Y[a.offYk[k] + a.offYs[s]] : 0.0;
-    }
-    for (int k = threadIdx.x; k < KR; k += blockDim.x) ktab[k] = a.offXk[k < a.K ? k : a.K - 1];
-    __syncthreads();
-
     const int lt = lane & 15, lk = lane >> 4;
-    const int nwaves = (int)gridDim.x * 8, w = (int)blockIdx.x * 8 + wave;
     if (w >= a.ntiles) return;
     const int ntl = (a.ntiles - w + nwaves - 1) / nwaves;   // tiles of this wave: w, w + nwaves, ...
     const int64_t* kt = ktab + lk;
@@ -166,6 +153,57 @@ __global__ __launch_bounds__(512) void tall_kernel(TallArgs a)
     }
 }
 
+template <bool TALL_N, int NS, int CH>
+__global__ __launch_bounds__(512) void tall_kernel(TallArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double tall_lds[];
+    constexpr int SP = NS == 1 ? 16 : 48;   // row stride of the Y image: 32 dwords mod 64, a ds_read_b64 of (4 k) x (16 s) is conflict-free
+    const int KR = a.nch * CH * 4;          // rows of the image: K padded to whole chunks
+    double* Yl = tall_lds;
+    int64_t* ktab = reinterpret_cast<int64_t*>(tall_lds + (size_t)KR * SP);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // per wave: the X row offsets and the C row offsets of its next TALL_EP tiles (read back by other lanes of the same wave only)
+    int64_t* rX = ktab + KR + (size_t)wave * (2 * TALL_EP * 16);
+    for (int idx = threadIdx.x; idx < KR * 16 * NS; idx += blockDim.x) {
+        const int k = idx / (16 * NS), s = idx % (16 * NS);
+        Yl[k * SP + s] = (k < a.K && s < a.S) ? a.Y[a.offYk[k] + a.offYs[s]] : 0.0;
+    }
+    for (int k = threadIdx.x; k < KR; k += blockDim.x) ktab[k] = a.offXk[k < a.K ? k : a.K - 1];
+    __syncthreads();
+    tall_stream<TALL_N, NS, CH>(a, Yl, ktab, rX, (int)blockIdx.x * 8 + wave, (int)gridDim.x * 8, lane);
+}
+
+// Two products that stream the SAME tall array against the SAME skinny matrix, one along each of the array's two leading indices
+// (y(j; b,i,a) = sum_e t(j,e) <eb|ia> and x(b; j,i,a) = sum_e <be|ia> t(j,e), src/ccsd.f90:1165-1191, :1275-1290): waves 0-3 of a
+// workgroup run problem a (C's lanes along s), waves 4-7 problem b (C's lanes along t), tile for tile side by side -- tile n of either
+// is a strip of the same v x v slab, and the workgroups of an XCD take runs of consecutive tiles, so that whichever wave comes second
+// finds the slab in that XCD's L2: the array crosses HBM once instead of twice.  One image of the skinny matrix serves both.
+template <int NS, int CH>
+__global__ __launch_bounds__(512) void tall_dual_kernel(TallArgs a, TallArgs b)
+{
+    extern __shared__ __attribute__((aligned(16))) double tall_lds[];
+    constexpr int SP = NS == 1 ? 16 : 48;
+    const int KR = a.nch * CH * 4;
+    double* Yl = tall_lds;
+    int64_t* ktab = reinterpret_cast<int64_t*>(tall_lds + (size_t)KR * SP);   // [a's | b's]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int64_t* rX = ktab + 2 * KR + (size_t)wave * (2 * TALL_EP * 16);
+    for (int idx = threadIdx.x; idx < KR * 16 * NS; idx += blockDim.x) {
+        const int k = idx / (16 * NS), s = idx % (16 * NS);
+        Yl[k * SP + s] = (k < a.K && s < a.S) ? a.Y[a.offYk[k] + a.offYs[s]] : 0.0;
+    }
+    for (int k = threadIdx.x; k < KR; k += blockDim.x) {
+        ktab[k] = a.offXk[k < a.K ? k : a.K - 1];
+        ktab[KR + k] = b.offXk[k < b.K ? k : b.K - 1];
+    }
+    __syncthreads();
+    // workgroup b of the launch runs on XCD b % 8: virtual workgroup numbers that are consecutive inside an XCD
+    const int g = (int)gridDim.x, vb = (g & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (g >> 3) + ((int)blockIdx.x >> 3);
+    const int w = vb * 4 + (wave & 3), nw = g * 4;
+    if (wave < 4) tall_stream<false, NS, CH>(a, Yl, ktab, rX, w, nw, lane);
+    else tall_stream<true, NS, CH>(b, Yl, ktab + KR, rX, w, nw, lane);
+}
+
 // chunk length and count for nl = ceil(K / 4) loads per tile: the fewest padded loads, the longer chunk on a tie
 static void tall_chunks(int K, int* ch, int* nch)
 {
@@ -225,9 +263,8 @@ static hipError_t tall_launch_ch(int ch, const TallArgs& a, size_t lds, int grid
     return hipErrorInvalidValue;
 }
 
-hipError_t tall_launch(const GettProblem& p, hipStream_t stream)
+static TallArgs tall_args(const GettProblem& p, int* ch)
 {
-    if (!tall_eligible(p)) return hipErrorInvalidValue;
     const bool tall_n = p.N > p.M;   // C's lanes (n) run along the tall index
     TallArgs a;
     a.X = tall_n ? p.B : p.A;
@@ -244,20 +281,83 @@ hipError_t tall_launch(const GettProblem& p, hipStream_t stream)
     a.K = p.K;
     a.alpha = p.alpha;
     a.beta = p.beta;
-    int ch;
-    tall_chunks(p.K, &ch, &a.nch);
+    tall_chunks(p.K, ch, &a.nch);
     a.ntiles = (a.T + 15) / 16;
+    return a;
+}
+static int tall_cus()
+{
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
+    return cus;
+}
+
+hipError_t tall_launch(const GettProblem& p, hipStream_t stream)
+{
+    if (!tall_eligible(p)) return hipErrorInvalidValue;
+    const bool tall_n = p.N > p.M;
+    int ch;
+    const TallArgs a = tall_args(p, &ch);
+    const int cus = tall_cus();
     const size_t lds = tall_lds_bytes(p.K, a.S);
     // (a second workgroup per CU where the LDS images and -- one 16-column fragment -- the registers allow it)
     const int per_cu = (a.S <= 16 && lds <= (size_t)76 * 1024) ? 2 : 1;
     const int grid = std::max(1, std::min(cus * per_cu, (a.ntiles + 7) / 8));
     if (a.S <= 16) return tall_n ? tall_launch_ch<true, 1>(ch, a, lds, grid, stream) : tall_launch_ch<false, 1>(ch, a, lds, grid, stream);
     return tall_n ? tall_launch_ch<true, 2>(ch, a, lds, grid, stream) : tall_launch_ch<false, 2>(ch, a, lds, grid, stream);
+}
+
+// ---- two products over one tall array in one launch (tall_dual_kernel)
+static size_t tall_dual_lds_bytes(int K, int S)
+{
+    int ch, nch;
+    tall_chunks(K, &ch, &nch);
+    return tall_lds_bytes(K, S) + (size_t)nch * ch * 4 * sizeof(int64_t);   // (the second problem's K-offset table)
+}
+
+bool tall_dual_eligible(const GettProblem& p1, const GettProblem& p2)
+{
+    static const bool off = [] { const char* e = getenv("AFESP_TALL_DUAL"); return e && e[0] == '0'; }();
+    if (off || !tall_eligible(p1) || !tall_eligible(p2)) return false;
+    const bool n1 = p1.N > p1.M, n2 = p2.N > p2.M;
+    if (n1 == n2) return false;   // one product with C's lanes along the skinny index, one along the tall one
+    int c1, c2;
+    const TallArgs a = tall_args(p1, &c1), b = tall_args(p2, &c2);
+    // the same tall array, the same skinny matrix (the CALLER vouches that both products enumerate its two indices alike: one image
+    // of it serves both), the same extents
+    if (a.X != b.X || a.Y != b.Y || a.T != b.T || a.S != b.S || a.K != b.K || c1 != c2 || a.nch != b.nch) return false;
+    return tall_dual_lds_bytes(p1.K, a.S) <= (size_t)150 * 1024;
+}
+
+template <int NS, int CH>
+static hipError_t tall_dual_launch_one(const TallArgs& a, const TallArgs& b, size_t lds, int grid, hipStream_t st)
+{
+    static const hipError_t attr =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(tall_dual_kernel<NS, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((tall_dual_kernel<NS, CH>), dim3(grid), dim3(512), lds, st, a, b);
+    return hipGetLastError();
+}
+
+hipError_t tall_launch_dual(const GettProblem& p1, const GettProblem& p2, hipStream_t stream)
+{
+    if (!tall_dual_eligible(p1, p2)) return hipErrorInvalidValue;
+    const bool first_n = p1.N > p1.M;   // the kernel's problem a has C's lanes along s, b along t
+    int ch;
+    const TallArgs a = tall_args(first_n ? p2 : p1, &ch), b = tall_args(first_n ? p1 : p2, &ch);
+    const size_t lds = tall_dual_lds_bytes(p1.K, a.S);
+    int grid = std::max(1, std::min(tall_cus(), (a.ntiles + 3) / 4));
+    if (grid >= 8) grid &= ~7;   // (whole eighths: every XCD the same run of tiles)
+    switch (ch) {
+#define AFESP_TALL_CASE(c) case c: return a.S <= 16 ? tall_dual_launch_one<1, c>(a, b, lds, grid, stream) : tall_dual_launch_one<2, c>(a, b, lds, grid, stream);
+        AFESP_TALL_CASE(4) AFESP_TALL_CASE(5) AFESP_TALL_CASE(6) AFESP_TALL_CASE(7) AFESP_TALL_CASE(8) AFESP_TALL_CASE(9) AFESP_TALL_CASE(10)
+        AFESP_TALL_CASE(11) AFESP_TALL_CASE(12) AFESP_TALL_CASE(13) AFESP_TALL_CASE(14) AFESP_TALL_CASE(15) AFESP_TALL_CASE(16)
+#undef AFESP_TALL_CASE
+    }
+    return hipErrorInvalidValue;
 }
 
 void preload_tall()
