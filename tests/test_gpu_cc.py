@@ -208,7 +208,7 @@ def test_completely_renormalised_triples_match_bundled_outputs(eng, name):
 
 
 @pytest.mark.parametrize("fused", [1, 0, "large", "ring"])
-@pytest.mark.parametrize("o,v", [(4, 9), (12, 72), (5, 13)])
+@pytest.mark.parametrize("o,v", [(4, 9), (12, 72), (5, 13), (18, 21)])
 def test_one_iteration_term_by_term(eng, o, v, fused, monkeypatch):
     """Every intermediate and both residuals after one update from non-trivial amplitudes (t1 != 0).  The second size is
     the largest the oracle does in seconds and is past the thresholds where the launcher switches to the kernels config 5
@@ -221,6 +221,9 @@ def test_one_iteration_term_by_term(eng, o, v, fused, monkeypatch):
         # "ring": the large-system path as config 5 runs it -- the six o^3 v^3 ring products as two launches of the LDS-DMA GEMM
         # (csrc/ring.hip; from o v = 2048 by itself); "large": the same path with those products on the gather kernel
         monkeypatch.setenv("AFESP_RING_TG_MIN", "1" if fused == "ring" else "1000000")
+        # the streamed tall x skinny kernel from 64 rows on (default 2^17): at (12, 72) and (18, 21) the products of t1 with <eb|ia> then run
+        # as config 5 runs them -- y and x_voov in ONE launch of tall_dual_kernel (12 / 18 columns: one / two fragments, ragged rows)
+        monkeypatch.setenv("AFESP_TALL_MIN", "64")
         if fused == "ring":
             # ... and the pair forms at every size: there the T1 equation's asym(m,i,e,f) <ef|ma> is a trace of the t2 <ef|ia> product
             monkeypatch.setenv("AFESP_PP_SYM", "1")
