@@ -1345,7 +1345,8 @@ int afesp_ccsd_iteration_flop(afesp_ctx* ctx, double* flop)
         // products), and the bare t(i,e) <ab|ej> term as a copy of x_voov instead of a third o^2 v^3 product
         const bool large = !ccsd_uses_lanes(ctx->cc);
         const double oooo = (sym && large) ? 4.0 * (os * os * ps + oa * oa * pa) : 2.0 * O * O * O * O * V * V;
-        const double o2v3 = large ? 16.0 : 18.0;
+        // (... and asym(m,i,e,f) <ef|ma> -> r1 as a trace of the pair-form t2 <ef|ia> product: one more o^2 v^3 product that is not executed)
+        const double o2v3 = large ? (sym ? 14.0 : 16.0) : 18.0;
         if (flop)
             *flop = pp + ooov + 12.0 * o3v3 + oooo + 2.0 * O * O * O * O * V + o2v3 * O * O * V * V * V +
                     2.0 * O * V * V * V + 14.0 * O * O * O * V * V;
