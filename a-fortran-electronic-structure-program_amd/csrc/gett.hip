@@ -156,6 +156,7 @@ struct GettKernelArgs {
     int dbg;      // measurement only: bit 0 skips the epilogue stores
     const GettGroup* groups;   // grouped launch (gett.h) or nullptr
     int total_tiles;
+    int sk_units;              // stream-K instantiation (SK): K steps per workgroup
 };
 
 // XCD-aware bijective remap (cdna_hip_programming.md T1): blocks b, b+8, b+16... share an XCD (and its L2);
@@ -172,7 +173,12 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg)
 // TS >= TN: column fragments STAGED per wave (the B image is 16 WN TS columns wide) while TN of them are multiplied -- tiles of 112
 // or 96 columns (TN = 7 / 6, TS = 8, one wave column) for the pair products whose 210 / 190 columns fill 82 % / 74 % of two
 // 128-column tiles: the staging map needs a power of two, the accumulators do not.
-template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int W, bool GRP = false, bool RAG = !GRP, int TS = TN>
+// SK = true: stream-K.  The tiles' K steps form ONE sequence (tile after tile); workgroup w runs steps [w U, (w + 1) U) of it, U =
+// sk_units -- the tail of one tile and the head of the next (U < steps per tile: the launcher's condition) -- and every piece goes to
+// the partial-sum slab of its rank among the pieces of its tile (gett_reduce_kernel adds them up; the launcher zeroes the slabs that
+// only some tiles reach).  For products of a few hundred long tiles -- the pp-ladder's pair products at o = 20, v = 200: 158 tiles of
+// 1270 steps are 1.85 rounds of 256 workgroups in three K slices, 7 % of the device idle -- every workgroup gets the same 784 steps.
+template <int WM, int WN, int TM, int TN, bool AKC, bool BKC, int W, bool GRP = false, bool RAG = !GRP, int TS = TN, bool SK = false>
 // Occupancy bound of the 4-wave tiles: two waves per SIMD, i.e. a budget of 256 registers.  With more than that hipcc keeps
 // the accumulators in AGPRs, and on gfx950 v_mfma_f64_16x16x4_f64 with AGPR accumulators issues every 138 cycles instead of
 // every 64 (tools/mfma_peak.hip: 34.7 against 77.7 TFLOP/s, one wave per SIMD, sixteen independent accumulators).
@@ -205,10 +211,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
     // Grouped launch: the tile ids of all groups are concatenated; `cursor` is the group of the previous lookup (ids only
     // grow along a workgroup's stream).
     const int ntiles_all = GRP ? a.total_tiles : a.mtiles * a.ntiles;
-    const int ntl = (ntiles_all - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    // stream-K: this workgroup's steps [sk_g0, sk_g1) of the sequence, its first tile and the step inside it where it starts
+    const int sk_g0 = SK ? (int)blockIdx.x * a.sk_units : 0, sk_g1 = SK ? min(sk_g0 + a.sk_units, ntiles_all * nk) : 0;
+    if (SK && sk_g0 >= sk_g1) return;
+    const int sk_first = SK ? sk_g0 / nk : 0, sk_kt0 = SK ? sk_g0 - sk_first * nk : 0;
+    const int ntl = SK ? (sk_g1 - 1) / nk - sk_first + 1 : (ntiles_all - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    int ctile = 0;   // tiles of this workgroup's stream finished so far
     auto origin = [&](int j, int& m0, int& n0, int& cursor) {
         const int r0 = j * (int)gridDim.x;
-        int tile = r0 + xcd_remap(blockIdx.x, min((int)gridDim.x, ntiles_all - r0));
+        int tile = SK ? sk_first + j : r0 + xcd_remap(blockIdx.x, min((int)gridDim.x, ntiles_all - r0));
         int nt = a.ntiles;
         if (GRP) {
             while (tile >= uniform_i32(a.groups[cursor + 1].tile_start)) ++cursor;
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
         const int ml = m0 + wm * 16 * TM + (lane >> 4);
         const int64_t* offCn = GRP ? uniform_ptr(a.groups[cgrp].offCn) : p.offCn;
         const int Ncur = GRP ? uniform_i32(a.groups[cgrp].N) : p.N;
-        if (a.ksplit == 1) {
+        if (!SK && a.ksplit == 1) {
             double* Cb = p.C + (p.batchC ? p.batchC[z] : 0);
             int64_t cn[TN];
 #pragma unroll
@@ -271,7 +283,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
                 }
             }
         } else {
-            double* slab = a.ws + ((int64_t)z * a.ksplit + split) * (int64_t)p.M * p.N;
+            // (stream-K: the rank of this workgroup among the pieces of the tile -- the first piece starts in workgroup (tile nk) / U)
+            const int part = SK ? (int)blockIdx.x - (int)(((int64_t)(sk_first + ctile) * nk) / a.sk_units) : z * a.ksplit + split;
+            double* slab = a.ws + (int64_t)part * (int64_t)p.M * p.N;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -287,7 +301,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
         }
     };
 
-    const int nk = (kend - kbeg + BK - 1) / BK;
     if (nk <= 0) {   // empty contraction: C = beta*C
         for (int j = 0; j < ntl; ++j) {
             int m0, n0;
@@ -298,14 +311,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
     }
     // the last step of every tile is partial (grouped launches take whole K steps only, gett_launch_grouped)
     const bool ragged = RAG ? ((kend - kbeg) % BK) != 0 : false;
-    const int G = ntl * nk;                          // K steps in this workgroup's stream
+    const int G = SK ? sk_g1 - sk_g0 : ntl * nk;     // K steps in this workgroup's stream
 
     // Gather cursors.  Data fetches run two stream steps ahead of the MFMAs, their K offsets three steps ahead; when the
     // data cursor leaves a tile the row/column offsets of the next tile are reloaded in place (they are dead until the
     // next fetch, three MFMA groups later).
     Stager<BM, AKC, NT, W> stA;
     Stager<BNS, BKC, NT, W> stB;
-    int fkt = 0, ftile = 0, kok = 0;
+    int fkt = sk_kt0, ftile = 0, kok = sk_kt0;
     {
         int m0, n0;
         origin(0, m0, n0, fgrp);
@@ -352,8 +365,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
     stB.fetch(rb0);
     advance_fetch();
     next_ko();
-    stA.stash(lds, ra0, t, kbeg, kend, ragged && nk == 1);
-    stB.stash(lds + TA::SIZE, rb0, t, kbeg, kend, ragged && nk == 1);
+    stA.stash(lds, ra0, t, kbeg + sk_kt0 * BK, kend, ragged && sk_kt0 == nk - 1);
+    stB.stash(lds + TA::SIZE, rb0, t, kbeg + sk_kt0 * BK, kend, ragged && sk_kt0 == nk - 1);
     stA.fetch(ra1);                       // step 1 (stale but valid addresses if it does not exist)
     stB.fetch(rb1);
     advance_fetch();
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
     if (AFESP_GETT_VARIANT_ & 4) {   // (a real raise for waves 4-7 only: the guard must be provably wave-uniform)
         if (NT == 512 && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(1);
     } else if (NT == 512 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    int kt = 0, ctile = 0;
+    int kt = sk_kt0;
 // Schedule variants of one stream step (compile-time, A/B-measured in one GPU session: tools/ab_gemm.py):
 //   EARLY   the data of step g+1 is written to LDS right after the barrier that freed its buffer, so the whole step's
 //           MFMAs cover the ds_write completion the next barrier waits for; otherwise ("late") just before sub-step 2
@@ -491,6 +504,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
     }
 #undef AFESP_GETT_LOOP
 #undef AFESP_GETT_STASH
+    if (SK && kt != 0) {   // the stream ended inside a tile: its piece
+        int m0, n0;
+        origin(ctile, m0, n0, cgrp);
+        store_tile(m0, n0);
+    }
     if ((VARIANT & 64) && lane == 0 && blockIdx.x < 256 && wave < 8 && blockIdx.y == 0 && blockIdx.z == 0) {
         unsigned long long* d = g_gett_stamp + ((int)blockIdx.x * 8 + wave) * 4;
         d[0] = __builtin_amdgcn_s_memtime() - stamp_t0;
@@ -600,9 +618,13 @@ static int resident_blocks(Kern kern, int threads)
     return cus * occ;
 }
 
-template <int WM, int WN, int TM, int TN, bool AK, bool BK_, int W, bool GRP = false, bool RAG = !GRP, int TS = TN>
+template <int WM, int WN, int TM, int TN, bool AK, bool BK_, int W, bool GRP = false, bool RAG = !GRP, int TS = TN, bool SK = false>
 static void launch_one(const GettKernelArgs& a, dim3 grid, hipStream_t st)
 {
+    if (SK) {   // (stream-K: the launcher has sized the grid)
+        hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG, TS, SK>), grid, dim3(64 * WM * WN), 0, st, a);
+        return;
+    }
     static const int cap = resident_blocks(gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG, TS>, 64 * WM * WN);
     // persistent grid: no more workgroups than the device holds at once, the rest of the tiles are walked in-kernel
     int per = cap / (int)(grid.y * grid.z);
@@ -624,6 +646,17 @@ static void launch_cfg(const GettKernelArgs& a, dim3 grid, hipStream_t st)
     else if (ak) launch_one<WM, WN, TM, TN, true, false, W, false, true, TS>(a, grid, st);
     else if (bk) launch_one<WM, WN, TM, TN, false, true, W, false, true, TS>(a, grid, st);
     else launch_one<WM, WN, TM, TN, false, false, W, false, true, TS>(a, grid, st);
+}
+
+// (stream-K instantiations: the 256 x 112 / 256 x 96 tiles with 16-byte staging only -- the pair products of the pp-ladder)
+template <int WM, int WN, int TM, int TN, int W, int TS>
+static void launch_cfg_sk(const GettKernelArgs& a, dim3 grid, hipStream_t st)
+{
+    const bool ak = a.p.a_kcontig, bk = a.p.b_kcontig;
+    if (ak && bk) launch_one<WM, WN, TM, TN, true, true, W, false, true, TS, true>(a, grid, st);
+    else if (ak) launch_one<WM, WN, TM, TN, true, false, W, false, true, TS, true>(a, grid, st);
+    else if (bk) launch_one<WM, WN, TM, TN, false, true, W, false, true, TS, true>(a, grid, st);
+    else launch_one<WM, WN, TM, TN, false, false, W, false, true, TS, true>(a, grid, st);
 }
 
 #ifdef AFESP_GETT_GROUPED_TU
@@ -738,9 +771,34 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     a.dbg = g_dbg;
     a.groups = nullptr;
     a.total_tiles = 0;
+    a.sk_units = 0;
     a.gm = g_group_m > 0 ? g_group_m : (a.ntiles >= 8 ? 4 : a.ntiles >= 4 ? 8 : a.ntiles >= 2 ? 16 : 32);
     if (a.gm > a.mtiles) a.gm = a.mtiles;
     dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)a.ksplit, (unsigned)p.nbatch);
+    // Stream-K (gett_kernel, SK) for the 256 x 112 / 96 tiles where the slices chosen above leave a round of the device partly idle:
+    // every workgroup the same U consecutive K steps of the tiles' sequence, U below a tile's length; the pieces of a tile -- ceil(steps / U)
+    // of them, one more where the sequence is cut inside its first U steps -- meet in the slabs of the split-K workspace.
+    static const bool sk_off = getenv("AFESP_GETT_SK") && getenv("AFESP_GETT_SK")[0] == '0';
+    bool sk = false;
+    if (!sk_off && tm == 16 && (tn == 6 || tn == 7) && wide && p.nbatch == 1 && force_split == 0 && a.ksplit > 1 && ksteps >= 64 && ws.ptr) {
+        const int wgs = 256;   // (one 8-wave workgroup per CU)
+        const int64_t items = tiles * a.ksplit, rounds = (items + wgs - 1) / wgs;
+        const int64_t total = tiles * ksteps;
+        const int U = (int)((total + wgs - 1) / wgs);
+        const int parts = (ksteps + U - 1) / U + 1;
+        if ((double)items / (double)(rounds * wgs) < 0.97 && U >= 32 && U < ksteps && parts <= 8 &&
+            (size_t)parts * p.M * p.N * sizeof(double) <= ws.bytes && total < ((int64_t)1 << 31)) {
+            sk = true;
+            a.sk_units = U;
+            a.kchunk = ksteps * BK;
+            a.ksplit = parts;
+            grid = dim3((unsigned)((total + U - 1) / U), 1, 1);
+            // the slabs that only the tiles cut early reach: zero (every tile writes the first ceil(steps / U) of them)
+            const int always = (ksteps + U - 1) / U;
+            hipError_t me = hipMemsetAsync(ws.ptr + (size_t)always * p.M * p.N, 0, (size_t)(parts - always) * p.M * p.N * sizeof(double), stream);
+            if (me != hipSuccess) return me;
+        }
+    }
     static const bool gett_debug = getenv("AFESP_GETT_DEBUG") != nullptr;   // every launch: extents, tile codes, K slices
     if (gett_debug)
         fprintf(stderr, "gett_launch M %d N %d K %d batch %d akc %d bkc %d wide %d -> tm %d tn %d tiles %d x %d split %d (steps per slice %d)\n", p.M, p.N, p.K,
@@ -758,8 +816,13 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     AFESP_CFG(8, 8, 2, 2, 4, 4) AFESP_CFG(16, 8, 4, 2, 4, 4) AFESP_CFG(8, 16, 2, 4, 4, 4)
 #undef AFESP_CFG
     // 256 x 112 / 256 x 96: eight waves one above the other, 2 x 7 / 2 x 6 accumulators each, a 128-column image
-    if (tm == 16 && tn == 7) { if (wide) launch_cfg<8, 1, 2, 7, 2, 8>(a, grid, stream); else launch_cfg<8, 1, 2, 7, 1, 8>(a, grid, stream); }
-    if (tm == 16 && tn == 6) { if (wide) launch_cfg<8, 1, 2, 6, 2, 8>(a, grid, stream); else launch_cfg<8, 1, 2, 6, 1, 8>(a, grid, stream); }
+    if (sk) {
+        if (tn == 7) launch_cfg_sk<8, 1, 2, 7, 2, 8>(a, grid, stream);
+        else launch_cfg_sk<8, 1, 2, 6, 2, 8>(a, grid, stream);
+    } else {
+        if (tm == 16 && tn == 7) { if (wide) launch_cfg<8, 1, 2, 7, 2, 8>(a, grid, stream); else launch_cfg<8, 1, 2, 7, 1, 8>(a, grid, stream); }
+        if (tm == 16 && tn == 6) { if (wide) launch_cfg<8, 1, 2, 6, 2, 8>(a, grid, stream); else launch_cfg<8, 1, 2, 6, 1, 8>(a, grid, stream); }
+    }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
     if (a.ksplit > 1) {
@@ -798,6 +861,7 @@ hipError_t gett_launch_grouped(const GettProblem& p, const GettGroup* dev_groups
     a.dbg = g_dbg;
     a.groups = dev_groups;
     a.total_tiles = total_tiles;
+    a.sk_units = 0;
     // a patch of gm m-tiles x all n-tiles of a group should be the ~32 tiles one XCD works on in a round (its L2 then
     // serves every operand panel of the patch once)
     a.gm = g_group_m > 0 ? g_group_m : std::max(1, (32 + max_ntiles / 2) / std::max(1, max_ntiles));

@@ -67,6 +67,25 @@ def test_contract_tile_shapes_and_split_k(eng, split, tm, tn):
     assert np.max(np.abs(got - ref)) < 1e-12
 
 
+@pytest.mark.parametrize("tn,beta", [(7, 0.0), (6, -0.5)])
+def test_stream_k_pieces_of_long_tiles(eng, tn, beta):
+    """The 256 x 112 / 256 x 96 tiles of the pp-ladder's pair products run stream-K where whole (tile, K slice) items would leave a round
+    of the device partly idle (csrc/gett.hip, SK): every workgroup takes the same number of consecutive K steps of the tiles' sequence,
+    the pieces of a tile meet in the split-K slabs.  Ragged rows, columns and K tail; 40 tiles of 301 steps -> 48 steps per workgroup,
+    up to eight pieces per tile, an accumulating product included."""
+    rng = np.random.default_rng(11)
+    M, N, K = 4990, 16 * tn * 2 - (18 if tn == 7 else 2), 4806
+    A = _rand(rng, K, M)
+    B = _rand(rng, N, K)
+    # (both orders of the result: the tall extent as the tile's 256 rows -- the ladder's own shape -- and as its columns)
+    for lc in ("nm", "mn"):
+        C0 = _rand(rng, *((M, N) if lc == "mn" else (N, M)))
+        prod = A.T @ B.T
+        ref = beta * C0 + 0.5 * (prod if lc == "mn" else prod.T)
+        got = eng.contract(0.5, A, "km", B, "nk", beta, C0, lc, force_tm=16, force_tn=tn)
+        assert np.max(np.abs(got - ref)) < 1e-13 * K, lc
+
+
 def test_contract_gemv_shapes(eng):
     rng = np.random.default_rng(3)
     o, v = 4, 9
