@@ -62,6 +62,8 @@ int afesp_ccsd_solve(afesp_ctx* ctx, int maxiter, double e_tol, double t_tol, do
                      int* niter);
 /* Converged amplitudes (what move_alloc hands to int_store_cc, src/ccsd.f90:386-387). */
 int afesp_ccsd_get_amplitudes(afesp_ctx* ctx, double* t1, double* t2);
+/* t2 must carry the symmetry of closed-shell amplitudes, t2(i,j,a,b) = t2(j,i,b,a) -- every set the solver itself produces does, to the
+ * bit; the residual is formed as r2 + its image, and a large system's DIIS overlaps are summed over a <= b only. */
 int afesp_ccsd_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2);
 /* Named device tensor -> host (tests / debugging).  Names: v_oovv v_ovov v_vvov v_oovo v_oooo v_vvvv I_vo I_vv I_oo_p
  * I_oo c_oovv asym_t2 x_voov I_oooo I_ovov I_voov I_vovv_p I_ooov_p r1 r2 D1 D2 t1 t2
