@@ -157,6 +157,7 @@ struct GettKernelArgs {
     const GettGroup* groups;   // grouped launch (gett.h) or nullptr
     int total_tiles;
     int sk_units;              // stream-K instantiation (SK): K steps per workgroup
+    int sk_nk;                 // ... and the steps a tile counts for in the sequence (>= its own: the steps behind K multiply zeros)
 };
 
 // XCD-aware bijective remap (cdna_hip_programming.md T1): blocks b, b+8, b+16... share an XCD (and its L2);
@@ -211,7 +212,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
     // Grouped launch: the tile ids of all groups are concatenated; `cursor` is the group of the previous lookup (ids only
     // grow along a workgroup's stream).
     const int ntiles_all = GRP ? a.total_tiles : a.mtiles * a.ntiles;
-    const int nk = (kend - kbeg + BK - 1) / BK;
+    // (stream-K: a tile is sk_nk steps of the sequence -- its own, padded so that workgroups eight apart, i.e. on one XCD, start at
+    // the same step of their tiles and read the narrow operand's lines together; the steps behind K are masked like a K tail)
+    const int nk = SK ? a.sk_nk : (kend - kbeg + BK - 1) / BK;
+    const int nk_real = (kend - kbeg + BK - 1) / BK;
     // stream-K: this workgroup's steps [sk_g0, sk_g1) of the sequence, its first tile and the step inside it where it starts
     const int sk_g0 = SK ? (int)blockIdx.x * a.sk_units : 0, sk_g1 = SK ? min(sk_g0 + a.sk_units, ntiles_all * nk) : 0;
     if (SK && sk_g0 >= sk_g1) return;
@@ -365,8 +369,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
     stB.fetch(rb0);
     advance_fetch();
     next_ko();
-    stA.stash(lds, ra0, t, kbeg + sk_kt0 * BK, kend, ragged && sk_kt0 == nk - 1);
-    stB.stash(lds + TA::SIZE, rb0, t, kbeg + sk_kt0 * BK, kend, ragged && sk_kt0 == nk - 1);
+    stA.stash(lds, ra0, t, kbeg + sk_kt0 * BK, kend, SK ? sk_kt0 >= nk_real - 1 : ragged && sk_kt0 == nk - 1);
+    stB.stash(lds + TA::SIZE, rb0, t, kbeg + sk_kt0 * BK, kend, SK ? sk_kt0 >= nk_real - 1 : ragged && sk_kt0 == nk - 1);
     stA.fetch(ra1);                       // step 1 (stale but valid addresses if it does not exist)
     stB.fetch(rb1);
     advance_fetch();
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 && TM * TN < 16 && !(AF
         const double* cB = cA + TA::SIZE;                                                       \
         const bool ld = (STEADY) || g + 2 < G, st = (STEADY) || g + 1 < G;                      \
         const int ktn = (kt + 1 == nk) ? 0 : kt + 1;                                            \
-        const bool tail = ragged && (ktn == nk - 1);                                            \
+        const bool tail = SK ? ktn >= nk_real - 1 : ragged && (ktn == nk - 1);                  \
         if (EARLY) { AFESP_GETT_STASH(pa, pb) }                                                 \
         frag(af1, bf1, cA, cB, 1);                                                              \
         if (ld) stA.fetch(qa);                                                                  \
@@ -772,6 +776,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     a.groups = nullptr;
     a.total_tiles = 0;
     a.sk_units = 0;
+    a.sk_nk = 0;
     a.gm = g_group_m > 0 ? g_group_m : (a.ntiles >= 8 ? 4 : a.ntiles >= 4 ? 8 : a.ntiles >= 2 ? 16 : 32);
     if (a.gm > a.mtiles) a.gm = a.mtiles;
     dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)a.ksplit, (unsigned)p.nbatch);
@@ -783,18 +788,24 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     if (!sk_off && tm == 16 && (tn == 6 || tn == 7) && wide && p.nbatch == 1 && force_split == 0 && a.ksplit > 1 && ksteps >= 64 && ws.ptr) {
         const int wgs = 256;   // (one 8-wave workgroup per CU)
         const int64_t items = tiles * a.ksplit, rounds = (items + wgs - 1) / wgs;
-        const int64_t total = tiles * ksteps;
-        const int U = (int)((total + wgs - 1) / wgs);
-        const int parts = (ksteps + U - 1) / U + 1;
-        if ((double)items / (double)(rounds * wgs) < 0.97 && U >= 32 && U < ksteps && parts <= 8 &&
-            (size_t)parts * p.M * p.N * sizeof(double) <= ws.bytes && total < ((int64_t)1 << 31)) {
+        // Workgroups w, w + 8, ... share an XCD and its L2.  With U = j nk' / 8 (nk' = a tile's steps rounded up to a multiple of
+        // eight, j = ceil(tiles / 32)) they all start at the same step of their tiles and walk the narrow operand's K range together:
+        // eight K positions in flight instead of 256 (U = total / 256 exactly: FETCH_SIZE of a ladder product 7.2 -> 10 GB, and only 3 of
+        // the 7 % that balance promises arrive).  The price: j / 8 >= tiles / 256, the last workgroups of the grid run short or not at all.
+        const int nkp = (ksteps + 7) / 8 * 8, j8 = (int)((tiles + 31) / 32);
+        const int U = j8 * (nkp / 8);
+        const int64_t total = tiles * nkp;
+        const int parts = (nkp + U - 1) / U + 1;
+        if ((double)items / (double)(rounds * wgs) < 0.97 && (double)tiles / (32.0 * j8) > (double)items / (double)(rounds * wgs) + 0.02 && j8 < 8 &&
+            U >= 32 && parts <= 8 && (size_t)parts * p.M * p.N * sizeof(double) <= ws.bytes && total < ((int64_t)1 << 31)) {
             sk = true;
             a.sk_units = U;
-            a.kchunk = ksteps * BK;
+            a.sk_nk = nkp;
+            a.kchunk = nkp * BK;
             a.ksplit = parts;
             grid = dim3((unsigned)((total + U - 1) / U), 1, 1);
             // the slabs that only the tiles cut early reach: zero (every tile writes the first ceil(steps / U) of them)
-            const int always = (ksteps + U - 1) / U;
+            const int always = (nkp + U - 1) / U;
             hipError_t me = hipMemsetAsync(ws.ptr + (size_t)always * p.M * p.N, 0, (size_t)(parts - always) * p.M * p.N * sizeof(double), stream);
             if (me != hipSuccess) return me;
         }
@@ -862,6 +873,7 @@ hipError_t gett_launch_grouped(const GettProblem& p, const GettGroup* dev_groups
     a.groups = dev_groups;
     a.total_tiles = total_tiles;
     a.sk_units = 0;
+    a.sk_nk = 0;
     // a patch of gm m-tiles x all n-tiles of a group should be the ~32 tiles one XCD works on in a round (its L2 then
     // serves every operand panel of the patch once)
     a.gm = g_group_m > 0 ? g_group_m : std::max(1, (32 + max_ntiles / 2) / std::max(1, max_ntiles));

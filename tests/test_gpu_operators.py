@@ -71,10 +71,10 @@ def test_contract_tile_shapes_and_split_k(eng, split, tm, tn):
 def test_stream_k_pieces_of_long_tiles(eng, tn, beta):
     """The 256 x 112 / 256 x 96 tiles of the pp-ladder's pair products run stream-K where whole (tile, K slice) items would leave a round
     of the device partly idle (csrc/gett.hip, SK): every workgroup takes the same number of consecutive K steps of the tiles' sequence,
-    the pieces of a tile meet in the split-K slabs.  Ragged rows, columns and K tail; 40 tiles of 301 steps -> 48 steps per workgroup,
-    up to eight pieces per tile, an accumulating product included."""
+    the pieces of a tile meet in the split-K slabs.  Ragged rows, columns and K tail; 60 tiles of 301 steps (304 in the sequence: workgroups
+    eight apart start at the same step of their tiles) -> 76 steps per workgroup, up to five pieces per tile, an accumulating product included."""
     rng = np.random.default_rng(11)
-    M, N, K = 4990, 16 * tn * 2 - (18 if tn == 7 else 2), 4806
+    M, N, K = 7670, 16 * tn * 2 - (18 if tn == 7 else 2), 4806
     A = _rand(rng, K, M)
     B = _rand(rng, N, K)
     # (both orders of the result: the tall extent as the tile's 256 rows -- the ladder's own shape -- and as its columns)
