@@ -1,5 +1,8 @@
 // capi.hip -- extern "C" boundary (include/afesp.h), the AO->MO transform, and the synthetic-input generators.
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -59,10 +62,48 @@ struct afesp_ctx {
 
 namespace {
 
+// The code-object preload (afesp_ctx_create) runs ONCE per process and device, and nobody launches beside it.  The runtime loads a
+// translation unit's device code on the first use of one of its kernels; two threads that first-touch the same unit at the same time
+// -- the startup threads of two contexts, or one of them and the caller's own first launch -- can end in the runtime's abort
+// "Cannot find Symbol with name ..." (seen once in 200 runs of the two-context test, inside afesp_synthetic_init of the first of two
+// contexts created back to back).  So: the first context of a device does the preloading, later ones skip it, and every entry point
+// that takes a context waits until it has finished (one relaxed load afterwards).
+struct PreloadGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int state[16] = {0};   // per device: 0 not started, 1 running, 2 done
+    std::atomic<int> running{0};
+    bool claim(int dev)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 16 || state[dev] != 0) return false;
+        state[dev] = 1;
+        running.fetch_add(1, std::memory_order_relaxed);
+        return true;
+    }
+    void done(int dev)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            state[dev] = 2;
+            running.fetch_sub(1, std::memory_order_release);
+        }
+        cv.notify_all();
+    }
+    void wait()
+    {
+        if (running.load(std::memory_order_acquire) == 0) return;
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return running.load(std::memory_order_acquire) == 0; });
+    }
+};
+PreloadGate g_preload;
+
 template <class F>
 int guarded(afesp_ctx* c, F&& f)
 {
     if (!c) return 1;
+    g_preload.wait();
     // A body that threw may have forked lanes without joining them: before the caller can free or re-initialise anything, every
     // lane is idle and lane 0 is the one in use again.
     auto settle = [&]() {
@@ -250,8 +291,14 @@ int afesp_ctx_create(int device, afesp_ctx** out)
         // small molecule would pay inside its first CCSD iteration.  Ask for it now, on a thread of its own: the caller goes
         // on with its host work (parsing eri.dat, the SCF set-up) meanwhile.  AFESP_NO_PRELOAD=1 switches it off.
         const char* np = getenv("AFESP_NO_PRELOAD");
-        if (!(np && np[0] == '1'))
-            c->cx.startup = std::thread([device, c] {
+        if (!(np && np[0] == '1')) {
+            // (claimed HERE, before the thread exists: from this moment every entry point waits for the preload -- PreloadGate)
+            const bool mine = g_preload.claim(device);
+            c->cx.startup = std::thread([device, c, mine] {
+                struct Release {
+                    int dev; bool on;
+                    ~Release() { if (on) g_preload.done(dev); }
+                } release{device, mine};
                 if (hipSetDevice(device) != hipSuccess) return;
                 // (the parallel streams of the call-by-call iteration: small systems run the launch-fused iteration on ONE stream since
                 // round 4, so the 10-25 ms of queue creation are only spent ahead of time on request; fork() makes them when needed)
@@ -284,6 +331,7 @@ int afesp_ctx_create(int device, afesp_ctx** out)
                 // launches it, and whatever loads here holds the runtime's lock against the caller's own first launches, e.g. the
                 // Fock builds of the SCF that els_amd starts at once; a large system loads it with its first product.
                 // AFESP_PRELOAD_GETT=1 restores it.)
+                if (!mine) return;   // (another context of this process has done it, or is at it: PreloadGate)
                 timed("kernels", preload_kernels);
                 timed("fused", preload_fused);
                 timed("contract", preload_contract);
@@ -293,6 +341,7 @@ int afesp_ctx_create(int device, afesp_ctx** out)
                 const char* pg = getenv("AFESP_PRELOAD_GETT");
                 if (pg && pg[0] == '1') timed("gett", preload_gett);
             });
+        }
     });
     if (rc) {
         if (c->cx.startup.joinable()) c->cx.startup.join();
