@@ -1364,7 +1364,13 @@ void preload_small_path_kernels()
                          reinterpret_cast<const void*>(antisym_pair_kernel), reinterpret_cast<const void*>(pp_expand_kernel),
                          reinterpret_cast<const void*>(pair_expand_add_kernel), reinterpret_cast<const void*>(pair_xform_kernel<1>),
                          reinterpret_cast<const void*>(pair_xform_kernel<2>), reinterpret_cast<const void*>(square_transpose_kernel)};
-    for (const void* f : fns) (void)hipFuncGetAttributes(&at, f);
+    const bool dbg = getenv("AFESP_PRELOAD_DEBUG") != nullptr;
+    int k = 0;
+    for (const void* f : fns) {
+        const hipError_t e = hipFuncGetAttributes(&at, f);
+        if (dbg && e != hipSuccess) fprintf(stderr, "afesp preload: kernel %d of the small path: %s\n", k, hipGetErrorString(e));
+        ++k;
+    }
     (void)hipGetLastError();
 }
 }  // namespace afesp
