@@ -262,6 +262,7 @@ struct CCTail {
     double *coef, *bmat;
     int64_t seq;
     const double* r2y = nullptr;   // a partial residual held with i and j exchanged (ring.hip), or null
+    bool half_hist = true;         // (with r2y) the DIIS overlaps summed over a <= b only: every history vector has e(i,j,a,b) = e(j,i,b,a)
 };
 void k_cc_tail(Context& cx, const CCTail& a);
 // out = sum_j coef[j] x_j with the coefficients handed over by value (the host solved for them)

@@ -62,48 +62,30 @@ struct afesp_ctx {
 
 namespace {
 
-// The code-object preload (afesp_ctx_create) runs ONCE per process and device, and nobody launches beside it.  The runtime loads a
-// translation unit's device code on the first use of one of its kernels; two threads that first-touch the same unit at the same time
-// -- the startup threads of two contexts, or one of them and the caller's own first launch -- can end in the runtime's abort
-// "Cannot find Symbol with name ..." (seen once in 200 runs of the two-context test, inside afesp_synthetic_init of the first of two
-// contexts created back to back).  So: the first context of a device does the preloading, later ones skip it, and every entry point
-// that takes a context waits until it has finished (one relaxed load afterwards).
-struct PreloadGate {
+// The code-object preload (afesp_ctx_create) runs ONCE per process and device: the first context of a device starts the start-up
+// thread, later ones start none.  What makes it safe beside the caller's own launches -- and two callers' launches beside each other --
+// is not this claim but first_use.h: every first use of a kernel function, by the preload lists and by every launch site alike, is
+// made under ONE process-wide lock (the round-5 abort "Cannot find Symbol with name ...slice_phys_kernel..." was the start-up thread
+// and afesp_synthetic_init resolving that one function at the same moment).  Entry points therefore no longer wait for the preload
+// (round 5 made them: the first Fock builds of els_amd run beside it again).
+struct PreloadClaim {
     std::mutex mu;
-    std::condition_variable cv;
-    int state[16] = {0};   // per device: 0 not started, 1 running, 2 done
-    std::atomic<int> running{0};
+    unsigned long long claimed = 0;   // bit per device (a device id >= 64 is never claimed: its kernels load on first use, under the lock)
     bool claim(int dev)
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (dev < 0 || dev >= 16 || state[dev] != 0) return false;
-        state[dev] = 1;
-        running.fetch_add(1, std::memory_order_relaxed);
+        if (dev < 0 || dev >= 64 || (claimed >> dev) & 1ull) return false;
+        claimed |= 1ull << dev;
         return true;
     }
-    void done(int dev)
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            state[dev] = 2;
-            running.fetch_sub(1, std::memory_order_release);
-        }
-        cv.notify_all();
-    }
-    void wait()
-    {
-        if (running.load(std::memory_order_acquire) == 0) return;
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [this] { return running.load(std::memory_order_acquire) == 0; });
-    }
 };
-PreloadGate g_preload;
+PreloadClaim g_preload;
 
 template <class F>
 int guarded(afesp_ctx* c, F&& f)
 {
     if (!c) return 1;
-    g_preload.wait();
+    first_use_tls_device() = c->cx.device;   // (the launch sites' per-device flags, first_use.h)
     // A body that threw may have forked lanes without joining them: before the caller can free or re-initialise anything, every
     // lane is idle and lane 0 is the one in use again.
     auto settle = [&]() {
@@ -292,13 +274,9 @@ int afesp_ctx_create(int device, afesp_ctx** out)
         // on with its host work (parsing eri.dat, the SCF set-up) meanwhile.  AFESP_NO_PRELOAD=1 switches it off.
         const char* np = getenv("AFESP_NO_PRELOAD");
         if (!(np && np[0] == '1')) {
-            // (claimed HERE, before the thread exists: from this moment every entry point waits for the preload -- PreloadGate)
-            const bool mine = g_preload.claim(device);
-            c->cx.startup = std::thread([device, c, mine] {
-                struct Release {
-                    int dev; bool on;
-                    ~Release() { if (on) g_preload.done(dev); }
-                } release{device, mine};
+            // one start-up thread per process and device (PreloadClaim); a later context of the device starts none
+            if (g_preload.claim(device)) c->cx.startup = std::thread([device, c] {
+                first_use_tls_device() = device;
                 if (hipSetDevice(device) != hipSuccess) return;
                 // (the parallel streams of the call-by-call iteration: small systems run the launch-fused iteration on ONE stream since
                 // round 4, so the 10-25 ms of queue creation are only spent ahead of time on request; fork() makes them when needed)
@@ -331,7 +309,6 @@ int afesp_ctx_create(int device, afesp_ctx** out)
                 // launches it, and whatever loads here holds the runtime's lock against the caller's own first launches, e.g. the
                 // Fock builds of the SCF that els_amd starts at once; a large system loads it with its first product.
                 // AFESP_PRELOAD_GETT=1 restores it.)
-                if (!mine) return;   // (another context of this process has done it, or is at it: PreloadGate)
                 timed("kernels", preload_kernels);
                 timed("fused", preload_fused);
                 timed("contract", preload_contract);
@@ -363,6 +340,7 @@ void afesp_ctx_destroy(afesp_ctx* ctx)
     ctx->cx.comm = nullptr;
     triples_plan_free(ctx->cc);
     so_triples_plan_free(ctx->so);
+    ring_free(ctx->cx, ctx->cc);   // (the host-side descriptor of the ring launches; its device blocks go with the context)
     delete ctx;
 }
 
@@ -450,9 +428,9 @@ static Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_
     t.colB = t.rowA + n + 256;
     t.offCm = (int64_t*)cx.scratch("ao2mo_t64", n + 128 + ncol + 128 + 2);
     t.offCn = t.offCm + n + 128;
-    hipLaunchKernelGGL(ao2mo_ct_kernel, dim3((unsigned)((n * t.Kc + 255) / 256)), dim3(256), 0, cx.stream, t.ct, Cm, (int)n, (int)t.Kc);
+    AFESP_KLAUNCH(ao2mo_ct_kernel, dim3((unsigned)((n * t.Kc + 255) / 256)), dim3(256), 0, cx.stream, t.ct, Cm, (int)n, (int)t.Kc);
     AFESP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(ao2mo_tables_kernel, dim3((unsigned)std::min<int64_t>((ncol + 256 + 255) / 256, 65536)), dim3(256), 0, cx.stream, t.rowA,
+    AFESP_KLAUNCH(ao2mo_tables_kernel, dim3((unsigned)std::min<int64_t>((ncol + 256 + 255) / 256, 65536)), dim3(256), 0, cx.stream, t.rowA,
                        t.colB, t.offCm, t.offCn, (int)n, (int)t.Kc, ncol);
     AFESP_HIP(hipGetLastError());
     const int64_t ng = (np + t.sl - 1) / t.sl;
@@ -470,14 +448,14 @@ static Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_
     AFESP_HIP(hipMemcpyAsync(cs_dev, t.cstart.data(), (size_t)(np + 1) * sizeof(int64_t), hipMemcpyHostToDevice, cx.stream));
     AFESP_HIP(hipMemsetAsync(t.colB_tri + ctot, 0, 256 * sizeof(uint32_t), cx.stream));
     AFESP_HIP(hipMemsetAsync(t.offCn_tri + ctot, 0, 128 * sizeof(int64_t), cx.stream));
-    hipLaunchKernelGGL(ao2mo_tables_tri_kernel, dim3((unsigned)std::min<int64_t>(np, 65536)), dim3(256), 0, cx.stream, t.colB_tri, t.offCn_tri,
+    AFESP_KLAUNCH(ao2mo_tables_tri_kernel, dim3((unsigned)std::min<int64_t>(np, 65536)), dim3(256), 0, cx.stream, t.colB_tri, t.offCn_tri,
                        cs_dev, (int)n, np, t.sl);
     AFESP_HIP(hipGetLastError());
     if (n > TG_BM) {
         const int64_t nlo = (int64_t)TG_BM * t.sl;
         t.colB_lo = (uint32_t*)cx.scratch("ao2mo_t32h", (nlo + 256) / 2 + 2);
         t.offCn_lo = (int64_t*)cx.scratch("ao2mo_t64h", nlo + 128 + 2);
-        hipLaunchKernelGGL(ao2mo_tables_lo_kernel, dim3((unsigned)std::min<int64_t>((nlo + 256 + 255) / 256, 65536)), dim3(256), 0, cx.stream,
+        AFESP_KLAUNCH(ao2mo_tables_lo_kernel, dim3((unsigned)std::min<int64_t>((nlo + 256 + 255) / 256, 65536)), dim3(256), 0, cx.stream,
                            t.colB_lo, t.offCn_lo, (int)n, (int)TG_BM, nlo);
         AFESP_HIP(hipGetLastError());
     }
@@ -697,6 +675,14 @@ int afesp_ccsd_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, const double* e
         const double* src = ctx->eri_mo_dev;
         double* tmp = nullptr;
         if (eri_mo_packed) {
+            // (a same-shape state is about to be initialised where it lies: the packed integrals it kept for ccsd_need_vvvv go back
+            // to the arena BEFORE their successor is asked for -- a geometry scan never holds two packed arrays)
+            if (ccsd_can_reinit(ctx->cc, (int)nocc, (int)nvirt, diis_n_errmat) && ctx->cc.eri_own) {
+                cx.quiesce();
+                if (ctx->cc.eri_src == ctx->cc.eri_own) ctx->cc.eri_src = nullptr;
+                cx.release(ctx->cc.eri_own);
+                ctx->cc.eri_own = nullptr;
+            }
             tmp = cx.alloc(neri_of(n));
             AFESP_HIP(hipMemcpyAsync(tmp, eri_mo_packed, sizeof(double) * neri_of(n), hipMemcpyHostToDevice, cx.stream));
             src = tmp;
@@ -839,6 +825,7 @@ int afesp_ccsd_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2
             ring_invalidate(ctx->cc);
         }
         ctx->cc.amps_touched = true;
+        if (t2) ctx->cc.hist_plain = ctx->cc.nerr + 1;   // (its error vector may lack the amplitudes' symmetry: full DIIS sums until it has left the history)
         if (t1) AFESP_HIP(hipMemcpyAsync(ctx->cc.t1.d, t1, sizeof(double) * ctx->cc.t1.size(), hipMemcpyHostToDevice, cx.stream));
         if (t2) AFESP_HIP(hipMemcpyAsync(ctx->cc.t2.d, t2, sizeof(double) * ctx->cc.t2.size(), hipMemcpyHostToDevice, cx.stream));
         cx.sync();
@@ -1340,7 +1327,7 @@ int afesp_synthetic_init(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, double sca
         for (int64_t i = 0; i < nocc; ++i) e[i] = -2.0 + (nocc > 1 ? (double)i / (double)(nocc - 1) : 0.0);
         for (int64_t a = 0; a < nvirt; ++a) e[nocc + a] = 1.0 + (nvirt > 1 ? 2.0 * (double)a / (double)(nvirt - 1) : 0.0);
         double* packed = cx.alloc(ne);
-        hipLaunchKernelGGL(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, packed, ne, scale, seed);
+        AFESP_KLAUNCH(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, packed, ne, scale, seed);
         AFESP_HIP(hipGetLastError());
         if (!ccsd_can_reinit(ctx->cc, (int)nocc, (int)nvirt, diis_n_errmat)) ctx->cc_programs_reset();
         else ctx->graph_cc.reset();
@@ -1362,7 +1349,7 @@ int afesp_synthetic_ao(afesp_ctx* ctx, int64_t nbasis, double scale, uint64_t se
         ctx->eri_ao_dev = cx.alloc(ne);
         ctx->eri_ao_n = nbasis;
         ctx->half_n = 0;
-        hipLaunchKernelGGL(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, ctx->eri_ao_dev, ne, scale, seed);
+        AFESP_KLAUNCH(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, ctx->eri_ao_dev, ne, scale, seed);
         AFESP_HIP(hipGetLastError());
         cx.sync();
     });
@@ -1462,7 +1449,7 @@ int afesp_bench_contract(afesp_ctx* ctx, const char* la, const int64_t* dimsA, c
             int64_t s = 1;
             for (int i = 0; i < t.rank; ++i) { t.dim[i] = dims[i]; t.stride[i] = s; s *= dims[i]; }
             t.d = cx.alloc(s);
-            hipLaunchKernelGGL(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, t.d, s, 1.0, seed);
+            AFESP_KLAUNCH(synth_packed_kernel, dim3(4096), dim3(256), 0, cx.stream, t.d, s, 1.0, seed);
             return t;
         };
         Tensor tA = mk(la, dimsA, 1), tB = mk(lb, dimsB, 2), tC = mk(lc, dimsC, 3);
@@ -1610,6 +1597,8 @@ int afesp_debug_stamps(unsigned long long* out, int n)
 }
 
 // which kernel took the products of this context so far (tests: a shape that should stream did, the LDS-DMA GEMM ran with 96-row tiles)
+uint64_t afesp_first_use_count(void) { return first_use_count().load(std::memory_order_relaxed); }
+
 int afesp_launch_counts(afesp_ctx* ctx, uint64_t out[4])
 {
     return guarded(ctx, [&] {

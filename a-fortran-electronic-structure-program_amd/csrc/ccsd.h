@@ -52,6 +52,10 @@ struct CCState : DiisRing {
     bool cs_packed = false;                         // pp_cs / pp_ca hold c+- of the current amplitudes (ccsd_intermediates)
     double* r1x = nullptr;                          // asym(m,i,e,f) <ef|ma> as a trace of the pair-form t2 <ef|ia> product (ccsd_ooov_pair_form)
     bool r1x_valid = false;
+    // iterations for which the DIIS history may still hold an error vector without the amplitudes' symmetry e(i,j,a,b) = e(j,i,b,a):
+    // afesp_ccsd_set_amplitudes accepts any t2, and the error vector of the iteration that starts from it lives for nerr iterations.
+    // While > 0 the large-system tail sums the DIIS overlaps over every element instead of a <= b (kernels.hip, cc_tail_kernel).
+    int hist_plain = 0;
     bool amps_touched = true;                       // t1 / t2 were replaced from outside since the last ccsd_intermediates (afesp_ccsd_set_amplitudes)
     int64_t pp_nm = 0;                                     // rows the row tables cover: max(v(v+1)/2, o v)
     double *ov_ws = nullptr, *ov_wa = nullptr;             // the same split of <ef|ia> (v_vvov) for I_ooov_p, built at init

@@ -42,6 +42,7 @@ void ccsd_init(Context& cx, CCState& s, int o, int v, const double* eri_mo_dev, 
         s.cs_packed = s.partials_live = false;
         s.tail_pending = false;
         s.nact = 0; s.it = 0;
+        s.hist_plain = 0;
     } else {
         ccsd_free(cx, s);
     }
@@ -755,6 +756,8 @@ void ccsd_tail_launch(Context& cx, CCState& s)
         a.t2 = st->t2.d; a.t1 = st->t1.d; a.r2 = st->r2.d; a.r1 = st->r1.d; a.voovv = st->v_oovv.d; a.D2 = st->D2.d; a.D1 = st->D1.d;
         a.pp = st->pp; a.t2_old = st->t2_old.d; a.o = st->o; a.v = st->v;
         a.r2y = ring_res_live(*st) ? ring_Y(*st) : nullptr;   // (large systems: one ring term lies in a buffer of its own, ring.hip)
+        a.half_hist = st->hist_plain == 0;
+        if (st->hist_plain > 0) --st->hist_plain;
         a.nerr = st->nerr;
         a.ny = 0; a.slot = 0;
         a.ht = a.he = nullptr; a.amp_s = a.hist_e = nullptr; a.stride = st->nvec;

@@ -39,8 +39,7 @@ __global__ void slice_asym_kernel(double* out, const double* packed, int d0, int
 }  // namespace
 void preload_ccsd_so()
 {
-    hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(slice_asym_kernel));
+    first_use_touch(reinterpret_cast<const void*>(slice_asym_kernel));
     (void)hipGetLastError();
 }
 namespace {
@@ -213,7 +212,7 @@ __global__ void so_ladder_expand_kernel(double* r2, const double* pa, int o, int
 #define SO_LAUNCH(kernel, n, ...)                                                         \
     do {                                                                                  \
         if ((n) > 0) {                                                                    \
-            hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(TB), 0, cx.stream, __VA_ARGS__); \
+            AFESP_KLAUNCH(kernel, dim3(blocks_for(n)), dim3(TB), 0, cx.stream, __VA_ARGS__); \
             AFESP_HIP(hipGetLastError());                                                 \
         }                                                                                 \
     } while (0)
@@ -224,7 +223,7 @@ __global__ void so_ladder_expand_kernel(double* r2, const double* pa, int o, int
         if (cx.rec) {                                                                                                    \
             if ((n) > 0)                                                                                                 \
                 cx.rec->opaque(READS, WRITES, [=](Context& c_) {                                                         \
-                    hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(TB), 0, c_.stream, __VA_ARGS__);                \
+                    AFESP_KLAUNCH(kernel, dim3(blocks_for(n)), dim3(TB), 0, c_.stream, __VA_ARGS__);                \
                     AFESP_HIP(hipGetLastError());                                                                        \
                 });                                                                                                      \
         } else {                                                                                                         \
@@ -441,9 +440,9 @@ int so_energy(Context& cx, SOState& s, double e_tol, double t_tol)
     const int64_t n2 = s.t2.size();
     const int nblk = (int)std::min<int64_t>((n2 + TB - 1) / TB, 1024);
     double* partial = cx.scratch("so_energy_partial", 2 * 1024);
-    hipLaunchKernelGGL(so_energy_kernel, dim3(nblk), dim3(TB), 0, cx.stream, partial, s.oovv.d, s.t1.d, s.t2.d, s.t2_old.d, s.o, s.v);
+    AFESP_KLAUNCH(so_energy_kernel, dim3(nblk), dim3(TB), 0, cx.stream, partial, s.oovv.d, s.t1.d, s.t2.d, s.t2_old.d, s.o, s.v);
     AFESP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(so_sum2_kernel, dim3(2), dim3(TB), 0, cx.stream, cx.scal, partial, nblk);
+    AFESP_KLAUNCH(so_sum2_kernel, dim3(2), dim3(TB), 0, cx.stream, cx.scal, partial, nblk);
     AFESP_HIP(hipGetLastError());
     double* h = host_scalars(cx, DIIS_FLAG_SLOT + 1);
     diis_check_flag(cx, h);

@@ -372,7 +372,7 @@ double* host_scalars(Context& cx, int n)
     }
     constexpr int PUB = 8 + 256;   // the publishing area of res_host: 64 values and their sequence number
     const double want = (double)++cx.pub_seq;
-    hipLaunchKernelGGL(publish_scalars_kernel, dim3(1), dim3(64), 0, cx.stream, cx.res_dev + PUB, cx.scal, n, want);
+    AFESP_KLAUNCH(publish_scalars_kernel, dim3(1), dim3(64), 0, cx.stream, cx.res_dev + PUB, cx.scal, n, want);
     AFESP_HIP(hipGetLastError());
     return host_scalars_wait(cx, n, want);
 }
@@ -680,7 +680,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
                     }
                     ta.n = nn[q];
                     const unsigned blocks = (unsigned)std::min<int64_t>((nn[q] + 255) / 256, 8192);
-                    hipLaunchKernelGGL(plan_table_kernel, dim3(blocks), dim3(256), 0, cx.stream, base + start[q], ta);
+                    AFESP_KLAUNCH(plan_table_kernel, dim3(blocks), dim3(256), 0, cx.stream, base + start[q], ta);
                     AFESP_HIP(hipGetLastError());
                 } else {
                     const std::vector<int64_t> t = table(*grp[q], whichs[q]);
@@ -933,11 +933,10 @@ __global__ __launch_bounds__(256) void permute_add_tiled_kernel(double* __restri
 
 void preload_contract()
 {
-    hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(permute_add_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(plan_table_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(permute_add_tiled_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(publish_scalars_kernel));
+    first_use_touch(reinterpret_cast<const void*>(permute_add_kernel));
+    first_use_touch(reinterpret_cast<const void*>(plan_table_kernel));
+    first_use_touch(reinterpret_cast<const void*>(permute_add_tiled_kernel));
+    first_use_touch(reinterpret_cast<const void*>(publish_scalars_kernel));
     (void)hipGetLastError();
 }
 
@@ -992,13 +991,13 @@ void permute_add(Context& cx, double alpha, const Tensor& in, const char* li, do
         t.alpha = alpha; t.beta = beta;
         blocks *= t.tiles_o * t.tiles_i;
         if (blocks < ((int64_t)1 << 31)) {
-            hipLaunchKernelGGL(permute_add_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, cx.stream, out.d, in.d, t);
+            AFESP_KLAUNCH(permute_add_tiled_kernel, dim3((unsigned)blocks), dim3(256), 0, cx.stream, out.d, in.d, t);
             AFESP_HIP(hipGetLastError());
             return;
         }
     }
     unsigned grid = (unsigned)std::min<int64_t>((a.n + 255) / 256, 4096);
-    hipLaunchKernelGGL(permute_add_kernel, dim3(grid), dim3(256), 0, cx.stream, out.d, in.d, a);
+    AFESP_KLAUNCH(permute_add_kernel, dim3(grid), dim3(256), 0, cx.stream, out.d, in.d, a);
     AFESP_HIP(hipGetLastError());
 }
 

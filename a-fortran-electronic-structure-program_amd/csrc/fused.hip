@@ -238,10 +238,9 @@ __global__ __launch_bounds__(256) void fused_ew_kernel(const EwOp* __restrict__ 
 
 void preload_fused()
 {
-    hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(fused_gemm_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(fused_ew_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(build_kofs_kernel));
+    first_use_touch(reinterpret_cast<const void*>(fused_gemm_kernel));
+    first_use_touch(reinterpret_cast<const void*>(fused_ew_kernel));
+    first_use_touch(reinterpret_cast<const void*>(build_kofs_kernel));
     (void)hipGetLastError();
 }
 
@@ -626,7 +625,7 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
     P->desc = cx.alloc_raw((int64_t)(img.size() / 8 + 2));
     AFESP_HIP(hipMemcpyAsync(P->desc, img.data(), img.size(), hipMemcpyHostToDevice, cx.stream));
     if (!kjobs.empty()) {
-        hipLaunchKernelGGL(build_kofs_kernel, dim3((unsigned)std::min(16, (kmax + 255) / 256), (unsigned)kjobs.size()), dim3(256), 0, cx.stream,
+        AFESP_KLAUNCH(build_kofs_kernel, dim3((unsigned)std::min(16, (kmax + 255) / 256), (unsigned)kjobs.size()), dim3(256), 0, cx.stream,
                            (const KofsJob*)((const char*)P->desc + kjobs_at));
         AFESP_HIP(hipGetLastError());
     }
@@ -669,16 +668,16 @@ void fused_run(Context& cx, const FusedProgram* P)
             if (!st.nitems) continue;
             if (!st.per_op.empty()) {
                 for (auto& r : st.per_op) {
-                    hipLaunchKernelGGL(fused_gemm_kernel, dim3((unsigned)((r.second + 3) / 4)), dim3(256), 0, cx.stream, st.items + r.first, r.second);
+                    AFESP_KLAUNCH(fused_gemm_kernel, dim3((unsigned)((r.second + 3) / 4)), dim3(256), 0, cx.stream, st.items + r.first, r.second);
                     AFESP_HIP(hipGetLastError());
                 }
                 continue;
             }
-            hipLaunchKernelGGL(fused_gemm_kernel, dim3((unsigned)((st.nitems + 3) / 4)), dim3(256), 0, cx.stream, st.items, st.nitems);
+            AFESP_KLAUNCH(fused_gemm_kernel, dim3((unsigned)((st.nitems + 3) / 4)), dim3(256), 0, cx.stream, st.items, st.nitems);
             AFESP_HIP(hipGetLastError());
         } else {
             if (st.nblk) {
-                hipLaunchKernelGGL(fused_ew_kernel, dim3((unsigned)st.nblk), dim3(256), 0, cx.stream, st.ewops, st.blks);
+                AFESP_KLAUNCH(fused_ew_kernel, dim3((unsigned)st.nblk), dim3(256), 0, cx.stream, st.ewops, st.blks);
                 AFESP_HIP(hipGetLastError());
             }
             for (auto& fn : st.opaque) fn(cx);

@@ -10,6 +10,7 @@
 // operands are gathered straight into LDS, so no permuted copy ever touches HBM.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "first_use.h"
 #include <stdint.h>
 
 namespace afesp {

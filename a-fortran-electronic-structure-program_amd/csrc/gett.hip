@@ -568,16 +568,14 @@ int g_dbg = 0;
 template <int WM, int WN, int TM, int TN, int W>
 static void preload_cfg()
 {
-    hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, true, true, W>));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, true, false, W>));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, false, true, W>));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, false, false, W>));
+    first_use_touch(reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, true, true, W>));
+    first_use_touch(reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, true, false, W>));
+    first_use_touch(reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, false, true, W>));
+    first_use_touch(reinterpret_cast<const void*>(gett_kernel<WM, WN, TM, TN, false, false, W>));
 }
 void preload_gett()
 {
-    hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_reduce_kernel));
+    first_use_touch(reinterpret_cast<const void*>(gett_reduce_kernel));
     // the small tiles first: they are what a small molecule launches within milliseconds of the context's creation
     preload_cfg<2, 2, 1, 1, 1>(); preload_cfg<2, 2, 1, 2, 1>(); preload_cfg<2, 2, 1, 4, 1>();
     preload_cfg<2, 2, 2, 1, 1>(); preload_cfg<2, 2, 2, 2, 1>(); preload_cfg<2, 2, 2, 2, 2>(); preload_cfg<2, 2, 2, 4, 1>(); preload_cfg<2, 2, 2, 4, 2>();
@@ -598,10 +596,9 @@ extern int g_dbg;
 // the grouped instantiations (the lists in gett_launch_grouped)
 void preload_gett_grouped()
 {
-    hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<2, 4, 4, 2, true, true, 2, true>));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<2, 4, 4, 2, true, true, 1, true>));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(gett_kernel<4, 2, 4, 4, true, true, 2, true>));
+    first_use_touch(reinterpret_cast<const void*>(gett_kernel<2, 4, 4, 2, true, true, 2, true>));
+    first_use_touch(reinterpret_cast<const void*>(gett_kernel<2, 4, 4, 2, true, true, 1, true>));
+    first_use_touch(reinterpret_cast<const void*>(gett_kernel<4, 2, 4, 4, true, true, 2, true>));
     (void)hipGetLastError();
 }
 // diagnostic builds: the stamps of the grouped kernels live in this translation unit
@@ -618,7 +615,10 @@ static int resident_blocks(Kern kern, int threads)
     int dev = 0, cus = 256, occ = 1;
     if (hipGetDevice(&dev) != hipSuccess) return cus;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, 0) != hipSuccess || occ <= 0) occ = 1;
+    {   // (the occupancy query resolves the function: a first use like any other, first_use.h)
+        std::lock_guard<std::mutex> lk(first_use_mutex());
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, threads, 0) != hipSuccess || occ <= 0) occ = 1;
+    }
     return cus * occ;
 }
 
@@ -626,7 +626,7 @@ template <int WM, int WN, int TM, int TN, bool AK, bool BK_, int W, bool GRP = f
 static void launch_one(const GettKernelArgs& a, dim3 grid, hipStream_t st)
 {
     if (SK) {   // (stream-K: the launcher has sized the grid)
-        hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG, TS, SK>), grid, dim3(64 * WM * WN), 0, st, a);
+        AFESP_KLAUNCH((gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG, TS, SK>), grid, dim3(64 * WM * WN), 0, st, a);
         return;
     }
     static const int cap = resident_blocks(gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG, TS>, 64 * WM * WN);
@@ -636,7 +636,7 @@ static void launch_one(const GettKernelArgs& a, dim3 grid, hipStream_t st)
     if (g_dbg & 2) per = 1 << 30;   // measurement only: one tile per workgroup
     if (g_dbg & 4) per = per / 4 > 0 ? per / 4 : 1;   // measurement only: a quarter of the device (tools/burst_probe.py)
     if ((int)grid.x > per) grid.x = (unsigned)per;
-    hipLaunchKernelGGL((gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG, TS>), grid, dim3(64 * WM * WN), 0, st, a);
+    AFESP_KLAUNCH((gett_kernel<WM, WN, TM, TN, AK, BK_, W, GRP, RAG, TS>), grid, dim3(64 * WM * WN), 0, st, a);
 }
 
 template <int WM, int WN, int TM, int TN, int W, int TS = TN>
@@ -839,7 +839,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     if (a.ksplit > 1) {
         int64_t mn = (int64_t)p.M * p.N;
         unsigned gx = (unsigned)((mn + 255) / 256 > 2048 ? 2048 : (mn + 255) / 256);
-        hipLaunchKernelGGL(gett_reduce_kernel, dim3(gx, (unsigned)p.nbatch), dim3(256), 0, stream, a);
+        AFESP_KLAUNCH(gett_reduce_kernel, dim3(gx, (unsigned)p.nbatch), dim3(256), 0, stream, a);
         err = hipGetLastError();
     }
     return err;

@@ -388,14 +388,13 @@ __global__ void fock_reduce_kernel(double* fock, const double* hcore, const doub
 
 #define LAUNCH(kernel, grid, ...)                                               \
     do {                                                                        \
-        hipLaunchKernelGGL(kernel, grid, dim3(TB), 0, cx.stream, __VA_ARGS__);  \
+        AFESP_KLAUNCH(kernel, grid, dim3(TB), 0, cx.stream, __VA_ARGS__);  \
         AFESP_HIP(hipGetLastError());                                           \
     } while (0)
 
 void preload_kernels()
 {
-    hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(fill_kernel));
+    first_use_touch(reinterpret_cast<const void*>(fill_kernel));
     (void)hipGetLastError();
 }
 
@@ -836,6 +835,7 @@ struct TailArgs {
     int64_t stride;
     int ny, slot;
     const double* r2y;             // YSW: a partial residual held with i and j exchanged (large systems, ring.hip)
+    int half;                      // YSW: the DIIS overlaps over a <= b only (every history vector is symmetric, CCState::hist_plain == 0)
 };
 // NYT = the history rows a thread reads per element (ny rounded up to 0 / 4 / 8 / 16): rows past ny are clamped duplicates
 template <int NYT, bool YSW = false>
@@ -873,7 +873,10 @@ __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p
         // (large systems, YSW: the error vectors have the symmetry of the amplitudes, e(i,j,a,b) = e(j,i,b,a) to the bit -- both are the same
         // sums of the same numbers -- so their overlaps are summed over a <= b only, the elements a < b twice: b is the slowest index, the
         // elements a <= b of a history vector are contiguous runs, and half of its bytes are not read (0.5 GB of 2.2 at eight vectors))
-        const bool hw = !YSW || a <= b;
+        // (only while every vector of the history is one the solver itself made: an amplitude set handed in from outside need not have
+        // the symmetry, and its error vector stays in the history for nerr iterations -- p.half is 0 for those, CCState::hist_plain)
+        const bool half = YSW && p.half;
+        const bool hw = !half || a <= b;
         if (NYT > 0) {
             as2 = p.amp_s[n1 + x];
             if (hw) {
@@ -893,7 +896,7 @@ __global__ __launch_bounds__(TB) void cc_tail_kernel(double* partial, TailArgs p
             p.ht[n1 + x] = t;
             p.he[n1 + x] = e;
             if (hw) {
-                const double ew = (YSW && a < b) ? 2.0 * e : e;
+                const double ew = (half && a < b) ? 2.0 * e : e;
 #pragma unroll
                 for (int q = 0; q < NYT; ++q) acc[q] += q < ny ? ew * (q == slot ? e : h[q]) : 0.0;
             }
@@ -978,7 +981,7 @@ void k_lincomb_vals(Context& cx, double* out, const double* xbase, int64_t xstri
 }
 void k_diis_solve(Context& cx, double* coef, double* bmat, double* flag, int n, int nerr, int slot)
 {
-    hipLaunchKernelGGL(diis_solve_kernel, dim3(1), dim3(TB), 0, cx.stream, coef, bmat, cx.scal + 64, flag, n, nerr, slot);
+    AFESP_KLAUNCH(diis_solve_kernel, dim3(1), dim3(TB), 0, cx.stream, coef, bmat, cx.scal + 64, flag, n, nerr, slot);
     AFESP_HIP(hipGetLastError());
 }
 void k_diis_push(Context& cx, double* ht, double* he, const double* amp, const double* amp_s, const double* hist_e, int64_t stride, int ny,
@@ -1013,6 +1016,7 @@ void k_cc_tail(Context& cx, const CCTail& a)
     p.t2 = a.t2; p.t1 = a.t1; p.r2 = a.r2; p.r1 = a.r1; p.voovv = a.voovv; p.D2 = a.D2; p.D1 = a.D1; p.pp = a.pp; p.t2_old = a.t2_old;
     p.o = a.o; p.v = a.v; p.ht = a.ht; p.he = a.he; p.amp_s = a.amp_s; p.hist_e = a.hist_e; p.stride = a.stride; p.ny = a.ny; p.slot = a.slot;
     p.r2y = a.r2y;
+    p.half = a.half_hist ? 1 : 0;
     const int nblk = (int)grid_for((int64_t)a.o * a.o * a.v * a.v, RED_BLOCKS);   // (only blocks that have elements write partials)
     if (a.r2y) {
         if (a.ny == 0) LAUNCH((cc_tail_kernel<0, true>), dim3(nblk), partials(cx), p);
@@ -1293,9 +1297,9 @@ void k_pair_xform(Context& cx, double* out, const double* in, const double* C, i
 {
     if (n > PX) throw Error(3, "k_pair_xform: more than 64 basis functions");
     if (npairs <= 0) return;
-    if (mode == 0) hipLaunchKernelGGL(pair_xform_kernel<0>, dim3((unsigned)npairs), dim3(256), 0, cx.stream, out, in, C, n);
-    else if (mode == 1) hipLaunchKernelGGL(pair_xform_kernel<1>, dim3((unsigned)npairs), dim3(256), 0, cx.stream, out, in, C, n);
-    else hipLaunchKernelGGL(pair_xform_kernel<2>, dim3((unsigned)npairs), dim3(256), 0, cx.stream, out, in, C, n);
+    if (mode == 0) AFESP_KLAUNCH(pair_xform_kernel<0>, dim3((unsigned)npairs), dim3(256), 0, cx.stream, out, in, C, n);
+    else if (mode == 1) AFESP_KLAUNCH(pair_xform_kernel<1>, dim3((unsigned)npairs), dim3(256), 0, cx.stream, out, in, C, n);
+    else AFESP_KLAUNCH(pair_xform_kernel<2>, dim3((unsigned)npairs), dim3(256), 0, cx.stream, out, in, C, n);
     AFESP_HIP(hipGetLastError());
 }
 void k_square_transpose(Context& cx, double* out, const double* in, int64_t n)
@@ -1336,7 +1340,7 @@ void k_build_fock(Context& cx, double* fock, const double* hcore, const double* 
     double *dv = work, *jpart = dv + np, *kp1 = jpart + FOCK_CHUNKS * n2, *kp2 = kp1 + np * n;
     LAUNCH(fock_dv_kernel, dim3(grid_for(np)), dv, dens, n);
     LAUNCH(fock_j_kernel, dim3((unsigned)((n2 + 255) / 256), FOCK_CHUNKS), jpart, u, dv, n);
-    hipLaunchKernelGGL(fock_k_kernel, dim3((unsigned)np), dim3(256), 2 * n * sizeof(double), cx.stream, kp1, kp2, u, dens, n);
+    AFESP_KLAUNCH(fock_k_kernel, dim3((unsigned)np), dim3(256), 2 * n * sizeof(double), cx.stream, kp1, kp2, u, dens, n);
     AFESP_HIP(hipGetLastError());
     LAUNCH(fock_reduce_kernel, dim3(grid_for(n2)), fock, hcore, jpart, kp1, kp2, n);
 }
@@ -1353,7 +1357,6 @@ namespace afesp {
 // use (0.1 - 0.7 ms each) -- three milliseconds of a process's first iteration otherwise
 void preload_small_path_kernels()
 {
-    hipFuncAttributes at;
     const void* fns[] = {reinterpret_cast<const void*>(asym_c_kernel), reinterpret_cast<const void*>(c_sympack_kernel),
                          reinterpret_cast<const void*>(denominators_kernel), reinterpret_cast<const void*>(mp2_energy_kernel),
                          reinterpret_cast<const void*>(mp2_packed_kernel<true>),
@@ -1364,13 +1367,6 @@ void preload_small_path_kernels()
                          reinterpret_cast<const void*>(antisym_pair_kernel), reinterpret_cast<const void*>(pp_expand_kernel),
                          reinterpret_cast<const void*>(pair_expand_add_kernel), reinterpret_cast<const void*>(pair_xform_kernel<1>),
                          reinterpret_cast<const void*>(pair_xform_kernel<2>), reinterpret_cast<const void*>(square_transpose_kernel)};
-    const bool dbg = getenv("AFESP_PRELOAD_DEBUG") != nullptr;
-    int k = 0;
-    for (const void* f : fns) {
-        const hipError_t e = hipFuncGetAttributes(&at, f);
-        if (dbg && e != hipSuccess) fprintf(stderr, "afesp preload: kernel %d of the small path: %s\n", k, hipGetErrorString(e));
-        ++k;
-    }
-    (void)hipGetLastError();
+    for (const void* f : fns) first_use_touch(f);   // (each under the process-wide first-use lock, first_use.h)
 }
 }  // namespace afesp

@@ -159,7 +159,7 @@ static RingTg* ring_get(Context& cx, CCState& s)
     r->cm1 = tab; r->cn1 = tab + n64; r->cm2 = tab + 2 * n64; r->cn2 = tab + 3 * n64;
     r->rc32 = (uint32_t*)(tab + 4 * n64);
     r->tab_block = tab;
-    hipLaunchKernelGGL(ring_tables_kernel, dim3((unsigned)std::min<int64_t>((n32 + 255) / 256, 4096)), dim3(256), 0, cx.stream, r->rc32, r->cm1,
+    AFESP_KLAUNCH(ring_tables_kernel, dim3((unsigned)std::min<int64_t>((n32 + 255) / 256, 4096)), dim3(256), 0, cx.stream, r->rc32, r->cm1,
                        r->cn1, r->cm2, r->cn2, s.o, s.v, r->Kc);
     AFESP_HIP(hipGetLastError());
     // descriptors: offsets are relative to the slab, so they are made once
@@ -237,7 +237,7 @@ bool ring_tg_pack(Context& cx, CCState& s)
     a.inv_o = tgemm_inverse(s.o);
     a.inv_oo = tgemm_inverse((int)oo);
     const int tiles = ((s.v + a.P - 1) / a.P) * ((s.v + a.Q - 1) / a.Q);
-    hipLaunchKernelGGL(ring_pack_kernel, dim3((unsigned)tiles), dim3(256), (size_t)(oo * a.P * a.Q * 8), cx.stream, a);
+    AFESP_KLAUNCH(ring_pack_kernel, dim3((unsigned)tiles), dim3(256), (size_t)(oo * a.P * a.Q * 8), cx.stream, a);
     AFESP_HIP(hipGetLastError());
     r->packed = true;
     return true;

@@ -247,7 +247,7 @@ static hipError_t tall_launch_one(const TallArgs& a, size_t lds, int grid, hipSt
     static const hipError_t attr =
         hipFuncSetAttribute(reinterpret_cast<const void*>(tall_kernel<TALL_N, NS, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((tall_kernel<TALL_N, NS, CH>), dim3(grid), dim3(512), lds, st, a);
+    AFESP_KLAUNCH((tall_kernel<TALL_N, NS, CH>), dim3(grid), dim3(512), lds, st, a);
     return hipGetLastError();
 }
 
@@ -338,7 +338,7 @@ static hipError_t tall_dual_launch_one(const TallArgs& a, const TallArgs& b, siz
     static const hipError_t attr =
         hipFuncSetAttribute(reinterpret_cast<const void*>(tall_dual_kernel<NS, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) return attr;
-    hipLaunchKernelGGL((tall_dual_kernel<NS, CH>), dim3(grid), dim3(512), lds, st, a, b);
+    AFESP_KLAUNCH((tall_dual_kernel<NS, CH>), dim3(grid), dim3(512), lds, st, a, b);
     return hipGetLastError();
 }
 
@@ -362,8 +362,7 @@ hipError_t tall_launch_dual(const GettProblem& p1, const GettProblem& p2, hipStr
 
 void preload_tall()
 {
-    hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(tall_kernel<false, 2, 13>));
+    first_use_touch(reinterpret_cast<const void*>(tall_kernel<false, 2, 13>));
     (void)hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 //   * fragments are read as ds_read_b128 pairs of k (the k order inside a step is remapped identically for A and B).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "first_use.h"
 #include <stdint.h>
 
 namespace afesp {

@@ -565,11 +565,10 @@ int tgemm_group_m(int M, int max_ntiles, int bm)
 
 void preload_tgemm()
 {
-    hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(tgemm_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(tgemm_mixed_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(tgemm_ring_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(tgemm_xform_kernel));
+    first_use_touch(reinterpret_cast<const void*>(tgemm_kernel));
+    first_use_touch(reinterpret_cast<const void*>(tgemm_mixed_kernel));
+    first_use_touch(reinterpret_cast<const void*>(tgemm_ring_kernel));
+    first_use_touch(reinterpret_cast<const void*>(tgemm_xform_kernel));
     (void)hipGetLastError();
 }
 
@@ -590,6 +589,7 @@ hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngrou
         int dev = 0, cus = 256, occ = 2;
         if (hipGetDevice(&dev) == hipSuccess) {
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+            std::lock_guard<std::mutex> lk(first_use_mutex());   // (the occupancy query resolves the function: a first use, first_use.h)
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, mixed ? tgemm_mixed_kernel : tgemm_kernel, 256, 0) != hipSuccess || occ <= 0) occ = 2;
         }
         cap = cus * occ;
@@ -623,10 +623,10 @@ hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngrou
         if (me != hipSuccess) return me;
         a.tickets = st.tickets;
     }
-    if (mixed) hipLaunchKernelGGL(tgemm_mixed_kernel, dim3(grid), dim3(256), 0, stream, a);
-    else if (p.tag == 1) hipLaunchKernelGGL(tgemm_ring_kernel, dim3(grid), dim3(256), 0, stream, a);
-    else if (p.tag == 2) hipLaunchKernelGGL(tgemm_xform_kernel, dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(tgemm_kernel, dim3(grid), dim3(256), 0, stream, a);
+    if (mixed) AFESP_KLAUNCH(tgemm_mixed_kernel, dim3(grid), dim3(256), 0, stream, a);
+    else if (p.tag == 1) AFESP_KLAUNCH(tgemm_ring_kernel, dim3(grid), dim3(256), 0, stream, a);
+    else if (p.tag == 2) AFESP_KLAUNCH(tgemm_xform_kernel, dim3(grid), dim3(256), 0, stream, a);
+    else AFESP_KLAUNCH(tgemm_kernel, dim3(grid), dim3(256), 0, stream, a);
     ++(mixed ? st.launches_mixed : st.launches);
     return hipGetLastError();
 }

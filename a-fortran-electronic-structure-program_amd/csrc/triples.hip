@@ -102,11 +102,11 @@ hipError_t triples_read_orbit_stamps(unsigned long long* out, int n)
 static void sum_partials(Context& cx, double* out, const double* partial, int nq, int nblk, double* tmp)
 {
     if (nblk > 8192) {
-        hipLaunchKernelGGL(triples_sum_kernel, dim3(nq, 128), dim3(256), 0, cx.stream, tmp, partial, nblk);
+        AFESP_KLAUNCH(triples_sum_kernel, dim3(nq, 128), dim3(256), 0, cx.stream, tmp, partial, nblk);
         AFESP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(triples_sum_kernel, dim3(nq), dim3(256), 0, cx.stream, out, tmp, 128);
+        AFESP_KLAUNCH(triples_sum_kernel, dim3(nq), dim3(256), 0, cx.stream, out, tmp, 128);
     } else {
-        hipLaunchKernelGGL(triples_sum_kernel, dim3(nq), dim3(256), 0, cx.stream, out, partial, nblk);
+        AFESP_KLAUNCH(triples_sum_kernel, dim3(nq), dim3(256), 0, cx.stream, out, partial, nblk);
     }
     AFESP_HIP(hipGetLastError());
 }
@@ -901,13 +901,13 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     if (!ops_valid) {
         const int64_t nblk = ((Kc + 31) / 32) * ((V + 31) / 32) * V * O;
         if (nblk < ((int64_t)1 << 31))
-            hipLaunchKernelGGL(triples_build_vt_tiled_kernel, dim3((unsigned)nblk), dim3(256), 0, cx.stream, vt.d, vtT.d, s.v_vvov.d, V, v2,
+            AFESP_KLAUNCH(triples_build_vt_tiled_kernel, dim3((unsigned)nblk), dim3(256), 0, cx.stream, vt.d, vtT.d, s.v_vvov.d, V, v2,
                                v2 * O, s.t2.d, o, v, (int)Kc);
         else
-            hipLaunchKernelGGL(triples_build_vt_kernel, blocks(Kc * v2 * O), dim3(256), 0, cx.stream, vt.d, vtT.d, s.v_vvov.d, V,
+            AFESP_KLAUNCH(triples_build_vt_kernel, blocks(Kc * v2 * O), dim3(256), 0, cx.stream, vt.d, vtT.d, s.v_vvov.d, V,
                                (int64_t)1, v2, v2 * O, s.t2.d, o, v, (int)Kc);
         AFESP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(triples_build_tt_kernel, blocks(Kc * V * O * O), dim3(256), 0, cx.stream, tt.d, s.t2.d, s.v_oovo.d, (int64_t)1, O,
+        AFESP_KLAUNCH(triples_build_tt_kernel, blocks(Kc * V * O * O), dim3(256), 0, cx.stream, tt.d, s.t2.d, s.v_oovo.d, (int64_t)1, O,
                            O * O, O * O * V, o, v, (int)Kc);
         AFESP_HIP(hipGetLastError());
     }
@@ -930,10 +930,10 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         vt2T.d = vt2.d + Kc * v2 * O;
         if (cx.t_ops_cr != s.cr_epoch) {
             // I_vovv_pp(d,k,b,c): strides of (b,c,k,d) = (V O, V^2 O, V, 1);  I_ooov_pp(j,i,l,a): (i,j,a,l) = (O, 1, O^3, O^2)
-            hipLaunchKernelGGL(triples_build_vt_kernel, blocks(Kc * v2 * O), dim3(256), 0, cx.stream, vt2.d, vt2T.d, s.I_vovv_pp.d, V * O,
+            AFESP_KLAUNCH(triples_build_vt_kernel, blocks(Kc * v2 * O), dim3(256), 0, cx.stream, vt2.d, vt2T.d, s.I_vovv_pp.d, V * O,
                                v2 * O, V, (int64_t)1, s.t2.d, o, v, (int)Kc);
             AFESP_HIP(hipGetLastError());
-            hipLaunchKernelGGL(triples_build_tt_kernel, blocks(Kc * V * O * O), dim3(256), 0, cx.stream, tt2.d, s.t2.d, s.I_ooov_pp.d, O,
+            AFESP_KLAUNCH(triples_build_tt_kernel, blocks(Kc * V * O * O), dim3(256), 0, cx.stream, tt2.d, s.t2.d, s.I_ooov_pp.d, O,
                                (int64_t)1, O * O * O, O * O, o, v, (int)Kc);
             AFESP_HIP(hipGetLastError());
             cx.t_ops_cr = s.cr_epoch;
@@ -1031,13 +1031,13 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
         }
         stamp();
         if (cr)
-            hipLaunchKernelGGL((triples_orbit_kernel<true, true>), dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
+            AFESP_KLAUNCH((triples_orbit_kernel<true, true>), dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
                                p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
         else if (!want_d)
-            hipLaunchKernelGGL((triples_orbit_kernel<false, true, false>), dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,
+            AFESP_KLAUNCH((triples_orbit_kernel<false, true, false>), dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,
                                Mpool, p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
         else
-            hipLaunchKernelGGL((triples_orbit_kernel<false, true>), dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
+            AFESP_KLAUNCH((triples_orbit_kernel<false, true>), dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool, Mpool,
                                p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
         AFESP_HIP(hipGetLastError());
         stamp();
@@ -1046,16 +1046,16 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
             cx.prof_orbit_bytes += 8.0 * 3.0 * (double)v3 * ch.nt;
         }
         if (pub) {
-            hipLaunchKernelGGL(triples_sum_publish_kernel, dim3(1), dim3(256), 0, cx.stream, cx.scal, pub, pub_seq, partial, nq, p->norb * ch.nt);
+            AFESP_KLAUNCH(triples_sum_publish_kernel, dim3(1), dim3(256), 0, cx.stream, cx.scal, pub, pub_seq, partial, nq, p->norb * ch.nt);
             AFESP_HIP(hipGetLastError());
         } else {
             sum_partials(cx, cx.scal, partial, nq, p->norb * ch.nt, sum_tmp);
         }
     }
     if (dbase) {
-        hipLaunchKernelGGL(triples_dbase_kernel, dim3(256), dim3(256), 0, cx.stream, partial, in, 256);
+        AFESP_KLAUNCH(triples_dbase_kernel, dim3(256), dim3(256), 0, cx.stream, partial, in, 256);
         AFESP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, 256);
+        AFESP_KLAUNCH(triples_sum_kernel, dim3(4), dim3(256), 0, cx.stream, cx.scal, partial, 256);
         AFESP_HIP(hipGetLastError());
     }
     double* h = pub ? host_scalars_wait(cx, 6, pub_seq) : host_scalars(cx, 6);
@@ -1139,7 +1139,7 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
     permute_add(cx, 1.0, s.t2, "qraf", 0.0, sub(tt, 0, V), "farq");
     permute_add(cx, -1.0, s.ovoo, "maqr", 0.0, sub(tt, V, O), "marq");
     permute_add(cx, 1.0, s.oovv, "pqxy", 0.0, vs, "xypq");
-    hipLaunchKernelGGL(so_levels_kernel, dim3((unsigned)((O + V + 255) / 256)), dim3(256), 0, cx.stream, e_so, s.e, (int)(O + V));
+    AFESP_KLAUNCH(so_levels_kernel, dim3((unsigned)((O + V + 255) / 256)), dim3(256), 0, cx.stream, e_so, s.e, (int)(O + V));
     AFESP_HIP(hipGetLastError());
     }
     cx.t_ops_owner = (const void*)&s;
@@ -1171,7 +1171,7 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
             gp.wide = true;   // (as in the spin-free plan: K-contiguous operands, Kc a multiple of 16)
             AFESP_HIP(gett_launch(gp, cx.ws, cx.stream));
         }
-        hipLaunchKernelGGL(triples_so_orbit_kernel, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,
+        AFESP_KLAUNCH(triples_so_orbit_kernel, dim3(p->norb, ch.nt), dim3(256), 0, cx.stream, partial, Xpool,
                            p->meta + ch.meta_off, p->orbits, in, p->norb * ch.nt);
         AFESP_HIP(hipGetLastError());
         // (two stages, 128 blocks first: one block walking the 67 200 partials of the H2O/cc-pVTZ shape took 0.10 ms of a 2.8 ms evaluation)
@@ -1183,15 +1183,14 @@ double so_triples(Context& cx, SOState& s, int64_t t_begin, int64_t t_end)
 
 void preload_triples()
 {
-    hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_sum_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_sum_publish_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_build_vt_tiled_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_build_tt_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_dbase_kernel));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_orbit_kernel<false, true, false>));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_orbit_kernel<false, true, true>));
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(triples_orbit_kernel<true, true, true>));
+    first_use_touch(reinterpret_cast<const void*>(triples_sum_kernel));
+    first_use_touch(reinterpret_cast<const void*>(triples_sum_publish_kernel));
+    first_use_touch(reinterpret_cast<const void*>(triples_build_vt_tiled_kernel));
+    first_use_touch(reinterpret_cast<const void*>(triples_build_tt_kernel));
+    first_use_touch(reinterpret_cast<const void*>(triples_dbase_kernel));
+    first_use_touch(reinterpret_cast<const void*>(triples_orbit_kernel<false, true, false>));
+    first_use_touch(reinterpret_cast<const void*>(triples_orbit_kernel<false, true, true>));
+    first_use_touch(reinterpret_cast<const void*>(triples_orbit_kernel<true, true, true>));
     (void)hipGetLastError();
     preload_tgemm();
 }

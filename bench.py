@@ -12,8 +12,8 @@ Workloads (BASELINE.json configs):
           means anything: the default, and what `value` is quoted on
   h2o_tz  config 2 shape: H2O/cc-pVTZ extents o=5, v=53 (its eri.dat is not bundled -> synthetic integrals)
   n2      config 3 extents o=7, v=21 (synthetic integrals; the real N2 / F2 inputs run in the `real_molecules_same_run` leg)
-value = algorithmic fp64 FLOP of the step (SURVEY.md 8(d), (T) counted over i<=j<=k as it is evaluated) / step time, summed over
-the job (strong scaling: total work fixed); `value_executed` counts only the multiply-adds the kernels issue.
+value = the fp64 multiply-adds (x 2) the kernels of the step issue / step time, summed over the job (strong scaling: total work
+fixed); `value_survey_count` is SURVEY.md 8(d)'s algorithmic count of the same step over the same time (one count per number).
 
 `--gpus N` without a launcher (WORLD_SIZE unset): this process starts N ranks of itself -- before anything touches the GPU -- and
 waits for them; under torchrun (WORLD_SIZE set) it must equal the world size.
@@ -400,6 +400,57 @@ class Reducer:
             eng.comm_destroy()
             self.own = False
             self.kind = "torch.distributed.all_reduce (afesp_comm_init failed on another rank)"
+        if self.own:
+            self._probe(rank)
+
+    def _probe(self, rank):
+        """Transport health is agreed BEFORE the first real collective: one tiny afesp_allreduce_sum right behind comm_init (the first time
+        ncclAllReduce runs on these N ranks at all), on a helper thread with a time limit, and its outcome -- fine / raised / still waiting
+        -- exchanged over torch.distributed.  All fine: the product's own transport serves the run.  All raised (nobody enqueued
+        anything): every rank falls back to torch.distributed and the line says so.  Anything one-sided -- a rank that raised while the
+        others sit in the library's stream synchronisation behind a collective waiting for it, or a rank that timed out -- cannot be
+        repaired from inside: every rank says so on stderr and exits non-zero at once, so the spawner fails fast instead of waiting in a
+        barrier."""
+        import threading
+        box = {}
+
+        def run():
+            try:
+                box["out"] = self.eng.allreduce_sum(np.array([float(rank + 1), 1.0]))
+            except Exception as exc:   # noqa: BLE001
+                box["err"] = exc
+
+        th = threading.Thread(target=run, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("AFESP_BENCH_PROBE_TIMEOUT", "90")))
+        w = self.world
+        if th.is_alive():
+            state = 2.0                                                            # still waiting in the library
+        elif "err" in box or not np.allclose(box.get("out", [0, 0]), [w * (w + 1) / 2, w], rtol=0, atol=1e-9):
+            state = 1.0                                                            # raised, or a wrong sum
+        else:
+            state = 0.0
+        hi = self.torch.tensor([state], dtype=self.torch.float64, device=self.cdev)
+        lo = hi.clone()
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        hi, lo = float(hi.cpu()[0]), float(lo.cpu()[0])
+        if hi == 0.0:
+            self.checked = True
+            return
+        if hi == 1.0 and lo == 1.0:   # every rank raised before anything was enqueued: a clean fall-back
+            try:
+                self.eng.comm_destroy()
+            except Exception:   # noqa: BLE001
+                pass
+            self.own = False
+            self.kind = f"torch.distributed.all_reduce (the probe afesp_allreduce_sum failed on every rank: {box.get('err')})"
+            return
+        sys.stderr.write(f"bench.py rank {rank}: the probe afesp_allreduce_sum ended one-sided (this rank: "
+                         f"{['fine', 'raised: ' + str(box.get('err')), 'no answer within the time limit'][int(state)]}); "
+                         "ranks disagree about the transport -- exiting\n")
+        sys.stderr.flush()
+        os._exit(3)
 
     count = 0
 
@@ -407,29 +458,7 @@ class Reducer:
         if self.world == 1:
             return np.asarray(values, dtype=np.float64)
         if self.own:
-            # The first afesp_allreduce_sum of a communicator is the first time its transport really runs (ncclAllReduce on N > 1
-            # GPUs has only ever executed on the driver's node): if it fails on any rank, every rank falls back to
-            # torch.distributed for the rest of the run and the line says so -- the measurement is not lost.
-            out, err = None, None
-            try:
-                out = self.eng.allreduce_sum(values)
-            except Exception as exc:   # noqa: BLE001
-                err = exc
-            if self.checked:
-                if err is not None:
-                    raise err
-                return out
-            self.checked = True
-            flag = self.torch.tensor([0.0 if err is not None else 1.0], dtype=self.torch.float64, device=self.cdev)
-            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
-            if float(flag.cpu()[0]) == 1.0:
-                return out
-            try:
-                self.eng.comm_destroy()
-            except Exception:   # noqa: BLE001
-                pass
-            self.own = False
-            self.kind = "torch.distributed.all_reduce (the first afesp_allreduce_sum failed" + (f": {err})" if err is not None else " on another rank)")
+            return self.eng.allreduce_sum(values)
         t = self.torch.from_numpy(np.ascontiguousarray(values, dtype=np.float64)).to(self.cdev)
         self.dist.all_reduce(t)
         return t.cpu().numpy()
@@ -594,7 +623,7 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
     elapsed, t_iter, t_trip = [float(x) for x in tt.cpu()]
     sec_per_step = elapsed / steps
     it_flop = int(eng.iteration_flop())     # the iteration as the engine evaluates it (pair forms counted as executed)
-    flop_step = it_flop + flops_t_sym(o, v)
+    flop_survey = flops_iter(o, v) + flops_t_sym(o, v)   # SURVEY 8(d), both parts algorithmic
     # executed: the (T) GEMMs evaluate o x o(o+1)/2 distinct blocks of 4 v^3 (v+o) flop (half of that where the occupied pair
     # coincides) instead of the symmetric count's 12 v^3 (v+o) per i<=j<=k triple; the CCSD iteration is replicated per rank
     split = world > 1 and red.own and eng.ccsd_is_split()   # the iteration's ring products and ladder run slice by slice on the ranks
@@ -603,18 +632,22 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
     res = None
     if rank == 0:
         res = {
-            "value": flop_step / sec_per_step / 1e12, "ms_per_step": sec_per_step * 1e3,
+            "value": flop_exec / sec_per_step / 1e12, "ms_per_step": sec_per_step * 1e3,
             "config": {"workload": f"{workload}: nocc={o} nvirt={v}, synthetic hashed ERIs scale {scale}; "
                                    "step = 1 CCSD iteration (replicated) + full (T) over i<=j<=k sharded across ranks",
                        "nocc": o, "nvirt": v, "triples": int(nt), "parallelism": (f"(T) ijk-shard x{world}; CCSD iteration: ring o^3v^3 products + pp-ladder split x{world} with one "
                                        f"all-reduce of [PP | residual], rest replicated" if split else f"(T) ijk-shard x{world}, CCSD replicas")},
-            "ccsd_iter_s": t_iter / steps, "t_s": t_trip / steps, "flop_per_step": flop_step,
-            "fraction_of_mfma_peak": flop_step / sec_per_step / 1e12 / (MFMA_F64_PEAK_TFLOPS * world),
-            "flop_per_step_executed": flop_exec,
-            "value_executed": flop_exec / sec_per_step / 1e12,
-            "fraction_of_mfma_peak_executed": flop_exec / sec_per_step / 1e12 / (MFMA_F64_PEAK_TFLOPS * world),
-            "rates_note": "value / fraction_of_mfma_peak: SURVEY 8(d) algorithmic count ((T) = [o(o+1)(o+2)/6] 12 v^3 (v+o)); "
-                          "value_executed / fraction_of_mfma_peak_executed: multiply-adds the kernels issue, all ranks",
+            "ccsd_iter_s": t_iter / steps, "t_s": t_trip / steps, "flop_per_step": flop_exec,
+            "fraction_of_mfma_peak": flop_exec / sec_per_step / 1e12 / (MFMA_F64_PEAK_TFLOPS * world),
+            # one count per number ("report which, never mix"): the headline is what the kernels issue; the survey's
+            # algorithmic count of the same step -- every contraction site of the iteration, (T) over i<=j<=k -- under a name of its own
+            "flop_per_step_survey_count": flop_survey,
+            "value_survey_count": flop_survey / sec_per_step / 1e12,
+            "fraction_of_mfma_peak_survey_count": flop_survey / sec_per_step / 1e12 / (MFMA_F64_PEAK_TFLOPS * world),
+            "rates_note": "value / fraction_of_mfma_peak: the multiply-adds the kernels issue (iteration as evaluated: pair forms; (T): "
+                          "o x o(o+1)/2 blocks of 4 v^3 (v+o), half where the pair coincides), all ranks; *_survey_count: SURVEY 8(d)'s "
+                          "algorithmic count of the step (iteration: every contraction site with the ladder over a<=b; (T) = "
+                          "[o(o+1)(o+2)/6] 12 v^3 (v+o)) -- larger than what is executed, so its fraction can exceed the kernel's",
             "e_t": [float(x) for x in acc["last"]], "rccl_ranks": rccl_ranks, "t_allreduce": red.kind,
             "ccsd_split": bool(split), "ccsd_split_check": split_check,
         }

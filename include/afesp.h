@@ -63,7 +63,9 @@ int afesp_ccsd_solve(afesp_ctx* ctx, int maxiter, double e_tol, double t_tol, do
 /* Converged amplitudes (what move_alloc hands to int_store_cc, src/ccsd.f90:386-387). */
 int afesp_ccsd_get_amplitudes(afesp_ctx* ctx, double* t1, double* t2);
 /* t2 must carry the symmetry of closed-shell amplitudes, t2(i,j,a,b) = t2(j,i,b,a) -- every set the solver itself produces does, to the
- * bit; the residual is formed as r2 + its image, and a large system's DIIS overlaps are summed over a <= b only. */
+ * bit; the residual is formed as r2 + its image and the pp-ladder over pair indices.  (A large system sums its DIIS overlaps over a <= b
+ * only; for the nerr iterations in which the error vector of a handed-in set is part of the history it sums every element, so a set that
+ * is symmetric up to rounding costs nothing in accuracy.) */
 int afesp_ccsd_set_amplitudes(afesp_ctx* ctx, const double* t1, const double* t2);
 /* Named device tensor -> host (tests / debugging).  Names: v_oovv v_ovov v_vvov v_oovo v_oooo v_vvvv I_vo I_vv I_oo_p
  * I_oo c_oovv asym_t2 x_voov I_oooo I_ovov I_voov I_vovv_p I_ooov_p r1 r2 D1 D2 t1 t2
@@ -205,6 +207,10 @@ int afesp_test_inject(afesp_ctx* ctx, int what);
  * layer's planner, the LDS-DMA GEMM with 128-row tiles, the LDS-DMA GEMM with 96-row tiles where the rows end} -- tests check with it
  * that a product took the kernel meant for its shape (tests/test_gpu_operators.py, tests/test_gpu_cc.py). */
 int afesp_launch_counts(afesp_ctx* ctx, uint64_t out[4]);
+/* Test / diagnostic hook, per process: launch sites that have resolved their kernel function under the process-wide first-use lock so
+ * far (csrc/first_use.h: every first use of a kernel function -- by a launch, an occupancy query or the start-up thread's preload -- is
+ * made under one lock, so two host threads never first-touch a translation unit or a function at the same time). */
+uint64_t afesp_first_use_count(void);
 /* Diagnostic builds only: n > 0: per (workgroup, wave) cycle sums of the GEMM kernel's last launch (tools/stamp_probe.py);
  * n < 0: the first -n phase sums of the (T) orbit kernel since the last call (tools/orbit_stamps.py).  Zeros in a shipped build. */
 int afesp_debug_stamps(unsigned long long* out, int n);

@@ -157,6 +157,29 @@ def test_amplitudes_set_again_between_intermediates_and_update(eng, monkeypatch)
     assert np.max(np.abs(_p(eng.tensor("r2")) - _p(cc.field("r2")))) < 1e-12
 
 
+def test_solve_from_amplitudes_handed_in_on_the_large_system_path(eng, monkeypatch):
+    """afesp_ccsd_set_amplitudes then afesp_ccsd_solve down the large-system path: the error vector of the iteration that starts from the
+    handed-in set stays in the DIIS history for nerr iterations, and while it does the two-kernel tail sums the DIIS overlaps over every
+    element (CCState::hist_plain) instead of a <= b; afterwards it halves them again.  Every iteration energy against the oracle, which
+    sums everything, through more iterations than the history has slots."""
+    monkeypatch.setenv("AFESP_SMALL_MAX", "0")
+    monkeypatch.setenv("AFESP_RING_TG_MIN", "1")
+    o, v, nerr = 4, 9, 3
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05)
+    cc = orc.OracleCC(o, v, eri, e, nerr)
+    eng.ccsd_init(o, v, e, eri, nerr)
+    rng = np.random.default_rng(11)
+    t1 = 0.02 * rng.standard_normal((o, v))
+    t2 = 0.02 * rng.standard_normal((o, o, v, v))
+    t2 = 0.5 * (t2 + t2.transpose(1, 0, 3, 2))
+    cc.t1[...] = t1; cc.t2[...] = t2
+    eng.set_amplitudes(t1, t2)
+    nit, en, rm = eng.do_ccsd_spatial(30, 1e-10, 1e-10)
+    onit, oen, orm = cc.solve(30, 1e-10, 1e-10)
+    assert nit == onit and nit > nerr + 2, (nit, onit)
+    assert np.max(np.abs(en[:nit + 1] - oen[:nit + 1])) < 1e-10 and np.max(np.abs(rm[:nit + 1] - orm[:nit + 1])) < 1e-10
+
+
 @pytest.mark.parametrize("pp_sym", ["0", "1"])
 def test_reinitialised_state_follows_new_integrals(pp_sym, monkeypatch):
     """Initialised again where it lies with OTHER integrals of the same extents (the next geometry of a scan), on both forms of the
@@ -860,6 +883,49 @@ def test_two_live_contexts_launch_the_lds_dma_gemm_side_by_side():
         print("ok")
     """) % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "a-fortran-electronic-structure-program_amd")
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AFESP_TG_DYNAMIC="2"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_two_contexts_first_use_the_large_system_kernels_from_two_threads():
+    """Every first use of a kernel function is made under one process-wide lock (csrc/first_use.h), whoever makes it: here two contexts on
+    two host threads enter the large-system iteration -- gather kernel, streamed tall x skinny kernel, the ring launches of the LDS-DMA
+    GEMM, the two-kernel tail -- and then (T) as their FIRST calls, with the start-up thread's preload running (AFESP_NO_PRELOAD unset),
+    i.e. the translation units the preload list does not name (gett, tall, ring) are first-touched by both threads at once.  Each
+    reproduces what a context does alone afterwards.  A process of its own: the threads start behind a barrier right after the
+    contexts exist, nothing has been launched before."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, threading
+        import numpy as np
+        sys.path.insert(0, %r)
+        from afesp_amd.capi import Engine, first_use_count
+        engs = [Engine(0), Engine(0)]
+        gate = threading.Barrier(2)
+        res = [None, None]
+        def work(k):
+            gate.wait()
+            e = engs[k]
+            e.synthetic_init(6 + k, 22 - 2 * k, 0.03, 7 + k, 6)
+            nit, en, rm = e.do_ccsd_spatial(10, 1e-9, 1e-9)
+            res[k] = (nit, en[:nit + 1].copy(), e.do_ccsd_t_spatial())
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        [t.start() for t in th]; [t.join() for t in th]
+        assert all(r is not None for r in res), res
+        n_sites = first_use_count()
+        assert n_sites > 20, n_sites          # the launch sites resolved their kernels under the lock
+        for k in range(2):                    # ... and alone, afterwards, each gets the same numbers
+            with Engine(0) as e:
+                e.synthetic_init(6 + k, 22 - 2 * k, 0.03, 7 + k, 6)
+                nit, en, rm = e.do_ccsd_spatial(10, 1e-9, 1e-9)
+                t = e.do_ccsd_t_spatial()
+            assert nit == res[k][0] and np.max(np.abs(en[:nit + 1] - res[k][1])) < 1e-13, (k, en, res[k][1])
+            assert np.max(np.abs(t - res[k][2])) < 1e-13 * max(1.0, np.max(np.abs(t))), (k, t, res[k][2])
+        for e in engs: e.close()
+        print("ok", n_sites)
+    """) % os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "a-fortran-electronic-structure-program_amd")
+    env = dict(os.environ, AFESP_SMALL_MAX="0", AFESP_RING_TG_MIN="1", AFESP_TALL_MIN="64")
+    env.pop("AFESP_NO_PRELOAD", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
 
 
