@@ -30,7 +30,7 @@ EXPORTS = [
     "afesp_read_eri_text", "afesp_write_fcidump", "afesp_set_eri", "afesp_build_fock", "afesp_ccsd_t_plain",
     "afesp_synthetic_ao", "afesp_ccsd_pp_ladder_flop", "afesp_ccsd_iteration_flop",
     "afesp_device_count", "afesp_comm_unique_id", "afesp_comm_init", "afesp_comm_destroy", "afesp_allreduce_sum",
-    "afesp_ccsd_t_block_size", "afesp_test_inject", "afesp_ccsd_is_split", "afesp_ccsd_set_split", "afesp_ccsd_set_fused", "afesp_ccsd_iteration_launches", "afesp_debug_stamps", "afesp_launch_counts", "afesp_first_use_count", "afesp_arena_stats",
+    "afesp_ccsd_t_block_size", "afesp_test_inject", "afesp_ccsd_is_split", "afesp_ccsd_set_split", "afesp_ccsd_set_fused", "afesp_ccsd_iteration_launches", "afesp_debug_stamps", "afesp_launch_counts", "afesp_first_use_count", "afesp_test_ring_path", "afesp_arena_stats",
 ]
 COMM_RCCL, COMM_HOST = 0, 1
 
@@ -120,6 +120,7 @@ def load_library():
     L.afesp_launch_counts.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.afesp_first_use_count.argtypes = []
     L.afesp_first_use_count.restype = C.c_uint64
+    L.afesp_test_ring_path.argtypes = [C.c_int64, C.c_int64]
     _lib = L
     return L
 

@@ -1597,6 +1597,14 @@ int afesp_debug_stamps(unsigned long long* out, int n)
 }
 
 // which kernel took the products of this context so far (tests: a shape that should stream did, the LDS-DMA GEMM ran with 96-row tiles)
+int afesp_test_ring_path(int64_t nocc, int64_t nvirt)
+{
+    CCState s;
+    s.o = (int)nocc;
+    s.v = (int)nvirt;
+    return ring_tg_applies(s) ? 1 : 0;
+}
+
 uint64_t afesp_first_use_count(void) { return first_use_count().load(std::memory_order_relaxed); }
 
 int afesp_launch_counts(afesp_ctx* ctx, uint64_t out[4])

@@ -211,6 +211,10 @@ int afesp_launch_counts(afesp_ctx* ctx, uint64_t out[4]);
  * far (csrc/first_use.h: every first use of a kernel function -- by a launch, an occupancy query or the start-up thread's preload -- is
  * made under one lock, so two host threads never first-touch a translation unit or a function at the same time). */
 uint64_t afesp_first_use_count(void);
+/* Test hook, host logic only (no device needed): 1 if a system of these extents takes the grouped ring launches of the LDS-DMA GEMM
+ * (csrc/ring.hip: from o v = 3584 on, and only while the 32-bit row byte offsets of an operand reach every row, 8 Kc o v < 4 GiB),
+ * 0 if its six o^3 v^3 ring products stay on the gather kernel. */
+int afesp_test_ring_path(int64_t nocc, int64_t nvirt);
 /* Diagnostic builds only: n > 0: per (workgroup, wave) cycle sums of the GEMM kernel's last launch (tools/stamp_probe.py);
  * n < 0: the first -n phase sums of the (T) orbit kernel since the last call (tools/orbit_stamps.py).  Zeros in a shipped build. */
 int afesp_debug_stamps(unsigned long long* out, int n);

@@ -139,3 +139,25 @@ def test_multi_rank_launcher_ends_the_job_when_a_rank_fails(tmp_path):
     assert res.returncode != 0
     assert "a rank failed" in res.stderr
     assert time.time() - t0 < 60
+
+
+def test_ring_launches_give_way_to_the_gather_kernel_at_the_row_offset_bound(monkeypatch):
+    """csrc/ring.hip addresses a row of an operand by a 32-bit byte offset: the grouped ring launches of the LDS-DMA GEMM apply from
+    o v = 3584 on and only while 8 Kc o v < 4 GiB (Kc = o v rounded up to whole K steps of 16); past that -- and below the lower bound --
+    the six ring products stay on the gather kernel, whose offsets are 64-bit.  Host logic, no device: faked extents either side of
+    both bounds (o v = 23 128 is the last product of o = 56 that fits, 23 184 the first that does not)."""
+    from afesp_amd import capi
+    L = capi.load_library()
+    monkeypatch.delenv("AFESP_RING_TG", raising=False)
+    monkeypatch.delenv("AFESP_RING_TG_MIN", raising=False)
+    assert L.afesp_test_ring_path(20, 200) == 1 and L.afesp_test_ring_path(40, 360) == 1
+    assert L.afesp_test_ring_path(16, 160) == 0                     # o v = 2560 < 3584
+    assert L.afesp_test_ring_path(56, 413) == 1                     # 8 * 23136 * 23128 = 4.2807e9 < 2^32 - 4096
+    assert L.afesp_test_ring_path(56, 414) == 0                     # 8 * 23184 * 23184 = 4.3000e9: the gather kernel
+    assert L.afesp_test_ring_path(64, 512) == 0 and L.afesp_test_ring_path(100, 1000) == 0
+    for o, v in ((56, 413), (56, 414), (30, 300), (72, 321), (73, 317)):
+        ov = o * v
+        kc = (ov + 15) // 16 * 16
+        assert L.afesp_test_ring_path(o, v) == (1 if ov >= 3584 and 8 * kc * ov < 2**32 - 4096 else 0), (o, v)
+    monkeypatch.setenv("AFESP_RING_TG", "0")
+    assert L.afesp_test_ring_path(20, 200) == 0

@@ -192,3 +192,39 @@ def test_loop_sites_of_the_cpu_baseline_equal_their_defining_sums():
     ref = (-np.einsum("mjae,iemb->ijab", t2, I_ovov) - np.einsum("iema,mjeb->ijab", I_ovov, t2)
            + np.einsum("miea,ejmb->ijab", asym, I_voov))
     assert np.max(np.abs(out - f(ref))) < 1e-13
+
+
+def test_numpy_restatement_equals_the_loop_form():
+    """tests/np_cc.py (one dgemm per o^3 v^3 sum, the pp-ladder on sampled column pairs: what tools/big_system_check.py holds the device
+    against at sizes past config 5) against the loop-form restatement that the reference's bundled outputs pin, from amplitudes with
+    t1 != 0: every intermediate, r1, and r2 / the updated t2 on every column pair."""
+    import molecules
+    import np_cc
+    import orc
+    o, v = 3, 7
+    n, e, eri = molecules.synthetic_system(o, v, scale=0.05)
+    cc = orc.OracleCC(o, v, eri, e, 4)
+    rng = np.random.default_rng(5)
+    t1 = 0.05 * rng.standard_normal((o, v))
+    t2 = 0.05 * rng.standard_normal((o, o, v, v))
+    t2 = 0.5 * (t2 + t2.transpose(1, 0, 3, 2))
+    cc.t1[...] = t1; cc.t2[...] = t2
+    cc.L.orc_cc_intermediates(cc.h)
+    f = lambda name: np.array(cc.field(name))
+    oovv, ovov, vvov, oovo, oooo, vvvv = (f(k) for k in ("v_oovv", "v_ovov", "v_vvov", "v_oovo", "v_oooo", "v_vvvv"))
+    I = np_cc.intermediates(t1, t2, oovv, ovov, vvov, oovo, oooo)
+    for name in ("asym_t2", "c_oovv", "I_vo", "I_vv", "I_oo_p", "I_oo", "I_oooo", "I_ovov", "I_voov", "x_voov", "I_ooov_p"):
+        assert np.max(np.abs(I[name] - f(name))) < 1e-13, name
+    ref_vovv = f("I_vovv_p")
+    for a in range(v):
+        for b in range(v):
+            assert np.max(np.abs(np_cc.vovv_p_cols(t1, oovv, ovov, vvov, a, b) - ref_vovv[:, :, a, b])) < 1e-13
+    cc.L.orc_cc_amplitudes(cc.h)
+    assert np.max(np.abs(np_cc.r1(t1, I, oovv, ovov, vvov, oovo) - f("r1"))) < 1e-13
+    r2, D2, t2_new = f("r2"), f("D2"), np.array(cc.t2)
+    for a in range(v):
+        for b in range(v):
+            rab = np_cc.r2_cols(t1, t2, I, oovv, ovov, vvov, vvvv[:, :, a, b], a, b)
+            rba = np_cc.r2_cols(t1, t2, I, oovv, ovov, vvov, vvvv[:, :, b, a], b, a)
+            assert np.max(np.abs(rab - r2[:, :, a, b])) < 1e-13, (a, b)
+            assert np.max(np.abs(np_cc.new_t2_cols(rab, rba, oovv, D2, a, b) - t2_new[:, :, a, b])) < 1e-13, (a, b)
