@@ -40,8 +40,7 @@ struct afesp_ctx {
             if (exec) (void)hipGraphExecDestroy(exec);
             exec = nullptr;
             calls = 0;
-            const char* e = getenv("AFESP_NO_GRAPH");
-            disabled = e && e[0] == '1';
+            disabled = knobs().no_graph;
         }
     } graph_cc;
     int64_t eri_ao_n = 0;
@@ -86,6 +85,7 @@ int guarded(afesp_ctx* c, F&& f)
 {
     if (!c) return 1;
     first_use_tls_device() = c->cx.device;   // (the launch sites' per-device flags, first_use.h)
+    knobs_refresh();                          // (every AFESP_* variable follows the environment call by call, knobs.h)
     // A body that threw may have forked lanes without joining them: before the caller can free or re-initialise anything, every
     // lane is idle and lane 0 is the one in use again.
     auto settle = [&]() {
@@ -156,8 +156,7 @@ static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body 
     // Capturing and instantiating the ~110-node graph costs ~10 ms; a replay saves ~0.1 ms over the laned launches.  A real
     // molecule converges in 15-30 iterations, so the capture waits until a context has iterated long enough for it to pay
     // (AFESP_GRAPH_AFTER, default 40 calls).
-    const char* ga = getenv("AFESP_GRAPH_AFTER");
-    const int graph_after = ga ? atoi(ga) : 40;
+    const int graph_after = knobs().graph_after;
     if (g.calls == 0 || g.epoch != cx.scratch_epoch || g.calls < graph_after) {
         // first call, or cached scratch buffers were dropped since the last one: whatever the body (re)builds or allocates is
         // done here, outside any capture
@@ -193,7 +192,7 @@ static void replay(afesp_ctx* ctx, afesp_ctx::GraphSlot& g, bool eligible, Body 
         AFESP_HIP(hipGraphLaunch(g.exec, cx.stream));
         return;
     }
-    if (getenv("AFESP_GRAPH_DEBUG")) fprintf(stderr, "afesp: graph capture failed (body ok %d, end capture %d)\n", (int)ok, (int)e);
+    if (knobs().graph_debug) fprintf(stderr, "afesp: graph capture failed (body ok %d, end capture %d)\n", (int)ok, (int)e);
     (void)hipGetLastError();
     if (graph) (void)hipGraphDestroy(graph);
     g.exec = nullptr;
@@ -229,7 +228,7 @@ static bool ccsd_iteration_body(afesp_ctx* ctx)   // true: the launch-fused prog
     // DIIS history push in ONE pass over the residual instead of three (update, energy, push: 26 against 23 passes over o^2 v^2 elements at
     // eight history vectors, and no host wait between the energy and the push); the <= 17 x 17 system is then solved on the host.
     // AFESP_LARGE_TAIL=0: the three kernels.
-    if (!ccsd_uses_lanes(ctx->cc) && !(getenv("AFESP_LARGE_TAIL") && getenv("AFESP_LARGE_TAIL")[0] == '0')) {
+    if (!ccsd_uses_lanes(ctx->cc) && knobs().large_tail) {
         ccsd_intermediates(ctx->cx, ctx->cc, true);
         ccsd_amplitudes(ctx->cx, ctx->cc, true);
         ccsd_tail_launch(ctx->cx, ctx->cc);
@@ -272,16 +271,14 @@ int afesp_ctx_create(int device, afesp_ctx** out)
         // The device code of a translation unit is loaded on the first use of one of its kernels -- 55-70 ms in all, which a
         // small molecule would pay inside its first CCSD iteration.  Ask for it now, on a thread of its own: the caller goes
         // on with its host work (parsing eri.dat, the SCF set-up) meanwhile.  AFESP_NO_PRELOAD=1 switches it off.
-        const char* np = getenv("AFESP_NO_PRELOAD");
-        if (!(np && np[0] == '1')) {
+        if (!knobs().no_preload) {
             // one start-up thread per process and device (PreloadClaim); a later context of the device starts none
             if (g_preload.claim(device)) c->cx.startup = std::thread([device, c] {
                 first_use_tls_device() = device;
                 if (hipSetDevice(device) != hipSuccess) return;
                 // (the parallel streams of the call-by-call iteration: small systems run the launch-fused iteration on ONE stream since
                 // round 4, so the 10-25 ms of queue creation are only spent ahead of time on request; fork() makes them when needed)
-                const char* pl = getenv("AFESP_PRELOAD_LANES");
-                if (pl && pl[0] == '1') Context::prepare_lanes(c->cx.prepared, 6);   // (the context itself is not touched: fork() adopts them)
+                if (knobs().preload_lanes) Context::prepare_lanes(c->cx.prepared, 6);   // (the context itself is not touched: fork() adopts them)
                 {
                     // the runtime's own first-use set-up (staging buffers of pageable copies, its fill / copy kernels): ~8 ms that
                     // the first plan upload of a process would otherwise pay inside the first CCSD iteration
@@ -299,7 +296,7 @@ int afesp_ctx_create(int device, afesp_ctx** out)
                     if (st) (void)hipStreamDestroy(st);
                     (void)hipGetLastError();
                 }
-                const bool dbg = getenv("AFESP_PRELOAD_DEBUG") != nullptr;   // time per translation unit on stderr
+                const bool dbg = knobs().preload_debug;   // time per translation unit on stderr
                 auto timed = [dbg](const char* what, void (*fn)()) {
                     const auto t0 = std::chrono::steady_clock::now();
                     fn();
@@ -315,8 +312,7 @@ int afesp_ctx_create(int device, afesp_ctx** out)
                 timed("small path", preload_small_path_kernels);
                 timed("triples", preload_triples);
                 timed("ccsd_so", preload_ccsd_so);
-                const char* pg = getenv("AFESP_PRELOAD_GETT");
-                if (pg && pg[0] == '1') timed("gett", preload_gett);
+                if (knobs().preload_gett) timed("gett", preload_gett);
             });
         }
     });
@@ -509,8 +505,7 @@ static void ao2mo_tg_xform(Context& cx, Ao2moTg& t, const double* in, double* ou
     TgProblem p{t.ct, in, out, t.rowA + row0, t.offCm + row0, (int)M, true, (int)((n - (t.Kc - TG_BK) + 3) / 4)};
     p.tag = 2;
     // (rows that end at most 96 past a multiple of 128 -- n = 220: 92 -- take a 96-row last tile: three quarters of its MFMAs, tgemm.h)
-    static const bool mixed_off = getenv("AFESP_AO2MO_MIXED") && getenv("AFESP_AO2MO_MIXED")[0] == '0';
-    const int bm = (!mixed_off && M % TG_BM != 0 && M % TG_BM <= 96) ? TG_BM : 0;
+    const int bm = (knobs().ao2mo_mixed && M % TG_BM != 0 && M % TG_BM <= 96) ? TG_BM : 0;
     AFESP_HIP(tgemm_launch(p, dev, ng, tile, mx, cx.stream, cx.tg, bm));
 }
 }  // namespace
@@ -547,11 +542,10 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         // p >= q only -- 4 n^5 flop and two buffers of n^2 x npair instead of 8 n^5 and two of n^4.
         const int64_t np = n * (n + 1) / 2;
         const bool have_u = ao == ctx->eri_ao_dev && ctx->half_n == n && ctx->half_epoch == cx.scratch_epoch;   // afesp_build_fock left (ij|KL)
-        const char* blk_env = getenv("AFESP_AO2MO_BLOCKED");
         // slab by slab from temporaries of 16 GiB each (n >= 256): at n = 220 the blocked form is 5 % slower (58.9 against 55.8 ms:
         // one more pass over the half-transformed integrals) for 12.5 GB less -- it is there for the sizes where 2 n^2 npair
         // doubles no longer fit beside the rest (n = 400: 2 x 103 GB)
-        const bool blocked = blk_env ? blk_env[0] == '1' : n * n * np >= ((int64_t)1 << 31);
+        const bool blocked = knobs().ao2mo_blocked >= 0 ? knobs().ao2mo_blocked == 1 : n * n * np >= ((int64_t)1 << 31);
         if (!blocked) {
             // Small bases: the whole tensor at once, nine launches.  The two temporaries are cached scratch: a second transform in
             // the same context reuses them, the next afesp_ccsd_init / afesp_ccsd_so_init gives them back.
@@ -560,10 +554,9 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
             Tensor Ta = view(cx.scratch("ao2mo_a", n * n * np + 16), {n, n, np}), Tb = view(cx.scratch("ao2mo_b", n * n * np + 16), {n, n, np});
             // the LDS-DMA GEMM: even n, and from n = 96 on (its tile has 128 rows: below that most of a tile is padding and
             // the transform is launch-bound anyway); AFESP_AO2MO_TG=0 / 1: never / for every even n >= 16 (tests, A/B runs)
-            const char* tg_env = getenv("AFESP_AO2MO_TG");
-            const bool use_tg = n % 2 == 0 && n >= 16 && (tg_env ? tg_env[0] == '1' : n >= 96);
+            const bool use_tg = n % 2 == 0 && n >= 16 && (knobs().ao2mo_tg >= 0 ? knobs().ao2mo_tg == 1 : n >= 96);
             // up to 64 basis functions: the LDS-resident pair transform (AFESP_AO2MO_PAIR=0: the gather-GEMM form)
-            const bool pair_path = n <= 64 && !use_tg && !(getenv("AFESP_AO2MO_PAIR") && getenv("AFESP_AO2MO_PAIR")[0] == '0');
+            const bool pair_path = n <= 64 && !use_tg && knobs().ao2mo_pair;
             if (!have_u && !pair_path) k_unpack_half(cx, Ta.d, ao, (int)n);   // (ij|KL), ij squared up
             ctx->half_n = 0;                                             // the transform overwrites it
             if (use_tg) {
@@ -642,8 +635,7 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         ctx->eri_mo_n = n;
         // MP2 energy on the <ij|ab> slice (mp2.f90:418-440)
         double emp2 = 0.0;
-        const char* mpk = getenv("AFESP_MP2_PACKED");   // 0: the five-launch form at every size (A/B runs)
-        if (o * o * v * v <= ((int64_t)1 << 22) && !(mpk && mpk[0] == '0')) {
+        if (o * o * v * v <= ((int64_t)1 << 22) && knobs().mp2_packed) {   // (AFESP_MP2_PACKED=0: the five-launch form at every size, A/B runs)
             // small systems: one launch, straight from the packed array (the slice and the denominators are formed on the fly)
             emp2 = k_mp2_packed(cx, packed, canon_levels, (int)o, (int)v);
         } else {
@@ -1591,14 +1583,16 @@ int afesp_ccsd_t_block_size(afesp_ctx* ctx, int64_t nocc, int64_t nvirt, int cr,
 // diagnostic builds of the GEMM kernel (AFESP_GETT_VARIANT bit 64): the per-wave cycle stamps of the last launch
 int afesp_debug_stamps(unsigned long long* out, int n)
 {
+    knobs_refresh();
     if (n < 0) return triples_read_orbit_stamps(out, -n) == hipSuccess ? 0 : 1;   // the (T) orbit kernel's phase sums
-    if (getenv("AFESP_STAMPS_GROUPED")) return gett_read_stamps_grouped(out, n) == hipSuccess ? 0 : 1;
+    if (knobs().stamps_grouped) return gett_read_stamps_grouped(out, n) == hipSuccess ? 0 : 1;
     return gett_read_stamps(out, n) == hipSuccess ? 0 : 1;
 }
 
 // which kernel took the products of this context so far (tests: a shape that should stream did, the LDS-DMA GEMM ran with 96-row tiles)
 int afesp_test_ring_path(int64_t nocc, int64_t nvirt)
 {
+    knobs_refresh();
     CCState s;
     s.o = (int)nocc;
     s.v = (int)nvirt;

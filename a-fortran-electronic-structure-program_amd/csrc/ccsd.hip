@@ -25,8 +25,7 @@ static inline int64_t tri64(int64_t i, int64_t j) { return i >= j ? i * (i + 1) 
 // AFESP_CC_REINIT=0: always from scratch.
 bool ccsd_can_reinit(const CCState& s, int o, int v, int diis_nerr)
 {
-    const char* e = getenv("AFESP_CC_REINIT");
-    if (e && e[0] == '0') return false;
+    if (!knobs().cc_reinit) return false;
     return s.ready && s.o == o && s.v == v && s.nerr == diis_nerr && s.pp_sym == pp_sym_pays(o, v);
 }
 
@@ -235,10 +234,9 @@ bool ccsd_uses_lanes(const CCState& s) { return lanes_pay(s); }
 
 static bool lanes_pay(const CCState& s)
 {
-    static const bool off = [] { const char* e = getenv("AFESP_NO_LANES"); return e && e[0] == '1'; }();
+    const bool off = knobs().no_lanes;
     // (tuning knob AFESP_SMALL_MAX: the largest o^2 v^2 that still takes the small-system paths)
-    const char* e = getenv("AFESP_SMALL_MAX");
-    const int64_t small_max = e ? (int64_t)atof(e) : (int64_t)1 << 20;
+    const int64_t small_max = knobs().small_max;
     return !off && !s.sharded && s.t2.size() <= small_max;
 }
 
@@ -254,7 +252,7 @@ static bool lanes_pay(const CCState& s)
 // iteration both ways from the same amplitudes) before timing or trusting it.
 void ccsd_refresh_sharding(Context& cx, CCState& s)
 {
-    static const int env = [] { const char* e = getenv("AFESP_CC_SHARD"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const int env = knobs().cc_shard;
     const int world = cx.comm ? cx.comm->world : 1;
     s.sh_world = world;
     s.sh_rank = cx.comm ? cx.comm->rank : 0;
@@ -263,10 +261,7 @@ void ccsd_refresh_sharding(Context& cx, CCState& s)
     // measurement only (tools/split_slice_time.py): AFESP_CC_TIME_SLICE="rank,world" without a communicator -- the iteration does a
     // rank's share of the split form and skips the exchange; the amplitudes that come out are NOT the iteration's
     if (!cx.comm)
-        if (const char* e = getenv("AFESP_CC_TIME_SLICE")) {
-            int r = 0, w = 1;
-            if (sscanf(e, "%d,%d", &r, &w) == 2 && w > 1 && r >= 0 && r < w) { s.sharded = true; s.sh_rank = r; s.sh_world = w; }
-        }
+        if (knobs().cc_time_slice) { s.sharded = true; s.sh_rank = knobs().cc_time_rank; s.sh_world = knobs().cc_time_world; }
 }
 
 // This rank's slice [v0, v1) of a virtual index in a split iteration (the whole range otherwise).  (Cuts on even indices only -- so
@@ -467,7 +462,7 @@ static int tile_cols(int64_t n)
 }
 bool pp_sym_pays(int64_t O, int64_t V)
 {
-    if (const char* e = getenv("AFESP_PP_SYM")) return e[0] == '1';
+    if (knobs().pp_sym >= 0) return knobs().pp_sym == 1;
     // the split pays when it still halves the work after padding the o-pair extents to whole column tiles
     const double plain = (double)tile_cols(O * O) * (double)(V * V) * (double)(V * (V + 1) / 2);
     const double split = (double)tile_cols(O * (O + 1) / 2) * (double)(V * (V + 1) / 2) * (double)(V * (V + 1) / 2) +
@@ -559,11 +554,9 @@ void ccsd_pp_ladder(Context& cx, CCState& s)
     gp.A = s.pp_vs; gp.B = s.pp_cs; gp.C = s.pp_ps;
     gp.offAm = u + p0; gp.offBk = u + 2 * nm; gp.offCm = u + 2 * nm + 2 * kx + p0;
     gp.M = (int)(p1 - p0); gp.N = (int)ns; gp.K = (int)(fold ? ks + ns : ks);
-    const char* fs = getenv("AFESP_PP_SPLIT");   // tuning knob: K slices of the two pair products (0 = the launcher's own choice)
-    const int force_split = fs ? atoi(fs) : 0;
-    // tuning knob AFESP_PP_TILES="tm,tn,split,tm,tn,split": tile codes and K slices of the symmetric / the antisymmetric product
-    int pt[6] = {0, 0, force_split, 0, 0, force_split};
-    if (const char* e = getenv("AFESP_PP_TILES")) sscanf(e, "%d,%d,%d,%d,%d,%d", &pt[0], &pt[1], &pt[2], &pt[3], &pt[4], &pt[5]);
+    // tuning knobs AFESP_PP_SPLIT (K slices of the two pair products, 0 = the launcher's own choice) and
+    // AFESP_PP_TILES="tm,tn,split,tm,tn,split" (tile codes and K slices of the symmetric / the antisymmetric product)
+    const int* pt = knobs().pp_tiles;
     if (cx.rec) cx.rec->product(gp, s.pp_lds * np, ns * ks, ns * np);
     else if (p1 > p0) AFESP_HIP(gett_launch(gp, cx.ws, cx.stream, pt[2], pt[0], pt[1]));
     if (s.pp_pa) {

@@ -600,7 +600,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
             if (nbatch == 1 && !bA0 && !bB0 && !norepack) {
                 // (the other operand's free extent from which the copy pays: 256 -- a rank's 500-row slice of a ring product in a split
                 // iteration runs 0.52 ms from the operand as it lies, 0.29 + 0.07 from its copy; tuning knob AFESP_REPACK_MIN)
-                static const int64_t rp_min = [] { const char* e = getenv("AFESP_REPACK_MIN"); return e ? (int64_t)atoll(e) : (int64_t)256; }();
+                const int64_t rp_min = knobs().repack_min;
                 // (... or when the summation index is so long that both operands simply stream: gathered 8 bytes per line, a rank's
                 // slice of asym(m,i,e,f) <ef|ma> -> r1(i,a) ran at 0.9 TB/s -- 316 us for 288 MB)
                 int64_t Kd = 1;
@@ -656,8 +656,8 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
         // the six tables in one allocation (a plan per contraction site: ~45 of them in a CCSD iteration), each starting on a
         // 16-byte boundary; small ones are enumerated here and copied, big ones are written by the device
         {
-            const bool verify = getenv("AFESP_PLAN_VERIFY") != nullptr;   // tests: both builders, and the flags, must agree
-            const int64_t device_from = getenv("AFESP_PLAN_DEVICE_FROM") ? atoll(getenv("AFESP_PLAN_DEVICE_FROM")) : 32768;
+            const bool verify = knobs().plan_verify;   // tests: both builders, and the flags, must agree
+            const int64_t device_from = knobs().plan_device_from;
             int64_t** dst[6] = {&p.offAm, &p.offAk, &p.offBk, &p.offBn, &p.offCm, &p.offCn};
             size_t start[6], total = 0;
             for (int q = 0; q < 6; ++q) {
@@ -797,7 +797,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
         return;
     }
     // AFESP_CONTRACT_TRACE=1 (tools/contract_trace.py): every product alone on the device, its labels, extents and time on stderr
-    static const bool trace = getenv("AFESP_CONTRACT_TRACE") != nullptr;
+    const bool trace = knobs().contract_trace;
     // tall x skinny (one extent of C at most 32, K a few hundred: the products of t1 with a four-index array): streamed, tall.h
     const bool tall = !force_split && !force_tm && !force_tn && tall_eligible(g);
     ++(tall ? cx.n_tall : cx.n_gett);
@@ -825,7 +825,7 @@ void contract(Context& cx, double alpha, const Tensor& A0, const char* la0, cons
 
 void contract_pair(Context& cx, const ContractCall& c1, const ContractCall& c2)
 {
-    static const bool trace = getenv("AFESP_CONTRACT_TRACE") != nullptr;
+    const bool trace = knobs().contract_trace;
     auto plain = [&](const ContractCall& c) { contract(cx, c.alpha, *c.A, c.la, *c.B, c.lb, c.beta, *c.C, c.lc); };
     if (cx.rec || trace) {
         plain(c1);

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "knobs.h"
+
 #include <atomic>
 #include <mutex>
 

@@ -107,7 +107,7 @@ inline bool fused_exec(Context& cx, FusedSlot& slot, Body body)
     // re-initialised after many different systems: compile again)
     if (slot.prog && fused_plan_epoch(slot.prog) != cx.plan_epoch) fused_slot_reset(cx, slot);
     if (!slot.prog) {
-        const bool dbg = getenv("AFESP_FUSED_DEBUG") != nullptr;
+        const bool dbg = knobs().fused_debug;
         const auto t0 = std::chrono::steady_clock::now();
         Recorder rec;
         cx.rec = &rec;
@@ -136,7 +136,7 @@ inline bool fused_exec(Context& cx, FusedSlot& slot, Body body)
         if (!slot.prog) {
             slot.disabled = true;
             slot.why = rec.why;
-            if (getenv("AFESP_FUSED_DEBUG")) fprintf(stderr, "afesp: not fused: %s\n", rec.why.c_str());
+            if (knobs().fused_debug) fprintf(stderr, "afesp: not fused: %s\n", rec.why.c_str());
             return false;
         }
     }

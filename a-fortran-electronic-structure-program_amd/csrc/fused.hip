@@ -251,7 +251,7 @@ void Recorder::product(const GettProblem& g, int64_t a_span, int64_t b_span, int
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return fail("empty product");
     // A product with real work in it keeps the tiled kernel of its own (gett.h: LDS-staged 16-byte gathers, a launch of tens of
     // microseconds anyway); it takes its place in the levelled sequence as a kernel launched as it is.
-    static const double big = [] { const char* e = getenv("AFESP_FUSED_BIG_FLOP"); return e ? atof(e) : 4e8; }();
+    const double big = knobs().fused_big_flop;
     if (2.0 * g.M * (double)g.N * g.K >= big || a_span >= ((int64_t)1 << 28) || b_span >= ((int64_t)1 << 28) || c_span >= ((int64_t)1 << 28)) {
         std::vector<FusedRange> rd = {frange(g.A, a_span), frange(g.B, b_span)};
         if (g.beta != 0.0) rd.push_back(frange(g.C, c_span));
@@ -360,7 +360,7 @@ TileKind pick_tile(int M, int N)
 
 bool fused_enabled(const Context& cx)
 {
-    static const bool on = [] { const char* e = getenv("AFESP_FUSED"); return !(e && e[0] == '0'); }();
+    const bool on = knobs().fused;
     return cx.fused_mode >= 0 ? cx.fused_mode == 1 : on;
 }
 
@@ -382,7 +382,7 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
     cx.plan_uploads_issue();   // (whatever becomes of the program: the plans stay in the context and need their tables)
     if (r.failed) return nullptr;
     auto& ops = r.ops;
-    const bool debug = getenv("AFESP_FUSED_DEBUG") != nullptr;
+    const bool debug = knobs().fused_debug;
     // ---- levels: products on odd stages (their sums are complete one stage later), everything else on even ones
     int nstage = 0;
     for (size_t x = 0; x < ops.size(); ++x) {
@@ -442,11 +442,11 @@ FusedProgram* fused_compile(Context& cx, Recorder& r)
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cx.device) == hipSuccess && v > 0) ncu = v;
     }
-    auto envll = [](const char* name, int64_t dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; };
-    const int64_t target_items = envll("AFESP_FUSED_ITEMS", (int64_t)ncu * 8);
-    const int64_t min_steps = envll("AFESP_FUSED_MIN_STEPS", 8), max_mfma = envll("AFESP_FUSED_MAX_MFMA", 128);
-    const int nb_code = envll("AFESP_FUSED_NB", 4) == 2 ? 4 : 0;
-    const bool per_op = getenv("AFESP_FUSED_PER_OP") != nullptr;
+    // (tuning knobs AFESP_FUSED_ITEMS / _MIN_STEPS / _MAX_MFMA / _NB, knobs.h)
+    const int64_t target_items = knobs().fused_items > 0 ? knobs().fused_items : (int64_t)ncu * 8;
+    const int64_t min_steps = knobs().fused_min_steps, max_mfma = knobs().fused_max_mfma;
+    const int nb_code = knobs().fused_nb == 2 ? 4 : 0;
+    const bool per_op = knobs().fused_per_op;
     std::vector<int> slices(ops.size(), 0), tilecode(ops.size(), 0);
     std::vector<int64_t> slicelen(ops.size(), 0);
     std::vector<std::vector<size_t>> stage_ops((size_t)nstage);   // product ops of a stage
@@ -684,7 +684,7 @@ void fused_run(Context& cx, const FusedProgram* P)
             // The products that keep a tiled launch of their own are independent inside a stage, and at the sizes where they occur
             // (o ~ 10, v ~ 100) none of them fills the device: they run side by side on the context's lanes (each lane with a
             // split-K workspace of its own), the main stream waits for all of them.  AFESP_FUSED_LANES=0: one after the other.
-            static const bool lanes_on = !(getenv("AFESP_FUSED_LANES") && getenv("AFESP_FUSED_LANES")[0] == '0');
+            const bool lanes_on = knobs().fused_lanes;
             if (st.heavy.size() >= 2 && lanes_on) {
                 const int nl = (int)std::min<size_t>(st.heavy.size(), 4);
                 cx.lane_ws_bytes = std::max(cx.lane_ws_bytes, (size_t)64 << 20);

@@ -669,9 +669,9 @@ extern int g_group_m, g_allow_wide;
 int g_group_m = 0;   // >0 overrides the tile-walk group size (tuning knob, see afesp_set_tuning)
 int g_force_tm = 0, g_force_tn = 0, g_force_split = 0, g_allow_wide = 1;
 // K is sliced when a product has fewer tiles than this (tuning knob AFESP_SPLIT_BELOW)
-static const int g_split_below = getenv("AFESP_SPLIT_BELOW") ? atoi(getenv("AFESP_SPLIT_BELOW")) : 192;
+#define g_split_below (knobs().split_below)
 // ... into slices of at least this many K steps (tuning knob AFESP_SPLIT_MIN_STEPS)
-static const int g_split_min_steps = getenv("AFESP_SPLIT_MIN_STEPS") ? std::max(1, atoi(getenv("AFESP_SPLIT_MIN_STEPS"))) : 4;
+#define g_split_min_steps (knobs().split_min_steps)
 
 // Block tile extent (rows or columns) for a requested code: 1 -> 32, 2 -> 64, 4 -> 128; 8 = 128 with 8 waves.
 static int pick_t(int extent)
@@ -783,7 +783,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
     // Stream-K (gett_kernel, SK) for the 256 x 112 / 96 tiles where the slices chosen above leave a round of the device partly idle:
     // every workgroup the same U consecutive K steps of the tiles' sequence, U below a tile's length; the pieces of a tile -- ceil(steps / U)
     // of them, one more where the sequence is cut inside its first U steps -- meet in the slabs of the split-K workspace.
-    static const bool sk_off = getenv("AFESP_GETT_SK") && getenv("AFESP_GETT_SK")[0] == '0';
+    const bool sk_off = !knobs().gett_sk;
     bool sk = false;
     if (!sk_off && tm == 16 && (tn == 6 || tn == 7) && wide && p.nbatch == 1 && force_split == 0 && a.ksplit > 1 && ksteps >= 64 && ws.ptr) {
         const int wgs = 256;   // (one 8-wave workgroup per CU)
@@ -810,7 +810,7 @@ hipError_t gett_launch(const GettProblem& p, const GettWorkspace& ws, hipStream_
             if (me != hipSuccess) return me;
         }
     }
-    static const bool gett_debug = getenv("AFESP_GETT_DEBUG") != nullptr;   // every launch: extents, tile codes, K slices
+    const bool gett_debug = knobs().gett_debug;   // every launch: extents, tile codes, K slices
     if (gett_debug)
         fprintf(stderr, "gett_launch M %d N %d K %d batch %d akc %d bkc %d wide %d -> tm %d tn %d tiles %d x %d split %d (steps per slice %d)\n", p.M, p.N, p.K,
                 p.nbatch, (int)p.a_kcontig, (int)p.b_kcontig, (int)wide, tm, tn, a.mtiles, a.ntiles, a.ksplit, a.kchunk / BK);

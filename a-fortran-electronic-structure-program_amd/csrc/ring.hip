@@ -66,10 +66,8 @@ __global__ __launch_bounds__(256) void ring_tables_kernel(uint32_t* rc32, int64_
 // 8 Kc o v < 4 GiB.
 bool ring_tg_applies(const CCState& s)
 {
-    const char* e = getenv("AFESP_RING_TG");
-    if (e && e[0] == '0') return false;
-    const char* m = getenv("AFESP_RING_TG_MIN");
-    const int64_t min_ov = m ? (int64_t)atoll(m) : (int64_t)3584;
+    if (!knobs().ring_tg) return false;
+    const int64_t min_ov = knobs().ring_tg_min;
     const int64_t ov = (int64_t)s.o * s.v, Kc = (ov + TG_BK - 1) / TG_BK * TG_BK;
     return !s.sharded && ov >= min_ov && ov >= 2 * TG_BK && 8 * Kc * ov < ((int64_t)1 << 32) - 4096;
 }
@@ -225,7 +223,7 @@ static Tensor kview(const RingTg* r, double* buf, const CCState& s, int pos_m, i
 // extents (the o^2 block of one (p,q) does not fit the LDS) -- the caller runs k_asym_c
 bool ring_tg_pack(Context& cx, CCState& s)
 {
-    static const bool off = getenv("AFESP_RING_PACK") && getenv("AFESP_RING_PACK")[0] == '0';
+    const bool off = !knobs().ring_pack;
     const int64_t oo = (int64_t)s.o * s.o;
     if (off || oo * 8 > 65536 || oo >= 65536 / 4) return false;
     RingTg* r = ring_get(cx, s);

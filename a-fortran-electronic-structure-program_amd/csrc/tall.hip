@@ -227,14 +227,13 @@ static size_t tall_lds_bytes(int K, int S)
 
 bool tall_eligible(const GettProblem& p)
 {
-    static const bool off = [] { const char* e = getenv("AFESP_TALL"); return e && e[0] == '0'; }();
+    const bool off = !knobs().tall;
     if (off || p.nbatch != 1 || p.batchA || p.batchB || p.batchC) return false;
     const int64_t S = std::min(p.M, p.N), T = std::max(p.M, p.N);
     // The lanes of a load are 16 values of t in C's order: they touch whole lines when the tall operand is contiguous along k or
     // along that order of t.  A product that transposes its tall operand (t(j,e) <mb|ie> -> (i,j,m,b): 166 us here against 78
     // through the gather kernel's LDS image) stays with gett_kernel; below ~10^5 rows the two are level (AFESP_TALL_MIN).
-    const char* e = getenv("AFESP_TALL_MIN");
-    const int64_t tmin = e ? (int64_t)atof(e) : (int64_t)1 << 17;
+    const int64_t tmin = knobs().tall_min;
     const bool tall_n = p.N > p.M;
     const bool coalesced = tall_n ? (p.b_kcontig || p.b_nunit) : (p.a_kcontig || p.a_munit);
     if (S < 1 || S > 32 || T < tmin || T < 64 * S || p.K < 16 || !coalesced) return false;
@@ -320,7 +319,7 @@ static size_t tall_dual_lds_bytes(int K, int S)
 
 bool tall_dual_eligible(const GettProblem& p1, const GettProblem& p2)
 {
-    static const bool off = [] { const char* e = getenv("AFESP_TALL_DUAL"); return e && e[0] == '0'; }();
+    const bool off = !knobs().tall_dual;
     if (off || !tall_eligible(p1) || !tall_eligible(p2)) return false;
     const bool n1 = p1.N > p1.M, n2 = p2.N > p2.M;
     if (n1 == n2) return false;   // one product with C's lanes along the skinny index, one along the tall one

@@ -559,7 +559,7 @@ int tgemm_group_m(int M, int max_ntiles, int bm)
 {
     const int mtiles = (M + bm - 1) / bm;
     if (mtiles <= 4) return mtiles;   // few rows: the m-tiles of a column tile side by side (they share its B lines)
-    static const int patch = getenv("AFESP_TG_PATCH") ? atoi(getenv("AFESP_TG_PATCH")) : 64;   // tuning knob: tiles per patch
+    const int patch = knobs().tg_patch;   // tuning knob AFESP_TG_PATCH: tiles per patch
     return std::min(mtiles, std::max(1, (patch + max_ntiles / 2) / std::max(1, max_ntiles)));
 }
 
@@ -600,18 +600,17 @@ hipError_t tgemm_launch(const TgProblem& p, const TgGroup* dev_groups, int ngrou
     a.bm = mixed ? bm : TG_BM;
     a.mtiles = (p.M + a.bm - 1) / a.bm;
     a.total_tiles = total_tiles;
-    static const int dbg_env = getenv("AFESP_TG_DBG") ? atoi(getenv("AFESP_TG_DBG")) : 0;
-    a.dbg = dbg_env;
+    a.dbg = knobs().tg_dbg;
     a.gm = tgemm_group_m(p.M, max_ntiles, a.bm);
     a.inv_gm = tgemm_inverse(a.gm);
     a.inv_gl = tgemm_inverse(std::max(1, a.mtiles % a.gm));
-    static const int grid_env = getenv("AFESP_TG_GRID") ? atoi(getenv("AFESP_TG_GRID")) : 0;   // diagnostic: fewer workgroups, longer tile streams
+    const int grid_env = knobs().tg_grid;   // diagnostic AFESP_TG_GRID: fewer workgroups, longer tile streams
     const unsigned grid = (unsigned)std::min(total_tiles, grid_env > 0 ? grid_env : cap);
     // tickets: launches of many rounds of tiles whose grid splits evenly over the XCDs (AFESP_TG_DYNAMIC=0: always static)
-    static const int prio_env = getenv("AFESP_TG_PRIO_SHIFT") ? atoi(getenv("AFESP_TG_PRIO_SHIFT")) : 11;   // 2^11 x 10 ns = 20 us slices
+    const int prio_env = knobs().tg_prio_shift;   // AFESP_TG_PRIO_SHIFT: 2^11 x 10 ns = 20 us slices
     a.prio_shift = (int64_t)total_tiles >= (int64_t)2 * grid ? prio_env : 0;
-    static const bool dyn_env = !(getenv("AFESP_TG_DYNAMIC") && getenv("AFESP_TG_DYNAMIC")[0] == '0');
-    static const bool dyn_force = getenv("AFESP_TG_DYNAMIC") && getenv("AFESP_TG_DYNAMIC")[0] == '2';   // tests: also for small launches
+    const bool dyn_env = knobs().tg_dynamic != 0;
+    const bool dyn_force = knobs().tg_dynamic == 2;   // AFESP_TG_DYNAMIC=2 (tests): also for small launches
     a.tickets = nullptr;
     a.chunk = (int)(grid / 8);
     a.inv_chunk = tgemm_inverse(a.chunk);

@@ -477,7 +477,7 @@ static int fused_block_size(int o, int v, bool cr, int64_t budget_bytes)
     // launches; from about 900 columns on neither matters any more (config 5: s = 5, 7 -> 506.8, 506.0 ms; s = 4 -> 549), while
     // the pool grows with s^3 -- and every byte allocated for the first time costs on this runtime.  So: the
     // smallest size with >= 900 columns per group, or one of the next two if it fills its column tiles more than 2 % better.
-    if (const char* e = getenv("AFESP_T_BLOCK")) return std::max(1, std::min(smax, atoi(e)));   // tuning knob
+    if (knobs().t_block > 0) return std::max(1, std::min(smax, knobs().t_block));   // tuning knob AFESP_T_BLOCK
     const int smin = std::min(smax, std::max(1, (900 + v - 1) / v));
     auto fill = [&](int sz) { return (double)((int64_t)v * sz) / (double)((((int64_t)v * sz + 127) / 128) * 128); };
     int best = smin;
@@ -490,8 +490,7 @@ static int64_t device_pool_budget()
 {
     size_t mem_free = 0, mem_total = 0;
     AFESP_HIP(hipMemGetInfo(&mem_free, &mem_total));
-    const char* e = getenv("AFESP_T_POOL_GIB");   // tuning knob
-    if (e) return (int64_t)atoll(e) << 30;
+    if (knobs().t_pool_gib >= 0) return knobs().t_pool_gib << 30;   // tuning knob AFESP_T_POOL_GIB
     // upper limit of one pool: a quarter of the device, 64 GiB at most (fused_block_size normally stays well below it: 24 GB at
     // config 5)
     return std::min<int64_t>((int64_t)64 << 30, (int64_t)(mem_total / 4));
@@ -501,8 +500,7 @@ static int64_t device_pool_budget()
 // and every column of tt; AFESP_T_GEMM=gett forces the grouped gather kernel (A/B runs, tests of both).
 static bool fused_use_tg(int o, int v)
 {
-    const char* e = getenv("AFESP_T_GEMM");
-    if (e && !strcmp(e, "gett")) return false;
+    if (knobs().t_gemm_gett) return false;
     const int64_t O = o, V = v, Kc = (V + O + 15) / 16 * 16;
     return 8 * Kc * V * V < ((int64_t)1 << 32) && 8 * Kc * V * O * O < ((int64_t)1 << 32);
 }
@@ -543,8 +541,7 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
     int tm, tn, BM, BN;
     gett_grouped_tile((int)v2, true, &tm, &tn, &BM, &BN);
     const int mtiles = (int)((v2 + BM - 1) / BM);
-    const char* split_env = getenv("AFESP_T_SPLIT_TILES");   // test / tuning knob, read when a plan is built
-    const int64_t split_min_tiles = split_env ? atoll(split_env) : 1024;
+    const int64_t split_min_tiles = knobs().t_split_tiles;   // test / tuning knob AFESP_T_SPLIT_TILES, read when a plan is built
     // first pass: the largest number of distinct blocks Y^{p;qr} of one block triple inside the requested range = the pool size
     {
         int64_t fl = 0;
@@ -580,7 +577,7 @@ static TriplesPlan* plan_fused(Context& cx, void*& slot, int o, int v, int64_t t
         }
     }
     std::vector<int64_t> blk_off;
-    if (cr || getenv("AFESP_T_ONE_POOL")) {
+    if (cr || knobs().t_one_pool) {
         for (int64_t b = 0; b < max_blocks; ++b) blk_off.push_back(b * vp3);
         p->pool0 = nullptr;
     } else {
@@ -835,8 +832,7 @@ void triples_shard_bounds(int o, int v, bool cr, int world, int64_t* bounds)
     int tm, tn, BM, BN;
     gett_grouped_tile((int)(V * V), true, &tm, &tn, &BM, &BN);
     const int sb = fused_block_size(o, v, cr, device_pool_budget());
-    const char* split_env = getenv("AFESP_T_SPLIT_TILES");
-    const int64_t split_min_tiles = split_env ? atoll(split_env) : 1024;
+    const int64_t split_min_tiles = knobs().t_split_tiles;
     auto cost = [&](int64_t b, int64_t e) { return fused_range_cost(o, v, sb, b, e, BM, BN, split_min_tiles); };
     bounds[0] = 0;
     // A small system is launch-bound: a single triple already costs about as much as the whole list (the estimate's floor of
@@ -882,7 +878,7 @@ void ccsd_triples(Context& cx, CCState& s, int64_t t_begin, int64_t t_end, doubl
     t_begin = std::max<int64_t>(0, t_begin);
     t_end = std::min<int64_t>(triples_count(o), t_end);
     TriplesPlan* p = plan_fused(cx, s.tplan, s.o, s.v, t_begin, t_end, cr);
-    if (getenv("AFESP_T_DEBUG"))
+    if (knobs().t_debug)
         fprintf(stderr, "afesp (T): o %d v %d block %d chunks %zu kernel %s\n", o, v, p->sblock, p->chunks.size(), p->use_tg ? "tgemm" : "gett");
     // concatenated operands, summed index kappa = [d ; l] first (the reference also moves the summed index first, :2056-2066)
     //   vt(kappa,b,c,k): kappa<v: <cb|kd> = v_vvov(c,b,k,d);  kappa=v+l: t2(l,k,b,c)

@@ -16,6 +16,23 @@
  *   - every function returns 0 on success; non-zero -> afesp_last_error(ctx) (the Fortran host maps it to error(),
  *     src/error_handling.f90:7-20).  Without a usable GPU afesp_ctx_create fails: there is no CPU fallback.
  *   - extents are int64_t / int (the reference's int32 packed-index limit n<=99, src/integrals.f90:21, is lifted)
+ *
+ * Environment variables.  The library needs none.  Every AFESP_* variable it understands is defined, with its default, in ONE
+ * place -- csrc/knobs.h -- and follows the environment at the granularity of one call of this header (re-read at the top of every
+ * entry point; never in the middle of one).  Three kinds:
+ *   TEST-ONLY path selectors (they choose which kernels evaluate a quantity; results agree to ~1e-13 but summation orders differ --
+ *     tests use them to send a small system down a large system's path or to hold two forms of one product against each other; not
+ *     for production use):  AFESP_SMALL_MAX, AFESP_NO_LANES, AFESP_FUSED, AFESP_FUSED_LANES, AFESP_PP_SYM, AFESP_RING_TG,
+ *     AFESP_RING_TG_MIN, AFESP_RING_PACK, AFESP_LARGE_TAIL, AFESP_TALL, AFESP_TALL_MIN, AFESP_TALL_DUAL, AFESP_GETT_SK, AFESP_T_GEMM,
+ *     AFESP_T_ONE_POOL, AFESP_CC_REINIT, AFESP_CC_SHARD, AFESP_CC_TIME_SLICE, AFESP_AO2MO_TG, AFESP_AO2MO_PAIR, AFESP_AO2MO_MIXED,
+ *     AFESP_AO2MO_BLOCKED, AFESP_MP2_PACKED, AFESP_NO_GRAPH, AFESP_GRAPH_AFTER, AFESP_NO_PRELOAD, AFESP_PRELOAD_LANES,
+ *     AFESP_PRELOAD_GETT, AFESP_PLAN_VERIFY
+ *   tuning (tile / slice / pool sizes, scheduling):  AFESP_PP_SPLIT, AFESP_PP_TILES, AFESP_REPACK_MIN, AFESP_PLAN_DEVICE_FROM,
+ *     AFESP_FUSED_BIG_FLOP, AFESP_FUSED_ITEMS, AFESP_FUSED_MIN_STEPS, AFESP_FUSED_MAX_MFMA, AFESP_FUSED_NB, AFESP_SPLIT_BELOW,
+ *     AFESP_SPLIT_MIN_STEPS, AFESP_TG_PATCH, AFESP_TG_GRID, AFESP_TG_PRIO_SHIFT, AFESP_TG_DYNAMIC, AFESP_T_BLOCK, AFESP_T_POOL_GIB,
+ *     AFESP_T_SPLIT_TILES
+ *   diagnostics (printing, measurement; no effect on results):  AFESP_TG_DBG, AFESP_GRAPH_DEBUG, AFESP_PRELOAD_DEBUG,
+ *     AFESP_FUSED_DEBUG, AFESP_FUSED_PER_OP, AFESP_GETT_DEBUG, AFESP_T_DEBUG, AFESP_CONTRACT_TRACE, AFESP_STAMPS_GROUPED
  */
 #ifndef AFESP_H
 #define AFESP_H

@@ -40,7 +40,7 @@ def main():
     worst = {}
 
     def check(name, got, ref, tol=1e-10):
-        err = float(np.max(np.abs(got - ref)) / max(1.0, float(np.max(np.abs(ref)))))
+        err = float(np.max(np.abs(got - ref)) / float(np.max(np.abs(ref))))   # relative to the tensor's largest element
         worst[name] = err
         print(f"  {name:10s} max rel err {err:.2e}  (max |ref| {np.max(np.abs(ref)):.3e})", flush=True)
         assert err < tol, (name, err)
@@ -78,9 +78,9 @@ def main():
         rba = np_cc.r2_cols(t1, t2, I, oovv, ovov, vvov, vvvv(b, a), b, a)
         sym_ref = rab + rba.T
         sym_dev = r2d[:, :, a, b] + r2d[:, :, b, a].T   # (a term may sit in its image under (i<->j, a<->b): only the sum is defined)
-        e_r2 = max(e_r2, float(np.max(np.abs(sym_dev - sym_ref)) / max(1.0, float(np.max(np.abs(sym_ref))))))
+        e_r2 = max(e_r2, float(np.max(np.abs(sym_dev - sym_ref)) / float(np.max(np.abs(sym_ref)))))
         tn = np_cc.new_t2_cols(rab, rba, oovv, D2, a, b)
-        e_t2 = max(e_t2, float(np.max(np.abs(t2n[:, :, a, b] - tn)) / max(1.0, float(np.max(np.abs(tn))))))
+        e_t2 = max(e_t2, float(np.max(np.abs(t2n[:, :, a, b] - tn)) / float(np.max(np.abs(tn)))))
     print(f"  r2 + image on {len(pairs)} column pairs: max rel err {e_r2:.2e};  updated t2 there: {e_t2:.2e}", flush=True)
     assert e_r2 < 1e-10 and e_t2 < 1e-10
     sym = float(np.max(np.abs(t2n - t2n.transpose(1, 0, 3, 2))))
