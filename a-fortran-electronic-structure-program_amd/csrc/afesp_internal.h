@@ -270,19 +270,21 @@ void k_lincomb_vals(Context& cx, double* out, const double* xbase, int64_t xstri
 constexpr int DIIS_FLAG_SLOT = 48;   // cx.scal[48]: set by diis_solve_kernel when the solve fails, read with the energies
 void diis_check_flag(Context& cx, const double* host_scal);   // throws the reference's error (ccsd.f90:666) if it is set
 // pair-symmetric AO->MO: u(i,j,KL) from the packed array; out(k,l,PQ) = in(q,p,tri(k,l)); packed[tri(PQ,RS)] = full(s,r,PQ)
-void k_unpack_half(Context& cx, double* u, const double* packed, int n, int64_t c_begin = 0, int64_t c_end = -1);   // slab of (kl) pairs
-void k_pair_transpose(Context& cx, double* out, const double* in, int n);
+// (ld: leading dimension of the squared-up arrays, 0 = n; the LDS-DMA transforms pad it to whole K steps -- kernels.hip, pair_square_kernel)
+void k_unpack_half(Context& cx, double* u, const double* packed, int n, int64_t c_begin = 0, int64_t c_end = -1, int ld = 0);   // slab of (kl) pairs
+void k_pair_transpose(Context& cx, double* out, const double* in, int n, int ld = 0);
+void k_pad_rows_zero(Context& cx, double* x, int n, int ld, int64_t ncol);   // x(n .. ld - 1, c) = 0 for every column c
 // out(:,:,S) = C in(:,:,S) C^T for npairs symmetric n x n blocks, n <= 64: both quarter transforms of a pair index in one launch
 void k_pair_xform(Context& cx, double* out, const double* in, const double* C, int n, int64_t npairs, int mode = 0);   // modes: kernels.hip
 void k_square_transpose(Context& cx, double* out, const double* in, int64_t n);                                        // out(y, x) = in(x, y)
 void k_pair_square_packed(Context& cx, double* out, const double* g, int n, int64_t c_begin, int64_t c_end);   // out(k,l,P) = g(P, tri(k,l))
 void k_tri_pack(Context& cx, double* g, const double* half, int n, int64_t k_begin, int64_t k_end);           // g(PQ,K) = half(q,p,K)
-void k_pack_pairs(Context& cx, double* packed, const double* full, int n, int64_t p_begin = 0, int64_t p_end = -1);
+void k_pack_pairs(Context& cx, double* packed, const double* full, int n, int64_t p_begin = 0, int64_t p_end = -1, int ld = 0);
 // out(p,q,r,s) = packed[ index( (p+b0)(r+b2) | (q+b1)(s+b3) ) ]  physicist <pq|rs> from packed chemist (pr|qs)
 void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1, int d2, int d3, int b0, int b1, int b2,
                   int b3);
 // Fock matrix from the half-unpacked integrals u(x,y,P) (k_unpack_half); work holds k_build_fock_work(n) doubles
-void k_build_fock(Context& cx, double* fock, const double* hcore, const double* dens, const double* u, double* work, int n);
+void k_build_fock(Context& cx, double* fock, const double* hcore, const double* dens, const double* u, double* work, int n, int ld = 0);
 int64_t k_build_fock_work(int n);
 double* host_scalars(Context& cx, int n);
 double* host_scalars_slot(Context& cx, double* seq);          // a kernel of the caller publishes itself (contract.hip); nullptr: use host_scalars

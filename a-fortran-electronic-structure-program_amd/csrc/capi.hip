@@ -56,7 +56,10 @@ struct afesp_ctx {
         fused_slot_reset(cx, fused_iter);
     }
     void so_programs_reset() { fused_slot_reset(cx, fused_so); }
-    int64_t half_n = 0, half_epoch = -1;   // scratch "ao2mo_a" holds the half-unpacked AO integrals of this basis size / epoch
+    // the LDS-DMA transforms' temporaries whose padding rows are known to be zero (afesp_ao2mo_mp2): buffers, extents, scratch epoch
+    const double *pad_a = nullptr, *pad_b = nullptr;
+    int64_t pad_n = 0, pad_ld = 0, pad_epoch = -1;
+    int64_t half_n = 0, half_ld = 0, half_epoch = -1;   // scratch "ao2mo_a" holds the half-unpacked AO integrals of this basis size / leading dimension / epoch
 };
 
 namespace {
@@ -342,6 +345,24 @@ void afesp_ctx_destroy(afesp_ctx* ctx)
 
 const char* afesp_last_error(const afesp_ctx* ctx) { return ctx ? ctx->cx.last_error.c_str() : "null context"; }
 
+// Which form afesp_ao2mo_mp2 takes for basis size n, and the leading dimension of the squared-up temporaries that goes with it (the
+// half-unpacked AO integrals afesp_build_fock leaves for it included): the transforms on the LDS-DMA GEMM keep columns of
+// 16 ceil(n / 16) doubles -- every column then starts on a 128-byte line, for the GEMM's K steps and for the layout kernels' runs alike
+// (n = 220: 39.2 -> 36 ms per transform; n = 224 ran FASTER than n = 220 before, profiles/r06_ao2mo_alignment_scan.txt) -- every other
+// form keeps n.
+static bool ao2mo_blocked(int64_t n)
+{
+    const int64_t np = n * (n + 1) / 2;
+    return knobs().ao2mo_blocked >= 0 ? knobs().ao2mo_blocked == 1 : n * n * np >= ((int64_t)1 << 31);
+}
+static bool ao2mo_use_tg(int64_t n)
+{
+    // the LDS-DMA GEMM: even n, and from n = 96 on (its tile has 128 rows: below that most of a tile is padding and the transform is
+    // launch-bound anyway); AFESP_AO2MO_TG=0 / 1: never / for every even n >= 16 (tests, A/B runs)
+    return !ao2mo_blocked(n) && n % 2 == 0 && n >= 16 && (knobs().ao2mo_tg >= 0 ? knobs().ao2mo_tg == 1 : n >= 96);
+}
+static int64_t ao2mo_ld(int64_t n) { return ao2mo_use_tg(n) && knobs().ao2mo_pad ? (n + 15) / 16 * 16 : n; }
+
 // ---- a quarter transform on the LDS-DMA GEMM (tgemm.h): out(x2, m, S) = sum_x1 C(m, x1) in(x1, x2, S)
 // The transformed index is the fastest one of `in`, so every column (x2, S) of the product is a contiguous run of n doubles: both
 // operands are contiguous along the summation index (C goes in as a zero-padded transpose), which is all that kernel asks for.
@@ -355,14 +376,15 @@ __global__ __launch_bounds__(256) void ao2mo_ct_kernel(double* ct, const double*
     }
 }
 // rowA[m] = byte offset of row m of the padded transpose; colB[c] = byte offset of column c = x2 + n Sloc of a slab of `in`;
-// offCm[m] = n m; offCn[c] = x2 + n^2 Sloc (elements); the pads behind them (tgemm.h) are zero
-__global__ __launch_bounds__(256) void ao2mo_tables_kernel(uint32_t* rowA, uint32_t* colB, int64_t* offCm, int64_t* offCn, int n, int Kc, int64_t ncol)
+// offCm[m] = ld m; offCn[c] = x2 + ld n Sloc (elements); the pads behind them (tgemm.h) are zero.
+// ld: the temporaries' columns are ld doubles long (n of them data, the rest zero): ld = Kc puts every column on a 128-byte line
+__global__ __launch_bounds__(256) void ao2mo_tables_kernel(uint32_t* rowA, uint32_t* colB, int64_t* offCm, int64_t* offCn, int n, int Kc, int64_t ncol, int64_t ld)
 {
     for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < ncol + 256; x += (int64_t)gridDim.x * blockDim.x) {
         if (x < n + 256) rowA[x] = x < n ? (uint32_t)(8 * Kc * x) : 0u;
-        if (x < n + 128) offCm[x] = x < n ? (int64_t)n * x : 0;
-        colB[x] = x < ncol ? (uint32_t)(8 * (int64_t)n * x) : 0u;
-        if (x < ncol + 128) offCn[x] = x < ncol ? (x % n) + (int64_t)n * n * (x / n) : 0;
+        if (x < n + 128) offCm[x] = x < n ? ld * x : 0;
+        colB[x] = x < ncol ? (uint32_t)(8 * ld * x) : 0u;
+        if (x < ncol + 128) offCn[x] = x < ncol ? (x % n) + ld * n * (x / n) : 0;
     }
 }
 
@@ -370,31 +392,32 @@ __global__ __launch_bounds__(256) void ao2mo_tables_kernel(uint32_t* rowA, uint3
 // last transform therefore runs over the columns (r, PQ) with r <= p only -- p + 1 of them per pair PQ = tri(p, q), rounded up to
 // an even count (pairs of columns are stored together) -- about half of all: colB / offCn list them pair by pair, relative to
 // the pair's slab (cstart[PQ] = first column of the pair).
-__global__ __launch_bounds__(256) void ao2mo_tables_tri_kernel(uint32_t* colB, int64_t* offCn, const int64_t* cstart, int n, int64_t np, int64_t sl)
+__global__ __launch_bounds__(256) void ao2mo_tables_tri_kernel(uint32_t* colB, int64_t* offCn, const int64_t* cstart, int n, int64_t np, int64_t sl, int64_t ld)
 {
     for (int64_t P = blockIdx.x; P < np; P += gridDim.x) {
         const int64_t c0 = cstart[P], cnt = cstart[P + 1] - c0, rel = P % sl;
         for (int64_t r = threadIdx.x; r < cnt; r += blockDim.x) {
-            colB[c0 + r] = (uint32_t)(8 * (int64_t)n * (r + (int64_t)n * rel));
-            offCn[c0 + r] = r + (int64_t)n * n * rel;
+            colB[c0 + r] = (uint32_t)(8 * ld * (r + (int64_t)n * rel));
+            offCn[c0 + r] = r + ld * n * rel;
         }
     }
 }
 
 // columns (x2, S) with x2 < TG_BM only (the pair transposition behind the second transform reads its result (x2, m, S) for
 // x2 <= m only: the rows m < 128 are needed for these columns only), relative to a slab: column c = x2 + 128 Sloc
-__global__ __launch_bounds__(256) void ao2mo_tables_lo_kernel(uint32_t* colB, int64_t* offCn, int n, int cnt, int64_t ncol)
+__global__ __launch_bounds__(256) void ao2mo_tables_lo_kernel(uint32_t* colB, int64_t* offCn, int n, int cnt, int64_t ncol, int64_t ld)
 {
     for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < ncol + 256; x += (int64_t)gridDim.x * blockDim.x) {
         const int64_t x2 = x % cnt, sloc = x / cnt;
-        colB[x] = x < ncol ? (uint32_t)(8 * (int64_t)n * (x2 + (int64_t)n * sloc)) : 0u;
-        if (x < ncol + 128) offCn[x] = x < ncol ? x2 + (int64_t)n * n * sloc : 0;
+        colB[x] = x < ncol ? (uint32_t)(8 * ld * (x2 + (int64_t)n * sloc)) : 0u;
+        if (x < ncol + 128) offCn[x] = x < ncol ? x2 + ld * n * sloc : 0;
     }
 }
 
 namespace {
 struct Ao2moTg {
     int64_t n = 0, Kc = 0, sl = 0;   // basis size, padded summation length, (S) pairs per slab (one TgGroup each)
+    int64_t ld = 0;                  // leading dimension of the temporaries: Kc (ao2mo_ld), or n
     double* ct = nullptr;
     uint32_t *rowA = nullptr, *colB = nullptr;
     int64_t *offCm = nullptr, *offCn = nullptr;
@@ -411,13 +434,14 @@ struct Ao2moTg {
 };
 
 // tables and the padded transpose of the coefficient matrix for basis size n (cached scratch: rebuilt per call, microseconds)
-static Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_t np)
+static Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_t np, int64_t ld)
 {
     Ao2moTg t;
     t.n = n;
+    t.ld = ld;
     t.Kc = (n + 15) / 16 * 16;
     // a slab's columns are addressed with 32-bit byte offsets: n * sl columns of n doubles each below 4 GiB
-    t.sl = std::min<int64_t>(np, std::min<int64_t>(8192, (((int64_t)1 << 32) - 4096) / (8 * n * n)));
+    t.sl = std::min<int64_t>(np, std::min<int64_t>(8192, (((int64_t)1 << 32) - 4096) / (8 * t.ld * n)));
     const int64_t ncol = n * t.sl;
     t.ct = cx.scratch("ao2mo_ct", n * t.Kc);
     t.rowA = (uint32_t*)cx.scratch("ao2mo_t32", (n + 256 + ncol + 256) / 2 + 2);
@@ -427,7 +451,7 @@ static Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_
     AFESP_KLAUNCH(ao2mo_ct_kernel, dim3((unsigned)((n * t.Kc + 255) / 256)), dim3(256), 0, cx.stream, t.ct, Cm, (int)n, (int)t.Kc);
     AFESP_HIP(hipGetLastError());
     AFESP_KLAUNCH(ao2mo_tables_kernel, dim3((unsigned)std::min<int64_t>((ncol + 256 + 255) / 256, 65536)), dim3(256), 0, cx.stream, t.rowA,
-                       t.colB, t.offCm, t.offCn, (int)n, (int)t.Kc, ncol);
+                       t.colB, t.offCm, t.offCn, (int)n, (int)t.Kc, ncol, t.ld);
     AFESP_HIP(hipGetLastError());
     const int64_t ng = (np + t.sl - 1) / t.sl;
     t.groups_cap = 8 * (ng + 2);
@@ -445,14 +469,14 @@ static Ao2moTg ao2mo_tg_prepare(Context& cx, const double* Cm, int64_t n, int64_
     AFESP_HIP(hipMemsetAsync(t.colB_tri + ctot, 0, 256 * sizeof(uint32_t), cx.stream));
     AFESP_HIP(hipMemsetAsync(t.offCn_tri + ctot, 0, 128 * sizeof(int64_t), cx.stream));
     AFESP_KLAUNCH(ao2mo_tables_tri_kernel, dim3((unsigned)std::min<int64_t>(np, 65536)), dim3(256), 0, cx.stream, t.colB_tri, t.offCn_tri,
-                       cs_dev, (int)n, np, t.sl);
+                       cs_dev, (int)n, np, t.sl, t.ld);
     AFESP_HIP(hipGetLastError());
     if (n > TG_BM) {
         const int64_t nlo = (int64_t)TG_BM * t.sl;
         t.colB_lo = (uint32_t*)cx.scratch("ao2mo_t32h", (nlo + 256) / 2 + 2);
         t.offCn_lo = (int64_t*)cx.scratch("ao2mo_t64h", nlo + 128 + 2);
         AFESP_KLAUNCH(ao2mo_tables_lo_kernel, dim3((unsigned)std::min<int64_t>((nlo + 256 + 255) / 256, 65536)), dim3(256), 0, cx.stream,
-                           t.colB_lo, t.offCn_lo, (int)n, (int)TG_BM, nlo);
+                           t.colB_lo, t.offCn_lo, (int)n, (int)TG_BM, nlo, t.ld);
         AFESP_HIP(hipGetLastError());
     }
     return t;
@@ -481,8 +505,8 @@ static void ao2mo_tg_xform(Context& cx, Ao2moTg& t, const double* in, double* ou
         const int64_t s0 = std::max(s_begin, g * t.sl), s1 = std::min(s_end, (g + 1) * t.sl);
         TgGroup d{};
         d.a1 = d.a2 = 0;
-        d.b1 = d.b2 = n * n * g * t.sl;          // (the tables are relative to the slab's first pair)
-        d.c0 = n * n * g * t.sl;
+        d.b1 = d.b2 = t.ld * n * g * t.sl;       // (the tables are relative to the slab's first pair; columns are ld doubles long)
+        d.c0 = t.ld * n * g * t.sl;
         d.colB = tri ? t.colB_tri + t.cstart[(size_t)s0] : lo ? t.colB_lo + nlo * (s0 - g * t.sl) : t.colB + n * (s0 - g * t.sl);
         d.offCn = tri ? t.offCn_tri + t.cstart[(size_t)s0] : lo ? t.offCn_lo + nlo * (s0 - g * t.sl) : t.offCn + n * (s0 - g * t.sl);
         d.N = (int)ncols(s0, s1);
@@ -541,28 +565,35 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
         // Pair symmetry: (ij|kl) is transformed for the n(n+1)/2 pairs k >= l only, the half-transformed (pq|kl) kept for
         // p >= q only -- 4 n^5 flop and two buffers of n^2 x npair instead of 8 n^5 and two of n^4.
         const int64_t np = n * (n + 1) / 2;
-        const bool have_u = ao == ctx->eri_ao_dev && ctx->half_n == n && ctx->half_epoch == cx.scratch_epoch;   // afesp_build_fock left (ij|KL)
+        const int64_t L = ao2mo_ld(n);   // leading dimension of the squared-up temporaries (and of what afesp_build_fock left)
+        const bool have_u = ao == ctx->eri_ao_dev && ctx->half_n == n && ctx->half_ld == L && ctx->half_epoch == cx.scratch_epoch;   // afesp_build_fock left (ij|KL)
         // slab by slab from temporaries of 16 GiB each (n >= 256): at n = 220 the blocked form is 5 % slower (58.9 against 55.8 ms:
         // one more pass over the half-transformed integrals) for 12.5 GB less -- it is there for the sizes where 2 n^2 npair
         // doubles no longer fit beside the rest (n = 400: 2 x 103 GB)
-        const bool blocked = knobs().ao2mo_blocked >= 0 ? knobs().ao2mo_blocked == 1 : n * n * np >= ((int64_t)1 << 31);
+        const bool blocked = ao2mo_blocked(n);
         if (!blocked) {
             // Small bases: the whole tensor at once, nine launches.  The two temporaries are cached scratch: a second transform in
             // the same context reuses them, the next afesp_ccsd_init / afesp_ccsd_so_init gives them back.
             // (16 doubles of slack behind each: the LDS-DMA GEMM reads whole 16-element K steps, i.e. up to Kc - n elements past a
             // column's end -- the next column's, finite, times the zero padding of C -- and past the tensor's end behind the last one)
-            Tensor Ta = view(cx.scratch("ao2mo_a", n * n * np + 16), {n, n, np}), Tb = view(cx.scratch("ao2mo_b", n * n * np + 16), {n, n, np});
-            // the LDS-DMA GEMM: even n, and from n = 96 on (its tile has 128 rows: below that most of a tile is padding and
-            // the transform is launch-bound anyway); AFESP_AO2MO_TG=0 / 1: never / for every even n >= 16 (tests, A/B runs)
-            const bool use_tg = n % 2 == 0 && n >= 16 && (knobs().ao2mo_tg >= 0 ? knobs().ao2mo_tg == 1 : n >= 96);
+            // (the LDS-DMA form: columns of L = 16 ceil(n / 16) doubles, ao2mo_ld)
+            Tensor Ta = view(cx.scratch("ao2mo_a", L * n * np + 16), {n, n, np}), Tb = view(cx.scratch("ao2mo_b", L * n * np + 16), {n, n, np});
+            const bool use_tg = ao2mo_use_tg(n);
             // up to 64 basis functions: the LDS-resident pair transform (AFESP_AO2MO_PAIR=0: the gather-GEMM form)
             const bool pair_path = n <= 64 && !use_tg && knobs().ao2mo_pair;
-            if (!have_u && !pair_path) k_unpack_half(cx, Ta.d, ao, (int)n);   // (ij|KL), ij squared up
+            if (!have_u && !pair_path) k_unpack_half(cx, Ta.d, ao, (int)n, 0, -1, (int)L);   // (ij|KL), ij squared up
             ctx->half_n = 0;                                             // the transform overwrites it
             if (use_tg) {
-                AFESP_HIP(hipMemsetAsync(Ta.d + n * n * np, 0, 16 * sizeof(double), cx.stream));
-                AFESP_HIP(hipMemsetAsync(Tb.d + n * n * np, 0, 16 * sizeof(double), cx.stream));
-                Ao2moTg tg = ao2mo_tg_prepare(cx, Cm.d, n, np);
+                AFESP_HIP(hipMemsetAsync(Ta.d + L * n * np, 0, 16 * sizeof(double), cx.stream));
+                AFESP_HIP(hipMemsetAsync(Tb.d + L * n * np, 0, 16 * sizeof(double), cx.stream));
+                // (rows n .. L - 1 of every column are K padding of the products -- read, times the zero padding of C: finite, so zero.
+                // No kernel of this form or of afesp_build_fock writes them, so they are zeroed once per (buffers, n, L): 0.2 ms each)
+                if (ctx->pad_a != Ta.d || ctx->pad_b != Tb.d || ctx->pad_n != n || ctx->pad_ld != L || ctx->pad_epoch != cx.scratch_epoch) {
+                    k_pad_rows_zero(cx, Ta.d, (int)n, (int)L, n * np);
+                    k_pad_rows_zero(cx, Tb.d, (int)n, (int)L, n * np);
+                    ctx->pad_a = Ta.d; ctx->pad_b = Tb.d; ctx->pad_n = n; ctx->pad_ld = L; ctx->pad_epoch = cx.scratch_epoch;
+                }
+                Ao2moTg tg = ao2mo_tg_prepare(cx, Cm.d, n, np, L);
                 ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, 0, np, n, 0);         // (ij|K) -> (j p|K)        mp2.f90:321-333
                 // (jp|K) -> (x2 m|K), mp2.f90:338-348: the transposition below reads x2 <= m only -- the rows m < 128 are computed
                 // for the columns x2 < 128 only
@@ -572,7 +603,7 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
                 } else {
                     ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, 0, np, n, 0);
                 }
-                k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                // (kl|PQ), kl squared up, p >= q
+                k_pair_transpose(cx, Tb.d, Ta.d, (int)n, (int)L);       // (kl|PQ), kl squared up, p >= q
                 // Second pair: only (rs|PQ) with RS <= PQ is packed (mp2.f90:388-410), i.e. r <= p and s <= r.  Rows beyond the
                 // first 128 are therefore skipped for the pairs with p < 128, and the last transform runs over the columns
                 // (r, PQ) with r <= p only -- 2.6 n^5 flop in 128-row tiles instead of 4 (the reference: 8).
@@ -581,9 +612,10 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
                 ao2mo_tg_xform(cx, tg, Tb.d, Ta.d, ps, np, n, 0);
                 ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, 0, ps, m_lo, 1);      // (lr|P) -> (r s|P)        mp2.f90:375-385
                 ao2mo_tg_xform(cx, tg, Ta.d, Tb.d, ps, np, n, 1);
-                k_pack_pairs(cx, packed, Tb.d, (int)n);                  // mp2.f90:388-410
+                k_pack_pairs(cx, packed, Tb.d, (int)n, 0, -1, (int)L);   // mp2.f90:388-410
                 cx.sync();                                               // (the descriptors' host copies die with tg)
             } else if (pair_path) {
+                ctx->pad_n = 0;   // (this form writes the temporaries densely: whatever padding rows another form had zeroed are data now)
                 // up to 64 basis functions (every bundled input, the H2O/cc-pVTZ shape): both quarter transforms of a pair index in one
                 // kernel with the n x n block resident in LDS -- five launches for the whole transform (AFESP_AO2MO_PAIR=0: the
                 // gather-GEMM form below)
@@ -593,6 +625,7 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
                 k_square_transpose(cx, Ta.d, Tb.d, np);                      // g(K, PQ)
                 k_pair_xform(cx, packed, Ta.d, Cm.d, (int)n, np, 2);         // (kl|P) -> (rs|P), RS <= P  mp2.f90:357-410
             } else {
+                ctx->pad_n = 0;
                 contract(cx, 1.0, Cm, "pi", Ta, "ijK", 0.0, Tb, "pjK");      // mp2.f90:321-333
                 contract(cx, 1.0, Cm, "qj", Tb, "pjK", 0.0, Ta, "pqK");      // mp2.f90:338-348
                 k_pair_transpose(cx, Tb.d, Ta.d, (int)n);                    // (kl|PQ), kl squared up, p >= q
@@ -605,6 +638,7 @@ int afesp_ao2mo_mp2(afesp_ctx* ctx, int64_t nbasis, int64_t nocc, const double* 
             // (pq) pair, so only the half-transformed integrals have to exist as a whole -- pair-packed, g(PQ,K), np^2 doubles
             // (4.7 GB at n = 220) -- and the n^2 npair temporaries (2 x 9.4 GB) shrink to two slabs of S pairs.  S is chosen so
             // that a slab's column tiles fill whole rounds of the persistent GEMM grid.
+            ctx->pad_n = 0;
             int64_t S = std::max<int64_t>(16, ((int64_t)256 * 128 * 14 / n) / 16 * 16);
             if (S > np) S = (np + 15) / 16 * 16;
             double* g = cx.scratch("ao2mo_g", np * np);
@@ -1064,16 +1098,18 @@ int afesp_build_fock(afesp_ctx* ctx, int64_t nbasis, const double* density, cons
         AFESP_HIP(hipMemcpyAsync(buf + n2, core_hamil, sizeof(double) * n2, hipMemcpyHostToDevice, cx.stream));
         // the half-unpacked integrals (ij|KL) live in the scratch buffer the AO->MO transform starts from ("ao2mo_a"): built on
         // the first Fock build of an SCF, reused by every later one and by afesp_ao2mo_mp2
-        const int64_t np = nbasis * (nbasis + 1) / 2;
-        double* u = cx.scratch("ao2mo_a", n2 * np + 16);   // (+16: the size afesp_ao2mo_mp2 asks for, so that it finds this very buffer)
-        if (ctx->half_n != nbasis || ctx->half_epoch != cx.scratch_epoch) {
-            k_unpack_half(cx, u, ctx->eri_ao_dev, (int)nbasis);
+        const int64_t np = nbasis * (nbasis + 1) / 2, L = ao2mo_ld(nbasis);   // (columns as afesp_ao2mo_mp2 will want them)
+        double* u = cx.scratch("ao2mo_a", L * nbasis * np + 16);   // (+16: the size afesp_ao2mo_mp2 asks for, so that it finds this very buffer)
+        if (ctx->half_n != nbasis || ctx->half_ld != L || ctx->half_epoch != cx.scratch_epoch) {
+            if (ctx->pad_n != nbasis || ctx->pad_ld != L) ctx->pad_n = 0;   // (another layout lands in the buffer the transforms share)
+            k_unpack_half(cx, u, ctx->eri_ao_dev, (int)nbasis, 0, -1, (int)L);
             ctx->half_n = nbasis;
+            ctx->half_ld = L;
             ctx->half_epoch = cx.scratch_epoch;
         }
         double* work = cx.scratch("fock_work", k_build_fock_work((int)nbasis));
         ctx->half_epoch = cx.scratch_epoch;   // (growing fock_work moves the epoch, not u)
-        k_build_fock(cx, buf + 2 * n2, buf + n2, buf, u, work, (int)nbasis);
+        k_build_fock(cx, buf + 2 * n2, buf + n2, buf, u, work, (int)nbasis, (int)L);
         AFESP_HIP(hipMemcpyAsync(fock, buf + 2 * n2, sizeof(double) * n2, hipMemcpyDeviceToHost, cx.stream));
         cx.sync();
     });

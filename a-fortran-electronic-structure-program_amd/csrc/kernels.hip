@@ -335,21 +335,24 @@ __global__ void fock_dv_kernel(double* dv, const double* dens, int n)
         dv[p] = a == b ? dens[a + (int64_t)n * a] : dens[a + (int64_t)n * b] + dens[b + (int64_t)n * a];
     }
 }
-__global__ __launch_bounds__(256) void fock_j_kernel(double* jpart, const double* u, const double* dv, int n)
+// (ld: leading dimension of u(x, y, P), n or -- where afesp_ao2mo_mp2 will run its transforms on the LDS-DMA GEMM -- n rounded up to
+// whole K steps, afesp_internal.h: ao2mo_ld)
+__global__ __launch_bounds__(256) void fock_j_kernel(double* jpart, const double* u, const double* dv, int n, int ld)
 {
-    const int64_t n2 = (int64_t)n * n, np = (int64_t)n * (n + 1) / 2;
+    const int64_t n2 = (int64_t)n * n, np = (int64_t)n * (n + 1) / 2, pl = (int64_t)ld * n;
     const int64_t xy = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t per = (np + FOCK_CHUNKS - 1) / FOCK_CHUNKS, p0 = blockIdx.y * per, p1 = p0 + per < np ? p0 + per : np;
     if (xy >= n2) return;
+    const int64_t at = xy % n + (int64_t)ld * (xy / n);
     double acc = 0.0;
 #pragma unroll 8
-    for (int64_t p = p0; p < p1; ++p) acc += u[xy + n2 * p] * dv[p];
+    for (int64_t p = p0; p < p1; ++p) acc += u[at + pl * p] * dv[p];
     jpart[(int64_t)blockIdx.y * n2 + xy] = acc;
 }
-__global__ __launch_bounds__(256) void fock_k_kernel(double* kp1, double* kp2, const double* u, const double* dens, int n)
+__global__ __launch_bounds__(256) void fock_k_kernel(double* kp1, double* kp2, const double* u, const double* dens, int n, int ld)
 {
     extern __shared__ double dcol[];   // D(:,b) then D(:,a)
-    const int64_t n2 = (int64_t)n * n, p = blockIdx.x;
+    const int64_t n2 = (int64_t)ld * n, p = blockIdx.x;
     int b, a;
     unpair(p, b, a);
     for (int y = threadIdx.x; y < n; y += 256) {
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256) void fock_k_kernel(double* kp1, double* kp2, c
         double w1 = 0.0, w2 = 0.0;
 #pragma unroll 8
         for (int y = 0; y < n; ++y) {
-            const double v = m[x + (int64_t)n * y];
+            const double v = m[x + (int64_t)ld * y];
             w1 += v * dcol[y];
             w2 += v * dcol[n + y];
         }
@@ -1074,12 +1077,15 @@ void k_lincomb(Context& cx, double* out, const double* xbase, int64_t xstride, c
 //   MODE 2  out(k,l,P) = g(P, tri(k,l)), g a plain [np x np] array         the same from the pair-packed half-transformed integrals
 // The C blocks [c_begin, c_end) of the result are produced (c_begin a multiple of 16), at out(x,y,C - c_begin): the blocked
 // transform of afesp_ao2mo_mp2 works on slabs of C.
+// ld >= n: leading dimension of `out` (and of MODE 1's source): the LDS-DMA transforms of a basis size that is no multiple of 16 keep
+// their temporaries with columns of ld = 16 ceil(n / 16) doubles, so that every column -- a 128-byte line per K step of the GEMM,
+// a 128-byte run of this kernel -- starts on a line (round 6; n = 220: 39.2 -> 36 ms per transform).
 template <int MODE>
-__global__ __launch_bounds__(256) void pair_square_kernel(double* out, const double* src, int n, int64_t c_begin, int64_t c_end)
+__global__ __launch_bounds__(256) void pair_square_kernel(double* out, const double* src, int n, int64_t c_begin, int64_t c_end, int ld)
 {
     constexpr int T = 16, TP = T + 1, SC = T * TP + 3;   // rows padded: the mirrored tile is read out of LDS along y
     __shared__ double tile[T * SC];
-    const int64_t N = n, np = N * (N + 1) / 2;
+    const int64_t N = n, np = N * (N + 1) / 2, L = ld;
     const int nb = (n + T - 1) / T, nbp = nb * (nb + 1) / 2;
     // a workgroup owns the tile pair (x-block xb >= y-block yb) of one C block: src(C, tri(x,y)) is read once and written
     // to out(x,y,C) and to its mirror image out(y,x,C)
@@ -1097,7 +1103,7 @@ __global__ __launch_bounds__(256) void pair_square_kernel(double* out, const dou
     if (MODE == 1 && c0 + lane < c_end) {
         int q, p;
         unpair(c0 + lane, q, p);
-        pq_off = q + N * p;
+        pq_off = q + L * p;
     }
 #pragma unroll 4
     for (int it = 0; it < T; ++it) {
@@ -1105,7 +1111,7 @@ __global__ __launch_bounds__(256) void pair_square_kernel(double* out, const dou
         const int X = x0 + xi, Y = y0 + yi;
         if (X < n && Y < n && c0 + c < c_end)
             tile[c * SC + yi * TP + xi] = MODE == 0 ? src[tri(tri(X, Y), c0 + c)]
-                                        : MODE == 1 ? src[pq_off + N * N * tri(X, Y)] : src[(c0 + c) + np * tri(X, Y)];
+                                        : MODE == 1 ? src[pq_off + L * N * tri(X, Y)] : src[(c0 + c) + np * tri(X, Y)];
     }
     __syncthreads();
     const int64_t cr = c0 - c_begin;   // position of the block in the slab
@@ -1114,7 +1120,7 @@ __global__ __launch_bounds__(256) void pair_square_kernel(double* out, const dou
         if (X < n && Y < n) {
 #pragma unroll 4
             for (int c = 0; c < T; ++c)
-                if (c0 + c < c_end) out[X + N * Y + N * N * (cr + c)] = tile[c * SC + row * TP + lane];
+                if (c0 + c < c_end) out[X + L * Y + L * N * (cr + c)] = tile[c * SC + row * TP + lane];
         }
     }
     if (xb != yb) {
@@ -1122,22 +1128,22 @@ __global__ __launch_bounds__(256) void pair_square_kernel(double* out, const dou
         if (X < n && Y < n) {
 #pragma unroll 4
             for (int c = 0; c < T; ++c)
-                if (c0 + c < c_end) out[X + N * Y + N * N * (cr + c)] = tile[c * SC + lane * TP + row];
+                if (c0 + c < c_end) out[X + L * Y + L * N * (cr + c)] = tile[c * SC + lane * TP + row];
         }
     }
 }
 // packed[tri(PQ,RS)] = full(s,r,PQ - p_begin) for RS = tri(r,s) <= PQ, PQ in [p_begin, p_end)  (mp2.f90:388-410 on the
 // pair-packed result; the whole range in one call, or slab by slab)
-__global__ void pack_pairs_kernel(double* packed, const double* full, int n, int64_t p_begin, int64_t p_end)
+__global__ void pack_pairs_kernel(double* packed, const double* full, int n, int64_t p_begin, int64_t p_end, int ld)
 {
-    const int64_t N = n, np = N * (N + 1) / 2, tot = np * (p_end - p_begin);
+    const int64_t N = n, np = N * (N + 1) / 2, tot = np * (p_end - p_begin), L = ld;
     GRID_STRIDE(x, tot)
     {
         const int64_t rs = x % np, pq = p_begin + x / np;
         if (rs > pq) continue;
         int s_, r_;
         unpair(rs, s_, r_);
-        packed[pq * (pq + 1) / 2 + rs] = full[s_ + N * r_ + N * N * (pq - p_begin)];
+        packed[pq * (pq + 1) / 2 + rs] = full[s_ + L * r_ + L * N * (pq - p_begin)];
     }
 }
 // g(PQ, K) = half(q, p, K - k_begin), PQ = tri(p,q) over p >= q, K in [k_begin, k_end): the half-transformed integrals of a slab
@@ -1158,11 +1164,21 @@ static unsigned pair_square_grid(int n, int64_t c_begin, int64_t c_end)
     const int64_t nb = (n + 15) / 16;
     return (unsigned)(nb * (nb + 1) / 2 * ((c_end - c_begin + 15) / 16));
 }
-void k_unpack_half(Context& cx, double* u, const double* packed, int n, int64_t c_begin, int64_t c_end)
+void k_unpack_half(Context& cx, double* u, const double* packed, int n, int64_t c_begin, int64_t c_end, int ld)
 {
     const int64_t np = (int64_t)n * (n + 1) / 2;
     if (c_end < 0) c_end = np;
-    if (c_end > c_begin) LAUNCH(pair_square_kernel<0>, dim3(pair_square_grid(n, c_begin, c_end)), u, packed, n, c_begin, c_end);
+    if (c_end > c_begin) LAUNCH(pair_square_kernel<0>, dim3(pair_square_grid(n, c_begin, c_end)), u, packed, n, c_begin, c_end, ld > 0 ? ld : n);
+}
+// zeroes rows [n, ld) of every column of x(ld, ncol): the padding of the LDS-DMA transforms' temporaries (read as K padding, times zero)
+__global__ __launch_bounds__(256) void pad_rows_zero_kernel(double* x, int n, int ld, int64_t ncol)
+{
+    const int w = ld - n;
+    GRID_STRIDE(i, ncol * w) x[(i / w) * ld + n + (i % w)] = 0.0;
+}
+void k_pad_rows_zero(Context& cx, double* x, int n, int ld, int64_t ncol)
+{
+    if (ld > n && ncol > 0) LAUNCH(pad_rows_zero_kernel, dim3(grid_for(ncol * (ld - n), 65536)), x, n, ld, ncol);
 }
 // ---- both quarter transforms of a pair index in ONE kernel, for bases of up to 64 functions (mp2.f90:321-348 resp. :357-385):
 //   out(:, :, S) = C in(:, :, S) C^T   for every pair S, in(:, :, S) symmetric
@@ -1307,25 +1323,25 @@ void k_square_transpose(Context& cx, double* out, const double* in, int64_t n)
     const int64_t tiles = (n + 31) / 32;
     if (n > 0) LAUNCH(square_transpose_kernel, dim3((unsigned)(tiles * tiles)), out, in, n);
 }
-void k_pair_transpose(Context& cx, double* out, const double* in, int n)
+void k_pair_transpose(Context& cx, double* out, const double* in, int n, int ld)
 {
     const int64_t np = (int64_t)n * (n + 1) / 2;
-    LAUNCH(pair_square_kernel<1>, dim3(pair_square_grid(n, 0, np)), out, in, n, (int64_t)0, np);
+    LAUNCH(pair_square_kernel<1>, dim3(pair_square_grid(n, 0, np)), out, in, n, (int64_t)0, np, ld > 0 ? ld : n);
 }
 void k_pair_square_packed(Context& cx, double* out, const double* g, int n, int64_t c_begin, int64_t c_end)
 {
-    if (c_end > c_begin) LAUNCH(pair_square_kernel<2>, dim3(pair_square_grid(n, c_begin, c_end)), out, g, n, c_begin, c_end);
+    if (c_end > c_begin) LAUNCH(pair_square_kernel<2>, dim3(pair_square_grid(n, c_begin, c_end)), out, g, n, c_begin, c_end, n);
 }
 void k_tri_pack(Context& cx, double* g, const double* half, int n, int64_t k_begin, int64_t k_end)
 {
     const int64_t np = (int64_t)n * (n + 1) / 2;
     if (k_end > k_begin) LAUNCH(tri_pack_kernel, dim3(grid_for(np * (k_end - k_begin), 65536)), g, half, n, k_begin, k_end);
 }
-void k_pack_pairs(Context& cx, double* packed, const double* full, int n, int64_t p_begin, int64_t p_end)
+void k_pack_pairs(Context& cx, double* packed, const double* full, int n, int64_t p_begin, int64_t p_end, int ld)
 {
     const int64_t np = (int64_t)n * (n + 1) / 2;
     if (p_end < 0) p_end = np;
-    if (p_end > p_begin) LAUNCH(pack_pairs_kernel, dim3(grid_for(np * (p_end - p_begin), 65536)), packed, full, n, p_begin, p_end);
+    if (p_end > p_begin) LAUNCH(pack_pairs_kernel, dim3(grid_for(np * (p_end - p_begin), 65536)), packed, full, n, p_begin, p_end, ld > 0 ? ld : n);
 }
 void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1, int d2, int d3, int b0, int b1, int b2, int b3)
 {
@@ -1333,14 +1349,15 @@ void k_slice_phys(Context& cx, double* out, const double* packed, int d0, int d1
     if (n > 0) LAUNCH(slice_phys_kernel, dim3(grid_for(n, 65536)), out, packed, d0, d1, d2, d3, b0, b1, b2, b3);
 }
 
-void k_build_fock(Context& cx, double* fock, const double* hcore, const double* dens, const double* u, double* work, int n)
+void k_build_fock(Context& cx, double* fock, const double* hcore, const double* dens, const double* u, double* work, int n, int ld)
 {
+    if (ld <= 0) ld = n;
     // work: [ dv (npair) | jpart (FOCK_CHUNKS n^2) | kp1 (npair n) | kp2 (npair n) ]
     const int64_t n2 = (int64_t)n * n, np = (int64_t)n * (n + 1) / 2;
     double *dv = work, *jpart = dv + np, *kp1 = jpart + FOCK_CHUNKS * n2, *kp2 = kp1 + np * n;
     LAUNCH(fock_dv_kernel, dim3(grid_for(np)), dv, dens, n);
-    LAUNCH(fock_j_kernel, dim3((unsigned)((n2 + 255) / 256), FOCK_CHUNKS), jpart, u, dv, n);
-    AFESP_KLAUNCH(fock_k_kernel, dim3((unsigned)np), dim3(256), 2 * n * sizeof(double), cx.stream, kp1, kp2, u, dens, n);
+    LAUNCH(fock_j_kernel, dim3((unsigned)((n2 + 255) / 256), FOCK_CHUNKS), jpart, u, dv, n, ld);
+    AFESP_KLAUNCH(fock_k_kernel, dim3((unsigned)np), dim3(256), 2 * n * sizeof(double), cx.stream, kp1, kp2, u, dens, n, ld);
     AFESP_HIP(hipGetLastError());
     LAUNCH(fock_reduce_kernel, dim3(grid_for(n2)), fock, hcore, jpart, kp1, kp2, n);
 }

@@ -50,6 +50,7 @@ struct Knobs {
     int ao2mo_tg = -1;                      // AFESP_AO2MO_TG=0/1   quarter transforms never / always on the LDS-DMA GEMM (default: even n >= 96)
     bool ao2mo_pair = true;                 // AFESP_AO2MO_PAIR=0   n <= 64: gather-GEMM form instead of the LDS-resident pair transform
     bool ao2mo_mixed = true;                // AFESP_AO2MO_MIXED=0  128-row tiles only
+    bool ao2mo_pad = true;                  // AFESP_AO2MO_PAD=0    LDS-DMA transforms: temporaries with columns of n doubles instead of 16 ceil(n / 16)
     int ao2mo_blocked = -1;                 // AFESP_AO2MO_BLOCKED=0/1  whole tensor / slab by slab (default: by size)
     bool mp2_packed = true;                 // AFESP_MP2_PACKED=0   the five-launch MP2 energy at every size
     bool no_graph = false;                  // AFESP_NO_GRAPH=1     call-by-call small path: never capture a graph
@@ -114,6 +115,7 @@ inline void parse(Knobs& k)
     if ((e = get("AFESP_AO2MO_TG"))) k.ao2mo_tg = e[0] == '1' ? 1 : 0;
     k.ao2mo_pair = !is("AFESP_AO2MO_PAIR", '0');
     k.ao2mo_mixed = !is("AFESP_AO2MO_MIXED", '0');
+    k.ao2mo_pad = !is("AFESP_AO2MO_PAD", '0');
     if ((e = get("AFESP_AO2MO_BLOCKED"))) k.ao2mo_blocked = e[0] == '1' ? 1 : 0;
     k.mp2_packed = !is("AFESP_MP2_PACKED", '0');
     k.no_graph = is("AFESP_NO_GRAPH", '1');

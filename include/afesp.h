@@ -24,7 +24,7 @@
  *     tests use them to send a small system down a large system's path or to hold two forms of one product against each other; not
  *     for production use):  AFESP_SMALL_MAX, AFESP_NO_LANES, AFESP_FUSED, AFESP_FUSED_LANES, AFESP_PP_SYM, AFESP_RING_TG,
  *     AFESP_RING_TG_MIN, AFESP_RING_PACK, AFESP_LARGE_TAIL, AFESP_TALL, AFESP_TALL_MIN, AFESP_TALL_DUAL, AFESP_GETT_SK, AFESP_T_GEMM,
- *     AFESP_T_ONE_POOL, AFESP_CC_REINIT, AFESP_CC_SHARD, AFESP_CC_TIME_SLICE, AFESP_AO2MO_TG, AFESP_AO2MO_PAIR, AFESP_AO2MO_MIXED,
+ *     AFESP_T_ONE_POOL, AFESP_CC_REINIT, AFESP_CC_SHARD, AFESP_CC_TIME_SLICE, AFESP_AO2MO_TG, AFESP_AO2MO_PAIR, AFESP_AO2MO_MIXED, AFESP_AO2MO_PAD,
  *     AFESP_AO2MO_BLOCKED, AFESP_MP2_PACKED, AFESP_NO_GRAPH, AFESP_GRAPH_AFTER, AFESP_NO_PRELOAD, AFESP_PRELOAD_LANES,
  *     AFESP_PRELOAD_GETT, AFESP_PLAN_VERIFY
  *   tuning (tile / slice / pool sizes, scheduling):  AFESP_PP_SPLIT, AFESP_PP_TILES, AFESP_REPACK_MIN, AFESP_PLAN_DEVICE_FROM,
