@@ -707,6 +707,11 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             roof["flop_per_launch_padded"] = prof.get("gemm_flop_padded", 0.0) / nl
             roof["achieved_padded"] = prof.get("gemm_flop_padded", 0.0) / max(prof["gemm_ms"], 1e-9) / 1e9
             roof["share_of_step_time"] = prof["gemm_ms"] * 1e-3 / elapsed
+            # what the traffic below is held against: every Y block written once (the orbit kernel's bytes) + both operand sets read once
+            # (vt, vtT: 2 Kc v^2 o doubles; tt: Kc v o^2), per launch
+            kc, vp = (v + o + 15) // 16 * 16, (v + 7) // 8 * 8
+            c_bytes = 8.0 * vp**3 * (o * o * (o + 1) // 2) if world == 1 else prof["orbit_bytes"]   # distinct blocks Y^{p;qr}, q <= r (one rank: all of them)
+            roof["traffic_algorithmic"] = (c_bytes + 8.0 * (2 * kc * v * v * o + kc * v * o * o)) / nl
             tfile = latest_profile("traffic.json")
             live = live_pmc(workload) if (args.live_pmc and world == 1 and workload == args.workload) else None
             if live:
