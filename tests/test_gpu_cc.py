@@ -397,6 +397,13 @@ def test_ao2mo_on_the_lds_dma_gemm(n, o, monkeypatch):
                 eng.build_fock(n, np.eye(n), np.zeros((n, n)))
                 e3, third = eng.do_mp2_spatial(n, o, c, e, None)
                 assert np.array_equal(third, got[mode][1]) and e3 == got[mode][0]
+                # (round 6) the temporaries' columns are 16 ceil(n / 16) doubles long -- the same sums in the same order as with columns of n
+                monkeypatch.setenv("AFESP_AO2MO_PAD", "0")
+                e4, fourth = eng.do_mp2_spatial(n, o, c, e, eri)
+                monkeypatch.delenv("AFESP_AO2MO_PAD")
+                assert np.array_equal(fourth, got[mode][1]) and e4 == got[mode][0]
+                e5, fifth = eng.do_mp2_spatial(n, o, c, e, eri)      # ... and back: the padding rows are zeroed again
+                assert np.array_equal(fifth, got[mode][1]) and e5 == got[mode][0]
     scale = max(1.0, np.max(np.abs(got["0"][1])))
     assert np.max(np.abs(got["1"][1] - got["0"][1])) < 1e-11 * scale
     assert abs(got["1"][0] - got["0"][0]) < 1e-10 * max(1.0, abs(got["0"][0]))
