@@ -711,7 +711,10 @@ def measure(args, workload, steps, warmup, rank, world, local, dist, cdev, torch
             # (vt, vtT: 2 Kc v^2 o doubles; tt: Kc v o^2), per launch
             kc, vp = (v + o + 15) // 16 * 16, (v + 7) // 8 * 8
             c_bytes = 8.0 * vp**3 * (o * o * (o + 1) // 2) if world == 1 else prof["orbit_bytes"]   # distinct blocks Y^{p;qr}, q <= r (one rank: all of them)
-            roof["traffic_algorithmic"] = (c_bytes + 8.0 * (2 * kc * v * v * o + kc * v * o * o)) / nl
+            launches_per_t = max(nl / max(steps, 1), 1.0)   # (nl counts the launches of all timed steps)
+            if world != 1:
+                c_bytes /= max(steps, 1)                     # (orbit_bytes: summed over the timed steps too)
+            roof["traffic_algorithmic"] = (c_bytes + 8.0 * (2 * kc * v * v * o + kc * v * o * o)) / launches_per_t
             tfile = latest_profile("traffic.json")
             live = live_pmc(workload) if (args.live_pmc and world == 1 and workload == args.workload) else None
             if live:
