@@ -161,3 +161,22 @@ def test_ring_launches_give_way_to_the_gather_kernel_at_the_row_offset_bound(mon
         assert L.afesp_test_ring_path(o, v) == (1 if ov >= 3584 and 8 * kc * ov < 2**32 - 4096 else 0), (o, v)
     monkeypatch.setenv("AFESP_RING_TG", "0")
     assert L.afesp_test_ring_path(20, 200) == 0
+
+
+def test_every_environment_variable_is_defined_in_one_place_and_listed_in_the_header():
+    """csrc/knobs.h is the only file of the library that reads the environment; the AFESP_* names it parses are exactly the ones
+    include/afesp.h lists (test-only path selectors, tuning, diagnostics) -- plus AFESP_SO_FOO_AS_PUBLISHED / AFESP_LIBRARY, which belong
+    to the hosts, not to the library."""
+    import re
+    csrc = os.path.join(ROOT, "a-fortran-electronic-structure-program_amd", "csrc")
+    readers = []
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h")) and fn != "knobs.h":
+            if re.search(r"\bgetenv\s*\(", open(os.path.join(csrc, fn)).read()):
+                readers.append(fn)
+    assert readers == [], readers
+    parsed = set(re.findall(r'"(AFESP_[A-Z0-9_]+)"', open(os.path.join(csrc, "knobs.h")).read()))
+    header = open(os.path.join(ROOT, "include", "afesp.h")).read()
+    block = header[header.index("Environment variables."):header.index("#ifndef AFESP_H")]
+    listed = set(re.findall(r"AFESP_[A-Z0-9_]+", block)) - {"AFESP_H"}
+    assert parsed == listed, (sorted(parsed - listed), sorted(listed - parsed))
