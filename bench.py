@@ -422,7 +422,7 @@ class Reducer:
 
         th = threading.Thread(target=run, daemon=True)
         th.start()
-        th.join(timeout=float(os.environ.get("AFESP_BENCH_PROBE_TIMEOUT", "90")))
+        th.join(timeout=float(os.environ.get("AFESP_BENCH_PROBE_TIMEOUT", "180")))
         w = self.world
         if th.is_alive():
             state = 2.0                                                            # still waiting in the library
